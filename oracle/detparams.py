@@ -1,0 +1,70 @@
+"""Deterministic, RNG-library-independent parameter and input fills.  TEST INFRASTRUCTURE ONLY.
+
+Full-size hash tables are far too large to commit as fixtures, so golden generation
+(``make_golden.py``, which fills the *reference's* modules) and the tests (which fill the oracle's
+and the HIP path's modules) regenerate identical values from an integer hash of the element index
+and a per-tensor key.  Pure numpy uint64 arithmetic: independent of torch's RNG implementation.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def unit_hash(n, key, offset=0):
+    """n floats in [0, 1), a function of (key, offset + i) only (splitmix64 finaliser)."""
+    i = np.arange(offset, offset + n, dtype=np.uint64)
+    k = np.uint64(zlib.crc32(key.encode()) if isinstance(key, str) else int(key))
+    with np.errstate(over="ignore"):
+        z = i * np.uint64(0x9E3779B97F4A7C15) + (k + np.uint64(1)) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+def det_uniform(shape, key, lo, hi):
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = unit_hash(n, key)
+    return torch.from_numpy((np.float32(lo) + np.float32(hi - lo) * u).astype(np.float32)).reshape(shape)
+
+
+def fill_model(model, seed=0, hash_amp=0.5, flow_out_amp=0.02):
+    """Fill every parameter of a LiDAR4D-shaped module tree (reference, oracle or HIP build: they
+    share state-dict keys) with values that make every branch of the path numerically visible:
+    hash tables U(-hash_amp, hash_amp); static planes U(0.1, 0.5); time planes U(0.8, 1.2);
+    MLP weight matrices U(-b, b) with b = sqrt(6 / (64 + 64)); flow output layer U(-a, a)."""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.numel() == 0 or name.startswith("unet."):
+                continue
+            key = f"{seed}:{name}"
+            if name.startswith("planes_encoder."):
+                is_time = name.split(".")[-1] in ("2", "4", "5")  # combs (0,3) (1,3) (2,3)
+                lo, hi = (0.8, 1.2) if is_time else (0.1, 0.5)
+            elif name.endswith("mlp.4.weight") or (name.startswith("flow_net.mlp") and p.shape[0] == 6):
+                lo, hi = -flow_out_amp, flow_out_amp
+            elif name.startswith("flow_net.mlp") or name.endswith("_net.params"):
+                b = float(np.sqrt(6.0 / 128.0))
+                lo, hi = -b, b
+            else:  # hash tables
+                lo, hi = -hash_amp, hash_amp
+            p.copy_(det_uniform(tuple(p.shape), key, lo, hi).to(p.dtype))
+    return model
+
+
+def grad_digest(model):
+    """Per-parameter (sum, sum|.|, dot with a deterministic probe vector) of ``.grad``: a compact,
+    order-independent-enough fingerprint of gradients too large to store."""
+    out = {}
+    for name, p in model.named_parameters():
+        if p.numel() == 0 or name.startswith("unet."):
+            continue
+        g = p.grad
+        if g is None:
+            out[name] = np.zeros(3, dtype=np.float64)
+            continue
+        g = g.detach().double().reshape(-1).cpu()
+        probe = torch.from_numpy(unit_hash(g.numel(), "probe:" + name)).double() - 0.5
+        out[name] = np.array([g.sum().item(), g.abs().sum().item(), (g * probe).sum().item()])
+    return out

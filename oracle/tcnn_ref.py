@@ -1,0 +1,282 @@
+"""Oracle restatement of the tiny-cuda-nn operators used by LiDAR4D.  TEST INFRASTRUCTURE ONLY.
+
+**Parity unpinned.**  tiny-cuda-nn (NVlabs, PyTorch extension ``tinycudann``) is an un-vendored,
+unpinned dependency of the reference (reference README.md:88-91 clones ``master``); it is not in
+/root/reference and cannot be installed here.  This file restates its *published* algorithm as
+recorded in SURVEY.md Appendix A (``encodings/grid.h``, ``encodings/frequency.h``,
+``src/fully_fused_mlp.cu``, ``bindings/torch/tinycudann/modules.py``) and presents it behind the
+same Python surface the reference binds (``Encoding``, ``Network``; reference call sites
+model/hash_field.py:47-57,107-117, model/flow_field.py:67-77, model/lidar4d.py:68-117).
+
+Precision modes (``set_precision``):
+
+``"tcnn"``  the rounding points of tiny-cuda-nn's fp16 build, which the HIP path reproduces:
+            (R1) parameters fp32 -> fp16 on every forward; (R2) every Encoding output -> fp16;
+            (R3) Network input -> fp16 (after padding with 1.0), every hidden activation -> fp16
+            after ReLU, output -> fp16.  All *accumulation* is fp32 (tiny-cuda-nn itself
+            accumulates in fp16; fp32 is strictly closer to the real-valued result).
+            Output tensors are fp16, as tiny-cuda-nn's are.
+``"fp32"``  no rounding anywhere, fp32 outputs: the idealised reference used to generate the
+            golden fixtures through the reference's own glue code and to bound the fp16 effect.
+
+Deliberate deviation (documented): the Frequency encoding is evaluated as the exact
+``sin(2^k*pi*x)`` / ``cos(2^k*pi*x)`` (fp64 here, exact range reduction + sinpi/cospi in the HIP
+kernel); tiny-cuda-nn uses the fast-math ``__sinf`` whose error at the top octaves is ~1e-3.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+_PRECISION = "tcnn"
+
+PRIMES = (1, 2654435761, 805459861, 3674653429, 2097192037, 1434869437, 2165219737)
+
+
+def set_precision(mode):
+    global _PRECISION
+    assert mode in ("tcnn", "fp32")
+    _PRECISION = mode
+
+
+def get_precision():
+    return _PRECISION
+
+
+class _RoundHalfSTE(torch.autograd.Function):
+    """fp32 -> fp16 -> fp32 rounding, identity in backward (straight-through)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def rh(x):
+    """Apply an fp16 rounding point when the oracle is in tcnn mode."""
+    if _PRECISION == "tcnn":
+        return _RoundHalfSTE.apply(x)
+    return x
+
+
+def _out(x):
+    """tcnn modules emit fp16 tensors; keep autograd alive through the cast."""
+    if _PRECISION == "tcnn":
+        return x.half()
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# HashGrid
+# ----------------------------------------------------------------------------------------------
+def grid_level_meta(n_dims, n_levels, log2_hashmap_size, base_resolution, per_level_scale):
+    """Per-level (scale, resolution, n_entries, entry offset, hashed?) exactly as tiny-cuda-nn's host
+    code derives them, in float32 arithmetic."""
+    f32 = np.float32
+    log2_pls = np.log2(f32(per_level_scale)).astype(f32)
+    scales, ress, sizes, offsets, hashed = [], [], [], [], []
+    off = 0
+    for lvl in range(n_levels):
+        scale = f32(np.exp2(f32(lvl) * log2_pls).astype(f32) * f32(base_resolution) - f32(1.0))
+        res = int(np.ceil(scale)) + 1
+        max_params = (2 ** 32 - 1) // 2
+        dense = res ** n_dims
+        n = max_params if float(dense) > float(max_params) else dense
+        n = (n + 7) // 8 * 8
+        n = min(n, 1 << log2_hashmap_size)
+        # tiny-cuda-nn grid_index(): stride walk decides dense vs hashed addressing
+        stride = 1
+        for _ in range(n_dims):
+            if stride > n:
+                break
+            stride = (stride * res) & 0xFFFFFFFF
+        scales.append(float(scale))
+        ress.append(res)
+        sizes.append(n)
+        offsets.append(off)
+        hashed.append(bool(n < stride))
+        off += n
+    return {
+        "scale": scales,
+        "res": ress,
+        "size": sizes,
+        "offset": offsets,
+        "hashed": hashed,
+        "n_entries": off,
+    }
+
+
+def hashgrid_corner_indices(x, meta, lvl, n_dims):
+    """Corner entry indices [P, 2^D] (int64, level-local) and weights [P, 2^D] (fp32) of one level."""
+    scale = torch.tensor(meta["scale"][lvl], dtype=torch.float32)
+    res = meta["res"][lvl]
+    n = meta["size"][lvl]
+    pos = x.float() * scale + 0.5  # fmaf(scale, x, 0.5)
+    cell = torch.floor(pos)
+    frac = pos - cell
+    cell_u = cell.to(torch.int64) & 0xFFFFFFFF  # (uint32)(int)floor: negatives wrap
+    idx_list, w_list = [], []
+    for c in range(1 << n_dims):
+        w = torch.ones_like(frac[:, 0])
+        g = []
+        for d in range(n_dims):
+            if (c >> d) & 1:
+                w = w * frac[:, d]
+                g.append((cell_u[:, d] + 1) & 0xFFFFFFFF)
+            else:
+                w = w * (1.0 - frac[:, d])
+                g.append(cell_u[:, d])
+        if meta["hashed"][lvl]:
+            h = torch.zeros_like(g[0])
+            for d in range(n_dims):
+                h = h ^ ((g[d] * PRIMES[d]) & 0xFFFFFFFF)
+            idx = h
+        else:
+            idx = torch.zeros_like(g[0])
+            stride = 1
+            for d in range(n_dims):
+                if stride > n:
+                    break
+                idx = (idx + g[d] * stride) & 0xFFFFFFFF
+                stride = (stride * res) & 0xFFFFFFFF
+        idx_list.append(idx % n)
+        w_list.append(w)
+    return torch.stack(idx_list, -1), torch.stack(w_list, -1)
+
+
+class HashGridRef(nn.Module):
+    """tcnn ``Encoding`` with ``otype: HashGrid`` (Hash grid type, Linear interpolation)."""
+
+    def __init__(self, n_input_dims, cfg, seed=1337):
+        super().__init__()
+        self.n_input_dims = n_input_dims
+        self.n_levels = int(cfg["n_levels"])
+        self.n_features = int(cfg["n_features_per_level"])
+        self.meta = grid_level_meta(
+            n_input_dims,
+            self.n_levels,
+            int(cfg["log2_hashmap_size"]),
+            int(cfg["base_resolution"]),
+            float(cfg["per_level_scale"]),
+        )
+        self.n_output_dims = self.n_levels * self.n_features
+        g = torch.Generator().manual_seed(seed)
+        p = (torch.rand(self.meta["n_entries"] * self.n_features, generator=g) * 2 - 1) * 1e-4
+        self.params = nn.Parameter(p)
+        self.loss_scale = 128.0
+        self.seed = seed
+
+    def forward(self, x):
+        x = x.to(torch.float32).contiguous()
+        table = rh(self.params).view(-1, self.n_features)
+        outs = []
+        for lvl in range(self.n_levels):
+            idx, w = hashgrid_corner_indices(x, self.meta, lvl, self.n_input_dims)
+            vals = table[self.meta["offset"][lvl] + idx]  # [P, 2^D, F]
+            outs.append((w.unsqueeze(-1) * vals).sum(1))
+        return _out(rh(torch.cat(outs, -1)))
+
+
+# ----------------------------------------------------------------------------------------------
+# Frequency
+# ----------------------------------------------------------------------------------------------
+class FrequencyRef(nn.Module):
+    """tcnn ``Encoding`` with ``otype: Frequency``: per input dim
+    [sin(2^0 pi x), cos(2^0 pi x), ..., sin(2^11 pi x), cos(2^11 pi x)]; ``degree`` is ignored."""
+
+    def __init__(self, n_input_dims, cfg):
+        super().__init__()
+        self.n_input_dims = n_input_dims
+        self.n_frequencies = int(cfg.get("n_frequencies", 12))
+        self.n_output_dims = n_input_dims * self.n_frequencies * 2
+        self.params = nn.Parameter(torch.zeros(0))
+        self.loss_scale = 128.0
+        self.seed = 1337
+
+    def forward(self, x):
+        x = x.to(torch.float32)
+        xd = x.double()
+        k = torch.arange(self.n_frequencies, dtype=torch.float64)
+        arg = xd.unsqueeze(-1) * torch.exp2(k) * math.pi  # [P, D, K]
+        out = torch.stack([torch.sin(arg), torch.cos(arg)], -1)  # [P, D, K, 2]
+        out = out.reshape(x.shape[0], -1).float()
+        return _out(rh(out))
+
+
+# ----------------------------------------------------------------------------------------------
+# FullyFusedMLP
+# ----------------------------------------------------------------------------------------------
+def mlp_layer_shapes(n_in, n_out, n_neurons, n_hidden_layers):
+    """[(rows, cols)] of the row-major weight matrices in tcnn's flat ``params`` order."""
+    in_pad = (n_in + 15) // 16 * 16
+    out_pad = (n_out + 15) // 16 * 16
+    shapes = [(n_neurons, in_pad)]
+    for _ in range(n_hidden_layers - 1):
+        shapes.append((n_neurons, n_neurons))
+    shapes.append((out_pad, n_neurons))
+    return shapes
+
+
+class FusedMLPRef(nn.Module):
+    """tcnn ``Network`` with ``otype: FullyFusedMLP``, ReLU hidden activation, no output activation,
+    no biases; input padded to a multiple of 16 with the constant 1.0."""
+
+    def __init__(self, n_input_dims, n_output_dims, cfg, seed=1337):
+        super().__init__()
+        assert cfg.get("activation", "ReLU") == "ReLU"
+        assert cfg.get("output_activation", "None") == "None"
+        self.n_input_dims = n_input_dims
+        self.n_output_dims = n_output_dims
+        self.n_neurons = int(cfg["n_neurons"])
+        self.n_hidden_layers = int(cfg["n_hidden_layers"])
+        self.shapes = mlp_layer_shapes(n_input_dims, n_output_dims, self.n_neurons, self.n_hidden_layers)
+        g = torch.Generator().manual_seed(seed)
+        chunks = []
+        for rows, cols in self.shapes:
+            bound = math.sqrt(6.0 / (rows + cols))
+            chunks.append((torch.rand(rows * cols, generator=g) * 2 - 1) * bound)
+        self.params = nn.Parameter(torch.cat(chunks))
+        self.loss_scale = 128.0
+        self.seed = seed
+
+    def weights(self):
+        ws, off = [], 0
+        p = rh(self.params)
+        for rows, cols in self.shapes:
+            ws.append(p[off:off + rows * cols].view(rows, cols))
+            off += rows * cols
+        return ws
+
+    def forward(self, x):
+        x = x.to(torch.float32)
+        in_pad = self.shapes[0][1]
+        if in_pad > x.shape[1]:
+            x = torch.cat([x, torch.ones(x.shape[0], in_pad - x.shape[1], dtype=x.dtype)], -1)
+        h = rh(x)
+        ws = self.weights()
+        for w in ws[:-1]:
+            h = rh(torch.relu(h @ w.t()))
+        y = rh(h @ ws[-1].t())
+        return _out(y[:, : self.n_output_dims])
+
+
+# ----------------------------------------------------------------------------------------------
+# tinycudann Python surface
+# ----------------------------------------------------------------------------------------------
+def Encoding(n_input_dims, encoding_config, dtype=None, seed=1337):
+    otype = encoding_config["otype"]
+    if otype == "HashGrid":
+        return HashGridRef(n_input_dims, encoding_config, seed=seed)
+    if otype == "Frequency":
+        return FrequencyRef(n_input_dims, encoding_config)
+    raise ValueError(f"oracle: unsupported encoding otype {otype!r}")
+
+
+def Network(n_input_dims, n_output_dims, network_config, seed=1337):
+    if network_config["otype"] != "FullyFusedMLP":
+        raise ValueError("oracle: only FullyFusedMLP is restated")
+    return FusedMLPRef(n_input_dims, n_output_dims, network_config, seed=seed)

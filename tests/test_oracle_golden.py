@@ -1,0 +1,181 @@
+"""Pin the oracle (oracle/fields_ref.py, oracle/rays_ref.py) against fixtures produced by the REAL
+reference modules (oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields_ref, rays_ref
+from oracle.detparams import det_uniform, fill_model, grad_digest
+from oracle.make_golden import SMALL_MODEL, test_rays as make_rays
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=2e-5, atol=1e-6):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (ref max {b.abs().max().item():.3e})"
+
+
+def test_lidar_rays(golden):
+    g = golden("rays_64x1024")
+    H, W = int(g["H"]), int(g["W"])
+    for b in range(2):
+        ro, rd = rays_ref.lidar_rays(g["poses"][b], g["fov"][0], g["fov"][1], H, W)
+        close(ro[T(g["sel"])], g["rays_o"][b], rtol=1e-6)
+        close(rd[T(g["sel"])], g["rays_d"][b], rtol=1e-6, atol=1e-6)
+        close(rd.double().sum(0), g["rays_d_sum"][b], rtol=1e-9, atol=1e-3)
+        close(rd.double().abs().sum(0), g["rays_d_abs_sum"][b], rtol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["plain", "active_perturb", "tightbound"])
+def test_run_analytic(golden, fp32_oracle, tag):
+    g = golden("run_analytic_" + tag)
+
+    class Analytic(fields_ref.LiDAR4D):
+        def __init__(self, **kw):
+            torch.nn.Module.__init__(self)
+            self.bound, self.near_lidar, self.far_lidar = kw["bound"], kw["near"], kw["far"]
+            self.density_scale, self.active_sensor = kw["density_scale"], kw["active"]
+            self.register_buffer("aabb", torch.FloatTensor([-self.bound] * 3 + [self.bound] * 3))
+            self.out_lidar_dim = 2
+
+        def density(self, x, t):
+            r2 = ((x - torch.tensor([0.2, 0.1, -0.05])) ** 2).sum(-1)
+            return {"sigma": 400.0 * torch.exp(-r2 / 0.02) + 0.3, "geo_feat": torch.stack([x[:, 0], x[:, 1] * 2], -1)}
+
+        def attribute(self, x, d, mask=None, geo_feat=None):
+            out = torch.zeros(x.shape[0], 2)
+            a = torch.stack([torch.sigmoid(geo_feat[:, 0] * 3 + d[:, 0]), torch.sigmoid(geo_feat[:, 1] - d[:, 2])], -1)
+            out[mask] = a[mask]
+            return out
+
+    m = Analytic(bound=float(g["bound"]), near=float(g["near"]), far=float(g["far"]),
+                 density_scale=float(g["density_scale"]), active=bool(g["active"]))
+    out = m.run(T(g["rays_o"]), T(g["rays_d"]), torch.tensor([[0.3]]), num_steps=768,
+                perturb=bool(g["perturb"]), noise=T(g["noise"]))
+    assert torch.equal(out["z_vals"], T(g["z_vals"])), "z_vals must be bit-exact (sample positions)"
+    close(out["weights"], g["weights"], rtol=1e-6, atol=1e-12)
+    close(out["depth_lidar"], g["depth"], rtol=1e-6)
+    close(out["image_lidar"], g["image"], rtol=1e-6)
+    close(out["weights_sum_lidar"], g["weights_sum"], rtol=1e-6)
+    assert torch.equal(torch.nonzero(out["mask"].reshape(-1)).reshape(-1), T(g["mask_idx"]))
+
+
+def test_planes4d(golden, fp32_oracle):
+    g = golden("planes4d")
+    pl = fields_ref.Planes4D(output_dim=8, resolution=(8, 8, 8, 8), multiscale_res=(1, 2, 4))
+    with torch.no_grad():
+        for n, p in pl.named_parameters():
+            p.copy_(T(g["param." + n]))
+    xt = T(g["xt"]).clone().requires_grad_(True)
+    fs, fd = pl(xt)
+    close(fs, g["feat_static"])
+    close(fd, g["feat_dynamic"])
+    close(pl.forward_static(xt), g["feat_static_only"])
+    close(pl.forward_dynamic(xt), g["feat_dynamic_only"])
+    ((fs * T(g["gs"])).sum() + (fd * T(g["gd"])).sum()).backward()
+    close(xt.grad, g["grad_xt"], rtol=1e-4, atol=1e-5)
+    for n, p in pl.named_parameters():
+        close(p.grad, g["grad." + n], rtol=1e-4, atol=1e-5)
+
+
+def test_hashgrid4d_glue(golden, fp32_oracle):
+    g = golden("hashgrid4d_glue")
+    hg = fields_ref.HashGrid4D(base_resolution=16, max_resolution=256, time_resolution=8, n_levels=4,
+                               n_features_per_level=4, log2_hashmap_size=10, hash_size_dynamic=(8, 7, 7))
+    with torch.no_grad():
+        for n, p in hg.named_parameters():
+            p.copy_(det_uniform(tuple(p.shape), "hg:" + n, -0.5, 0.5))
+    x = T(g["x"])
+    for t in (0.0, 0.3, 1.0):
+        s_, d_ = hg(x, torch.tensor([[t]]))
+        close(s_, g[f"static_t{t}"])
+        close(d_, g[f"dynamic_t{t}"], atol=2e-6)
+    close(hg.forward_dynamic(x, torch.tensor(26 / 51)), g["dynamic_t0dim_26_51"], atol=2e-6)
+    d_ = hg.forward_dynamic(x, torch.tensor([[0.62]]))
+    close(d_, g["dynamic_t062"], atol=2e-6)
+    (d_ * T(g["gd"])).sum().backward()
+    for n, p in hg.named_parameters():
+        if "grad." + n in g.files:
+            close(p.grad, g["grad." + n], rtol=1e-4, atol=1e-5)
+        else:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0
+
+
+@pytest.fixture(scope="module")
+def small_model():
+    from oracle import tcnn_ref
+    prev = tcnn_ref.get_precision()
+    tcnn_ref.set_precision("fp32")
+    m = fill_model(fields_ref.LiDAR4D(**SMALL_MODEL), seed=7)
+    yield m
+    tcnn_ref.set_precision(prev)
+
+
+def _digest_close(model, g, prefix):
+    dig = grad_digest(model)
+    for n, v in dig.items():
+        ref = g[prefix + n]
+        scale = max(abs(ref[1]), 1e-12)
+        assert abs(v[0] - ref[0]) <= 2e-4 * scale + 1e-9, (n, v, ref)
+        assert abs(v[1] - ref[1]) <= 2e-4 * scale + 1e-9, (n, v, ref)
+        assert abs(v[2] - ref[2]) <= 2e-4 * scale + 1e-9, (n, v, ref)
+
+
+def test_density_small(golden, small_model):
+    g = golden("density_small")
+    pts = T(g["pts"])
+    for fi in (0, 25, 50):
+        small_model.zero_grad()
+        t = torch.tensor([[fi / 50]])
+        out = small_model.density(pts, t)
+        close(out["sigma"], g[f"sigma_f{fi}"], rtol=1e-4)
+        close(out["geo_feat"], g[f"geo_f{fi}"], rtol=1e-4, atol=1e-5)
+        gsig = det_uniform((512,), f"gsig{fi}", -1, 1)
+        ggeo = det_uniform((512, 15), f"ggeo{fi}", -1, 1)
+        ((out["sigma"] * gsig).sum() + (out["geo_feat"] * ggeo).sum()).backward()
+        _digest_close(small_model, g, f"gdig_f{fi}.")
+        fl = small_model.flow(pts, t)
+        close(fl["forward"], g[f"flow_fwd_f{fi}"], rtol=1e-4, atol=1e-7)
+        close(fl["backward"], g[f"flow_bwd_f{fi}"], rtol=1e-4, atol=1e-7)
+
+
+def test_attribute_small(golden, small_model):
+    g = golden("attribute_small")
+    for tag in ("empty", "sparse", "full"):
+        out = small_model.attribute(T(g["pts"]), T(g["dirs"]), mask=T(g["mask_" + tag]), geo_feat=T(g["geo"]))
+        close(out, g["out_" + tag], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["f25_T96", "f0_T768", "f50_T64"])
+def test_render_small(golden, small_model, tag):
+    g = golden("render_small_" + tag)
+    small_model.density_scale = float(g["density_scale"])
+    small_model.zero_grad()
+    t = torch.tensor([[int(g["frame"]) / 50]])
+    out = small_model.render(T(g["rays_o"]), T(g["rays_d"]), t, staged=False, num_steps=int(g["num_steps"]),
+                             perturb=bool(g["perturb"]), noise=T(g["noise"]))
+    assert torch.equal(out["z_vals"], T(g["z_vals"]))
+    close(out["weights"], g["weights"], rtol=2e-4, atol=1e-9)
+    close(out["depth_lidar"], g["depth"], rtol=1e-4)
+    close(out["image_lidar"], g["image"], rtol=1e-4, atol=1e-6)
+    close(out["weights_sum_lidar"], g["weights_sum"], rtol=1e-4)
+    got = set(torch.nonzero(out["mask"].reshape(-1)).reshape(-1).tolist())
+    want = set(g["mask_idx"].tolist())
+    # index-set equality, allowing only samples whose weight sits on the 1e-4 threshold to fp32 noise
+    w = T(g["weights"]).reshape(-1)
+    for i in got ^ want:
+        assert abs(float(w[i]) - 1e-4) < 1e-8, (i, float(w[i]))
+    ((out["depth_lidar"] * T(g["gdep"])).sum() + (out["image_lidar"] * T(g["gimg"])).sum()).backward()
+    _digest_close(small_model, g, "gdig.")
+    gs = golden("render_small_" + tag + "_staged")
+    with torch.no_grad():
+        st = small_model.render(T(g["rays_o"]), T(g["rays_d"]), t, staged=True, max_ray_batch=24,
+                                num_steps=int(g["num_steps"]), perturb=False)
+    close(st["depth_lidar"], gs["depth"], rtol=1e-4)
+    close(st["image_lidar"], gs["image"], rtol=1e-4, atol=1e-6)
