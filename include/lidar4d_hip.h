@@ -1,0 +1,215 @@
+/*
+ * lidar4d_hip.h -- C ABI of the MI355X-native LiDAR4D ray-rendering hot path (gfx950 / CDNA4).
+ *
+ * Drop-in boundary.  The reference binds this path to native code through two Python-level
+ * operator surfaces, and this header is what a maintainer would bind in their place
+ * (INTEGRATION.md shows the ctypes stubs):
+ *
+ *   - tiny-cuda-nn's `tcnn.Encoding` / `tcnn.Network` modules (reference call sites
+ *     model/hash_field.py:47-57,107-117; model/flow_field.py:67-77; model/lidar4d.py:68-117)
+ *       -> l4d_hashgrid_*, l4d_hashgrid_t_*, l4d_freq_fwd, l4d_mlp_*
+ *   - ATen kernels reached from the reference's torch code on the path
+ *     (F.grid_sample model/planes_field.py:77-81; cumprod/exp/mask model/renderer.py:77-129;
+ *      masked gather/scatter model/lidar4d.py:196-219)
+ *       -> l4d_planes_*, l4d_sample_rays, l4d_composite_*, l4d_attr_*
+ *
+ * Conventions (same as the reference's only in-tree native op, utils/chamfer3D/chamfer3D.cu:135-194:
+ * caller-allocated outputs, int status): every pointer is a DEVICE pointer unless its comment says
+ * "host"; tensors are dense row-major; `stream` is a hipStream_t passed as void*; every entry point
+ * returns 0 on success or a hipError_t value (l4d_last_error() gives the text).  No torch types.
+ * fp16 buffers are IEEE binary16 (`_Float16`), passed as void*.
+ */
+#ifndef LIDAR4D_HIP_H
+#define LIDAR4D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L4D_MAX_LEVELS 16
+#define L4D_ABI_VERSION 1
+
+/* Multi-resolution hash grid geometry (tiny-cuda-nn "HashGrid" encoding).
+ * Filled by host code (lidar4d_amd/gridmeta.py) exactly as tiny-cuda-nn's host code derives it. */
+typedef struct {
+  int32_t n_dims;      /* 2 or 3 */
+  int32_t n_features;  /* features per level: 2, 4 or 8 */
+  int32_t n_levels;    /* <= L4D_MAX_LEVELS */
+  uint32_t hashed_mask; /* bit l set: level l uses the coherent-prime hash, else dense strides */
+  float scale[L4D_MAX_LEVELS];
+  uint32_t res[L4D_MAX_LEVELS];
+  uint32_t size[L4D_MAX_LEVELS];   /* entries in level */
+  uint32_t offset[L4D_MAX_LEVELS]; /* first entry of level, in entries */
+} l4d_grid_desc;
+
+int l4d_version(void);
+const char* l4d_last_error(void);
+
+/* ---- tcnn.Encoding(HashGrid) : model/hash_field.py:107-117, model/flow_field.py:67-77 -------
+ * x        [P, x_stride] fp32; the grid's n_dims coordinates are columns cols[0..n_dims-1] (host)
+ * table    [n_entries, F] fp16 (level-major)
+ * out      [P, out_stride] fp16, columns [0, L*F)
+ */
+int l4d_hashgrid_fwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
+                     const int32_t* cols /*host*/, const void* table, void* out, int32_t out_stride,
+                     void* stream);
+/* dout [P, dout_stride] fp16 (dout_is_half=1) or fp32; grad_table [n_entries, F] fp32, ACCUMULATED
+ * into (atomics); gradient is multiplied by grad_scale before accumulation. */
+int l4d_hashgrid_bwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
+                     const int32_t* cols /*host*/, const void* dout, int32_t dout_stride,
+                     int32_t dout_is_half, float grad_scale, float* grad_table, void* stream);
+
+/* ---- HashGridT.forward : model/hash_field.py:76-88; FlowField grid + interpT : flow_field.py:102-125 ---
+ * Time blend of two slices + cubic-Lagrange interpT over the 4 feature chunks of each level, fused.
+ * tables   host array of n_slices device pointers, each a [n_entries, F] fp16 table (n_slices = 1: no blend)
+ * t        device pointer to ONE fp32: the call's time in [0,1] (no host sync: slice pair, blend
+ *          weights and Lagrange coefficients are derived on the device)
+ * out      [P, out_stride] fp32 or fp16 (out_is_half), columns [0, L*F/4); F in {4, 8}
+ */
+int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
+                       const int32_t* cols /*host*/, const void* const* tables /*host*/, int32_t n_slices,
+                       const float* t, void* out, int32_t out_stride, int32_t out_is_half, void* stream);
+/* dout [P, dout_stride] fp32 or fp16, multiplied by grad_scale; grad_tables host array of n_slices device
+ * pointers to fp32 tables (accumulated into).  Only the slices selected by *t are touched. */
+int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
+                       const int32_t* cols /*host*/, int32_t n_slices, const float* t, const void* dout,
+                       int32_t dout_stride, int32_t dout_is_half, float grad_scale,
+                       float* const* grad_tables /*host*/, void* stream);
+
+/* ---- Planes4D : model/planes_field.py:87-141,198-239 --------------------------------------------
+ * planes_cl  channel-last copy of the hex-plane parameters: for scale s, plane c (comb order
+ *            (0,1)(0,2)(0,3)(1,2)(1,3)(2,3)) a [H, W, C] fp32 block at element offset plane_off[s*6+c]
+ *            (host array), H = res of comb[1], W = res of comb[0].
+ * res        host [n_scales*4] resolutions (x,y,z,t) per scale
+ * xt         [P, 4] fp32
+ * which      0 = both, 1 = static only, 2 = dynamic only
+ * out_s/out_d [P, n_scales*C] fp32 (may be null when not requested)
+ */
+int l4d_planes_relayout(const float* const* planes /*host: n_scales*6 device ptrs, [1,C,H,W]*/,
+                        const int32_t* res /*host*/, int32_t n_scales, int32_t C, float* planes_cl,
+                        const int64_t* plane_off /*host*/, int32_t to_channel_last, void* stream);
+int l4d_planes_fwd(const float* planes_cl, const int64_t* plane_off /*host*/, const int32_t* res /*host*/,
+                   int32_t n_scales, int32_t C, const float* xt, int64_t P, int32_t which, float* out_s,
+                   float* out_d, void* stream);
+/* grad_cl accumulated (channel-last layout, atomics); dxt [P,4] fp32 overwritten when non-null
+ * (ATen grid_sampler border rule: zero where the un-normalised coordinate was clipped). */
+int l4d_planes_bwd(const float* planes_cl, const int64_t* plane_off /*host*/, const int32_t* res /*host*/,
+                   int32_t n_scales, int32_t C, const float* xt, int64_t P, int32_t which,
+                   const float* dout_s, const float* dout_d, float* grad_cl, float* dxt, void* stream);
+
+/* ---- tcnn.Encoding(Frequency) : model/lidar4d.py:68-74,208 --------------------------------------
+ * x [P, 3] fp32 -> out [P, out_stride] fp16 cols [0, 72): per dim [sin(2^k pi x), cos(2^k pi x)] k<12 */
+int l4d_freq_fwd(const float* x, int64_t P, int32_t n_dims, int32_t n_freq, void* out, int32_t out_stride,
+                 void* stream);
+
+/* ---- tcnn.Network(FullyFusedMLP) : model/lidar4d.py:83-117, nn.Linear stack flow_field.py:84-98 ---
+ * Bias-free ReLU MLP on MFMA (v_mfma_f32_16x16x32_f16, fp32 accumulate, fp16 activations).
+ * x        [P, in_pad] fp16 (caller pads with 1.0; in_pad multiple of 16, <= 128)
+ * weights  fp16, layers concatenated: [64, in_pad], (n_hidden-1) x [64, 64], [16, 64]
+ * y        [P, 16] fp16
+ * act      optional [n_hidden, P, 64] fp16 hidden activations (saved for backward) or null
+ * n_rows   optional device int32: only the first min(P, *n_rows) rows are processed (work lists sized
+ *          on the device, e.g. the weights>1e-4 compaction); buffers keep their P-row strides */
+int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad, int32_t n_hidden,
+                const void* weights, void* y, void* act, void* stream);
+/* dy [P,16] fp16 (already multiplied by the caller's loss scale); dx [P, in_pad] fp16 or null;
+ * grad_w fp32, same layout as weights, ACCUMULATED with 1/loss_scale applied. */
+int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64_t P, const int32_t* n_rows, int32_t in_pad,
+                int32_t n_hidden, const void* weights, void* dx, float* grad_w, float inv_loss_scale, void* stream);
+
+/* ---- LiDAR_Renderer.run : model/renderer.py:59-129 -----------------------------------------------
+ * sample: lin [T] = torch.linspace(0,1,T) (renderer.py:77; passed in so that the bits are the caller's
+ * torch build's), noise [N,T] in [0,1) or null (renderer.py:84) -> z_vals [N,T]; xyz [N*T,3] clipped to
+ * [-bound,bound] (renderer.py:88-89) or null */
+int l4d_sample_rays(const float* rays_o, const float* rays_d, const float* lin, const float* noise, int64_t N,
+                    int32_t T, float near, float far, float bound, float* z_vals, float* xyz, void* stream);
+/* composite: sigma [N,T] -> weights [N,T], weights_sum [N], depth [N] (= sum w z, not normalised),
+ * mask [N,T] (uint8, weights > 1e-4, renderer.py:110) and the compacted list of masked flat sample
+ * indices (grouped by ray, ascending inside a ray) + its length (device int32, zeroed here). */
+int l4d_composite_fwd(const float* sigma, const float* z_vals, int64_t N, int32_t T, float sample_dist,
+                      float density_scale, int32_t active_sensor, float* weights, float* weights_sum,
+                      float* depth, uint8_t* mask, int32_t* mask_idx, int32_t* mask_count, void* stream);
+/* image [N,C] = sum_t weights * attr [N*T, C]  (renderer.py:129) */
+int l4d_composite_image(const float* weights, const float* attr, int64_t N, int32_t T, int32_t C,
+                        float* image, void* stream);
+/* backward of depth = sum w z, wsum = sum w, image = sum w attr (and optional direct d_weights)
+ * wrt sigma [N,T] and attr [N*T,C] (d_attr may be null) */
+int l4d_composite_bwd(const float* sigma, const float* z_vals, const float* weights, const float* attr,
+                      int64_t N, int32_t T, int32_t C, float sample_dist, float density_scale,
+                      int32_t active_sensor, const float* d_depth, const float* d_wsum, const float* d_image,
+                      const float* d_weights /*[N,T] or null*/, float* d_sigma, float* d_attr, void* stream);
+
+/* ---- LiDAR4D.attribute glue : model/lidar4d.py:196-219 -------------------------------------------
+ * Work-list form of `x[mask]` / `output[mask] = h`: idx [cap] int32 flat sample indices (null = identity),
+ * count = device int32 with the list length (null = cap); no host sync is needed to size the launch.
+ * gather : xa[j] = [dir_enc[idx[j] / T] (n_enc fp16) | h[idx[j]][1..n_geo] (geo_feat, fp16) | 1.0 pad]
+ * scatter: attr[idx[j]] = (sigmoid(y_raydrop[j][0]), sigmoid(y_intensity[j][0])) rounded to fp16;
+ *          attr [P,2] fp32 must be zero-filled by the caller; attr_compact [cap,2] keeps the same values
+ * *_bwd  : the two adjoints; dy_* [cap,16] fp16 and dh [P,16] fp16 carry loss_scale */
+int l4d_attr_gather(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc,
+                    int32_t n_enc, const void* h, int32_t n_geo, void* xa, int32_t in_pad, void* stream);
+int l4d_attr_scatter(const int32_t* idx, const int32_t* count, int64_t cap, const void* y_raydrop,
+                     const void* y_intensity, float* attr, float* attr_compact, void* stream);
+int l4d_attr_scatter_bwd(const int32_t* idx, const int32_t* count, int64_t cap, const float* d_attr,
+                         const float* attr_compact, float loss_scale, void* dy_raydrop, void* dy_intensity,
+                         void* stream);
+int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int64_t cap, const void* dxa_raydrop,
+                        const void* dxa_intensity, int32_t in_pad, int32_t n_enc, int32_t n_geo, void* dh,
+                        void* stream);
+/* sigma = trunc_exp(h[:,0]) (model/activation.py:6-20) on the sigma net's fp16 output h [P,16], and its
+ * adjoint dh[:,0] = d_sigma * exp(clamp(h0,-15,15)) * loss_scale (fp16) */
+int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* stream);
+int l4d_sigma_bwd(const void* h, const float* d_sigma, int64_t P, float loss_scale, void* dh, void* stream);
+
+/* ---- LiDAR4D.density, fused field evaluation : model/lidar4d.py:139-179 ---------------------------
+ * One launch evaluates, per sample point, the hex-planes at (x,t) and at the two flow-warped neighbour
+ * frames, the static hash grid, the three HashGridT stacks at the three frames, the 0.5/0.25/0.25 blends and
+ * the concat, and writes the sigma network's padded fp16 input row.  Compute copies of the parameters: */
+#define L4D_MAX_TIME_SLICES 8
+#define L4D_MAX_PLANE_SCALES 8
+typedef struct {
+  l4d_grid_desc hash_static;                                   /* 3-D, F = 4 */
+  const void* hash_static_table;                               /* fp16 */
+  l4d_grid_desc hash_dynamic[3];                               /* xy, xz, yz: 2-D, F = 4 */
+  const void* hash_dynamic_tables[3][L4D_MAX_TIME_SLICES];     /* fp16, one table per time slice */
+  int32_t n_slices;
+  int32_t n_scales;                                            /* hex-plane scales */
+  int32_t plane_channels;                                      /* 8 */
+  int32_t plane_res[L4D_MAX_PLANE_SCALES * 4];                 /* (x,y,z,t) resolution per scale */
+  int64_t plane_off[L4D_MAX_PLANE_SCALES * 6];                 /* element offsets into planes_cl */
+  const float* planes_cl;                                      /* channel-last fp32 planes */
+} l4d_field_desc;
+typedef struct {                                               /* fp32 gradient buffers, accumulated into */
+  float* hash_static_table;
+  float* hash_dynamic_tables[3][L4D_MAX_TIME_SLICES];
+  float* planes_cl;
+} l4d_field_grads;
+
+int l4d_field_width(const l4d_field_desc* f /*host*/);         /* feature columns before padding */
+/* tinfo [8] fp32 (device) <- t: [t, t1=(f+1)/num_frames, t2=(f-1)/num_frames, has_fwd, has_bwd, f] */
+int l4d_time_setup(const float* t, int32_t num_frames, float* tinfo, void* stream);
+/* l4d_sample_rays variant that writes xt [N*T,4] = ((clip(o+d z)+bound)/(2 bound), t) (lidar4d.py:141,148-149) */
+int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, const float* lin, const float* noise,
+                       const float* t, int64_t N, int32_t T, float near, float far, float bound, float* z_vals,
+                       float* xt, void* stream);
+/* flow16 [P,16] fp16: flow network output (cols 0-2 forward, 3-5 backward); X [P,in_pad] fp16 */
+int l4d_density_encode_fwd(const l4d_field_desc* f /*host*/, const float* xt, const void* flow16,
+                           const float* tinfo, int64_t P, void* X, int32_t in_pad, void* stream);
+/* dX [P,in_pad] fp16 (loss-scaled); parameter gradients are accumulated multiplied by param_scale
+ * (= 1/loss_scale); dflow16 [P,16] fp16 stays in dX's scaled domain */
+int l4d_density_encode_bwd(const l4d_field_desc* f /*host*/, const l4d_field_grads* g /*host*/, const float* xt,
+                           const void* flow16, const float* tinfo, int64_t P, const void* dX, int32_t in_pad,
+                           float param_scale, void* dflow16, void* stream);
+
+/* ---- optimiser + casts (runner.py:506-508 Adam step; tcnn's per-forward fp32->fp16 param cast) ---- */
+int l4d_cast_f32_to_f16(const float* src, void* dst, int64_t n, void* stream);
+int l4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16 /*or null*/,
+                  int64_t n, float lr, float beta1, float beta2, float eps, float bias_c1, float bias_c2,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDAR4D_HIP_H */

@@ -1,0 +1,98 @@
+// Shared device/host helpers for the gfx950 kernels.  Compiled with -ffp-contract=off: every
+// fused multiply-add in these sources is an explicit fmaf(), so coordinate / index arithmetic
+// rounds exactly as the oracle's (and the reference's torch) separate mul+add do.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/lidar4d_hip.h"
+
+#define L4D_WAVE 64
+
+extern "C" void l4d_set_error(int code, const char* where);
+
+#define L4D_LAUNCH_CHECK(where)                         \
+  do {                                                  \
+    hipError_t e__ = hipGetLastError();                 \
+    if (e__ != hipSuccess) {                            \
+      l4d_set_error((int)e__, where);                   \
+      return (int)e__;                                  \
+    }                                                   \
+  } while (0)
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float h2f(half_t h) { return (float)h; }
+__device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }  // round-to-nearest-even
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Device copy of l4d_grid_desc passed by value as a kernel argument (236 bytes).
+struct GridDesc {
+  int n_levels;
+  uint32_t hashed_mask;
+  float scale[L4D_MAX_LEVELS];
+  uint32_t res[L4D_MAX_LEVELS];
+  uint32_t size[L4D_MAX_LEVELS];
+  uint32_t offset[L4D_MAX_LEVELS];
+};
+
+static inline GridDesc make_grid_desc(const l4d_grid_desc* d) {
+  GridDesc g;
+  g.n_levels = d->n_levels;
+  g.hashed_mask = d->hashed_mask;
+  for (int i = 0; i < L4D_MAX_LEVELS; ++i) {
+    g.scale[i] = d->scale[i];
+    g.res[i] = d->res[i];
+    g.size[i] = d->size[i];
+    g.offset[i] = d->offset[i];
+  }
+  return g;
+}
+
+// Lagrange basis of the reference's interpT (model/hash_field.py:65-74) at nodes {0,1/3,2/3,1}.
+// Products in the reference's order: for j, prod over m != j (ascending m) of (t - T[m]) / (T[j] - T[m]);
+// python's math.prod starts from the int 1, so the first factor is taken as is.
+__device__ __forceinline__ void lagrange4(float t, float c[4]) {
+  const double Td[4] = {0.0, 1.0 / 3.0, 2.0 / 3.0, 1.0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float p = 1.0f;
+    bool first = true;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m == j) continue;
+      // torch: (t_f32 - python_double) -> fp32 op with the scalar rounded to fp32; same for the divide
+      float f = (t - (float)Td[m]) / (float)(Td[j] - Td[m]);
+      p = first ? f : p * f;
+      first = false;
+    }
+    c[j] = p;
+  }
+}
+
+// Time-slice pair and blend weights of HashGridT.forward (model/hash_field.py:79-85).
+struct SlicePair {
+  int i1, i2;
+  float w1, w2;
+};
+__device__ __forceinline__ SlicePair slice_pair(float t, int n_slices) {
+  SlicePair s;
+  float idx = t * (float)(n_slices - 1);
+  float f = floorf(idx), c = ceilf(idx);
+  s.i1 = (int)f;
+  s.i2 = (int)c;
+  if (s.i1 == s.i2) {
+    s.w1 = 1.0f;
+    s.w2 = 0.0f;
+  } else {
+    s.w1 = c - idx;
+    s.w2 = idx - f;
+  }
+  return s;
+}

@@ -1,0 +1,282 @@
+// Multi-resolution hash-grid encoding for gfx950 (tiny-cuda-nn "HashGrid" semantics),
+// replacing tcnn.Encoding at the reference call sites model/hash_field.py:47-57,107-117 and
+// model/flow_field.py:67-77, plus the fused HashGridT (model/hash_field.py:76-88).
+//
+// Direct-gather formulation: one thread per (point, level); a block covers 256 consecutive points
+// of one level (blockIdx.y = level) so a level's table stays hot in that CU's L1/L2 while
+// consecutive samples of a ray (consecutive threads) share cells on the coarse levels.
+// Corner entries are fetched as one 4/8/16-byte vector (F = 2/4/8 fp16 features).
+#include "common.h"
+
+#include "hashgrid_dev.h"
+
+struct Cols {
+  int c[3];
+};
+
+// ------------------------------------------------------------------------------------------------
+// generic forward / backward
+// ------------------------------------------------------------------------------------------------
+template <int D, int F>
+__global__ void __launch_bounds__(256) hashgrid_fwd_kernel(GridDesc desc, const float* __restrict__ x, int64_t P,
+                                                          int x_stride, Cols cols, const half_t* __restrict__ table,
+                                                          half_t* __restrict__ out, int out_stride) {
+  const int lvl = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float xin[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = x[p * x_stride + cols.c[d]];
+  float acc[F];
+  level_lookup<D, F>(table + (size_t)desc.offset[lvl] * F, desc.scale[lvl], desc.res[lvl], desc.size[lvl],
+                     (desc.hashed_mask >> lvl) & 1u, xin, acc);
+  half_t h[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) h[f] = f2h(acc[f]);
+  typename EntryVec<F>::type* dst = reinterpret_cast<typename EntryVec<F>::type*>(out + p * out_stride + lvl * F);
+  *dst = *reinterpret_cast<typename EntryVec<F>::type*>(h);
+}
+
+template <int D, int F, bool HALF_IN>
+__global__ void __launch_bounds__(256) hashgrid_bwd_kernel(GridDesc desc, const float* __restrict__ x, int64_t P,
+                                                          int x_stride, Cols cols, const void* __restrict__ dout,
+                                                          int dout_stride, float grad_scale,
+                                                          float* __restrict__ grad_table) {
+  const int lvl = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float g_out[F];
+  bool any = false;
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    float v = HALF_IN ? h2f(reinterpret_cast<const half_t*>(dout)[p * dout_stride + lvl * F + f])
+                      : reinterpret_cast<const float*>(dout)[p * dout_stride + lvl * F + f];
+    g_out[f] = v * grad_scale;
+    any |= (g_out[f] != 0.0f);
+  }
+  if (!any) return;  // exact: zero upstream gradient contributes nothing
+  float xin[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = x[p * x_stride + cols.c[d]];
+  Cell<D> c = locate<D>(xin, desc.scale[lvl]);
+  float* gt = grad_table + (size_t)desc.offset[lvl] * F;
+#pragma unroll
+  for (int k = 0; k < (1 << D); ++k) {
+    uint32_t g[D];
+    float w = corner<D>(c, k, g);
+    uint32_t idx = grid_index<D>(g, desc.res[lvl], desc.size[lvl], (desc.hashed_mask >> lvl) & 1u);
+#pragma unroll
+    for (int f = 0; f < F; ++f) atomicAdd(gt + (size_t)idx * F + f, w * g_out[f]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// HashGridT: two time slices, linear blend, cubic-Lagrange interpT over the F=4 features of a level.
+// Rounding points follow the oracle: each slice's interpolated feature is rounded to fp16 (it is a
+// tcnn.Encoding output in the reference), blend and interpT are fp32.
+// ------------------------------------------------------------------------------------------------
+#define L4D_MAX_SLICES 16
+struct SliceTables {
+  const half_t* t[L4D_MAX_SLICES];
+};
+struct SliceGrads {
+  float* t[L4D_MAX_SLICES];
+};
+
+// F features of a level are split into 4 chunks of F/4 (num_basis = 4): out[lvl*(F/4) + j] = sum_b basis[b] * feat[b*(F/4) + j]
+// (hash_field.py:65-74 with F=4; flow_field.py:102-111 with F=8, a single table and no time blend).
+template <int D, int F, bool HALF_OUT>
+__global__ void __launch_bounds__(256) hashgrid_t_fwd_kernel(GridDesc desc, const float* __restrict__ x, int64_t P,
+                                                            int x_stride, Cols cols, SliceTables tabs, int n_slices,
+                                                            const float* __restrict__ t_ptr, void* __restrict__ out,
+                                                            int out_stride) {
+  constexpr int FO = F / 4;
+  const int lvl = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float t = *t_ptr;
+  const SlicePair sp = slice_pair(t, n_slices);
+  float basis[4];
+  lagrange4(t, basis);
+  float xin[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = x[p * x_stride + cols.c[d]];
+  const size_t off = (size_t)desc.offset[lvl] * F;
+  const bool hashed = (desc.hashed_mask >> lvl) & 1u;
+  float a[F], b[F];
+  level_lookup<D, F>(tabs.t[sp.i1] + off, desc.scale[lvl], desc.res[lvl], desc.size[lvl], hashed, xin, a);
+  if (sp.i1 != sp.i2) {
+    level_lookup<D, F>(tabs.t[sp.i2] + off, desc.scale[lvl], desc.res[lvl], desc.size[lvl], hashed, xin, b);
+#pragma unroll
+    for (int f = 0; f < F; ++f) a[f] = sp.w1 * h2f(f2h(a[f])) + sp.w2 * h2f(f2h(b[f]));
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) a[f] = h2f(f2h(a[f]));
+  }
+#pragma unroll
+  for (int j = 0; j < FO; ++j) {
+    float r = 0.0f;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) r += basis[bb] * a[bb * FO + j];
+    if (HALF_OUT)
+      reinterpret_cast<half_t*>(out)[p * out_stride + lvl * FO + j] = f2h(r);
+    else
+      reinterpret_cast<float*>(out)[p * out_stride + lvl * FO + j] = r;
+  }
+}
+
+template <int D, int F, bool HALF_IN>
+__global__ void __launch_bounds__(256) hashgrid_t_bwd_kernel(GridDesc desc, const float* __restrict__ x, int64_t P,
+                                                            int x_stride, Cols cols, int n_slices,
+                                                            const float* __restrict__ t_ptr,
+                                                            const void* __restrict__ dout, int dout_stride,
+                                                            float grad_scale, SliceGrads grads) {
+  constexpr int FO = F / 4;
+  const int lvl = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float go[FO];
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < FO; ++j) {
+    go[j] = (HALF_IN ? h2f(reinterpret_cast<const half_t*>(dout)[p * dout_stride + lvl * FO + j])
+                     : reinterpret_cast<const float*>(dout)[p * dout_stride + lvl * FO + j]) * grad_scale;
+    any |= go[j] != 0.0f;
+  }
+  if (!any) return;
+  const float t = *t_ptr;
+  const SlicePair sp = slice_pair(t, n_slices);
+  float basis[4];
+  lagrange4(t, basis);
+  float xin[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = x[p * x_stride + cols.c[d]];
+  Cell<D> c = locate<D>(xin, desc.scale[lvl]);
+  const size_t off = (size_t)desc.offset[lvl] * F;
+  float* g1 = grads.t[sp.i1] + off;
+  float* g2 = grads.t[sp.i2] + off;
+#pragma unroll
+  for (int k = 0; k < (1 << D); ++k) {
+    uint32_t g[D];
+    float w = corner<D>(c, k, g);
+    uint32_t idx = grid_index<D>(g, desc.res[lvl], desc.size[lvl], (desc.hashed_mask >> lvl) & 1u);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      float gf = go[f % FO] * basis[f / FO] * w;
+      atomicAdd(g1 + (size_t)idx * F + f, gf * sp.w1);
+      if (sp.i1 != sp.i2) atomicAdd(g2 + (size_t)idx * F + f, gf * sp.w2);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static inline Cols make_cols(const int32_t* cols, int D) {
+  Cols c;
+  for (int d = 0; d < 3; ++d) c.c[d] = d < D ? cols[d] : 0;
+  return c;
+}
+
+#define DISPATCH_DF(D_, F_, CALL)                        \
+  if (D_ == 2 && F_ == 2) { CALL(2, 2) }                 \
+  else if (D_ == 2 && F_ == 4) { CALL(2, 4) }            \
+  else if (D_ == 2 && F_ == 8) { CALL(2, 8) }            \
+  else if (D_ == 3 && F_ == 2) { CALL(3, 2) }            \
+  else if (D_ == 3 && F_ == 4) { CALL(3, 4) }            \
+  else if (D_ == 3 && F_ == 8) { CALL(3, 8) }            \
+  else { l4d_set_error(1, "hashgrid: unsupported n_dims/n_features"); return 1; }
+
+extern "C" int l4d_hashgrid_fwd(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride,
+                                const int32_t* cols, const void* table, void* out, int32_t out_stride,
+                                void* stream) {
+  if (P == 0) return 0;
+  GridDesc g = make_grid_desc(desc);
+  Cols c = make_cols(cols, desc->n_dims);
+  dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels), block(256);
+#define CALL(D, F)                                                                                          \
+  hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, \
+                     (const half_t*)table, (half_t*)out, out_stride);
+  DISPATCH_DF(desc->n_dims, desc->n_features, CALL)
+#undef CALL
+  L4D_LAUNCH_CHECK("l4d_hashgrid_fwd");
+  return 0;
+}
+
+extern "C" int l4d_hashgrid_bwd(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride,
+                                const int32_t* cols, const void* dout, int32_t dout_stride, int32_t dout_is_half,
+                                float grad_scale, float* grad_table, void* stream) {
+  if (P == 0) return 0;
+  GridDesc g = make_grid_desc(desc);
+  Cols c = make_cols(cols, desc->n_dims);
+  dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels), block(256);
+#define CALL(D, F)                                                                                                  \
+  if (dout_is_half)                                                                                                 \
+    hipLaunchKernelGGL((hashgrid_bwd_kernel<D, F, true>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, \
+                       dout, dout_stride, grad_scale, grad_table);                                                  \
+  else                                                                                                              \
+    hipLaunchKernelGGL((hashgrid_bwd_kernel<D, F, false>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride,  \
+                       c, dout, dout_stride, grad_scale, grad_table);
+  DISPATCH_DF(desc->n_dims, desc->n_features, CALL)
+#undef CALL
+  L4D_LAUNCH_CHECK("l4d_hashgrid_bwd");
+  return 0;
+}
+
+static int check_t(const l4d_grid_desc* desc, int n_slices) {
+  if ((desc->n_features != 4 && desc->n_features != 8) || n_slices > L4D_MAX_SLICES || n_slices < 1 ||
+      (desc->n_dims != 2 && desc->n_dims != 3)) {
+    l4d_set_error(1, "hashgrid_t: needs n_features in {4,8} (num_basis 4), n_dims in {2,3}, 1..16 slices");
+    return 1;
+  }
+  return 0;
+}
+
+#define DISPATCH_T(D_, F_, B_, CALL)                                   \
+  if (D_ == 2 && F_ == 4 && B_) { CALL(2, 4, true) }                   \
+  else if (D_ == 2 && F_ == 4) { CALL(2, 4, false) }                   \
+  else if (D_ == 3 && F_ == 4 && B_) { CALL(3, 4, true) }              \
+  else if (D_ == 3 && F_ == 4) { CALL(3, 4, false) }                   \
+  else if (D_ == 2 && F_ == 8 && B_) { CALL(2, 8, true) }              \
+  else if (D_ == 2 && F_ == 8) { CALL(2, 8, false) }                   \
+  else if (D_ == 3 && F_ == 8 && B_) { CALL(3, 8, true) }              \
+  else { CALL(3, 8, false) }
+
+extern "C" int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride,
+                                  const int32_t* cols, const void* const* tables, int32_t n_slices, const float* t,
+                                  void* out, int32_t out_stride, int32_t out_is_half, void* stream) {
+  if (P == 0) return 0;
+  if (check_t(desc, n_slices)) return 1;
+  GridDesc g = make_grid_desc(desc);
+  Cols c = make_cols(cols, desc->n_dims);
+  SliceTables tabs;
+  for (int i = 0; i < L4D_MAX_SLICES; ++i) tabs.t[i] = i < n_slices ? (const half_t*)tables[i] : nullptr;
+  dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels), block(256);
+#define CALL(D, F, B)                                                                                                \
+  hipLaunchKernelGGL((hashgrid_t_fwd_kernel<D, F, B>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, tabs, \
+                     n_slices, t, out, out_stride);
+  DISPATCH_T(desc->n_dims, desc->n_features, out_is_half, CALL)
+#undef CALL
+  L4D_LAUNCH_CHECK("l4d_hashgrid_t_fwd");
+  return 0;
+}
+
+extern "C" int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride,
+                                  const int32_t* cols, int32_t n_slices, const float* t, const void* dout,
+                                  int32_t dout_stride, int32_t dout_is_half, float grad_scale,
+                                  float* const* grad_tables, void* stream) {
+  if (P == 0) return 0;
+  if (check_t(desc, n_slices)) return 1;
+  GridDesc g = make_grid_desc(desc);
+  Cols c = make_cols(cols, desc->n_dims);
+  SliceGrads gr;
+  for (int i = 0; i < L4D_MAX_SLICES; ++i) gr.t[i] = i < n_slices ? grad_tables[i] : nullptr;
+  dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels), block(256);
+#define CALL(D, F, B)                                                                                                \
+  hipLaunchKernelGGL((hashgrid_t_bwd_kernel<D, F, B>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c,    \
+                     n_slices, t, dout, dout_stride, grad_scale, gr);
+  DISPATCH_T(desc->n_dims, desc->n_features, dout_is_half, CALL)
+#undef CALL
+  L4D_LAUNCH_CHECK("l4d_hashgrid_t_bwd");
+  return 0;
+}

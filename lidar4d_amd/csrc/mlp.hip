@@ -1,0 +1,540 @@
+// Fully-fused bias-free ReLU MLP on the gfx950 matrix cores, replacing tcnn.Network(FullyFusedMLP)
+// (model/lidar4d.py:83-117: sigma_net, intensity_net, raydrop_net) and the nn.Linear stack of
+// model/flow_field.py:84-98.  Hidden width 64, output padded to 16, input padded to a multiple of 16.
+//
+// Everything between the global loads and stores lives in registers: one wave owns a tile of batch
+// rows and chains v_mfma_f32_16x16x32_f16 (fp16 operands, fp32 accumulate) through the layers.
+//
+//   MFMA 16x16x32 operand layout (lane l: i = l & 15, g = l >> 4):
+//     A[i][8g..8g+7]   B[8g..8g+7][i]   C/D[4g + r][i], r = 0..3
+//   A and B have the same per-lane shape ("one row/column index, 8 consecutive k"), so a register set
+//   can be used as either operand.
+//
+// Forward orientation ("chain"): batch rows are the N dimension, C[neuron][row].  A lane then holds 4
+// neurons of ONE row per output tile; weight rows are loaded in the permuted order
+//   n1(mt, i) = 32*(mt>>1) + 8*(i>>2) + 4*(mt&1) + (i&3)
+// so that tiles 2ks and 2ks+1 together give the lane neurons 32ks+8g .. 32ks+8g+7 of its row: exactly
+// the next layer's B fragment.  No LDS, no shuffles between layers.
+//
+// Backward needs contractions over the BATCH (dW = dZ^T H).  Those want "8 consecutive rows per lane".
+// Instead of transposing through LDS the same quantities are produced a second time with the batch as
+// the M dimension ("orientation 2": C'[row][feature], lane = feature, 4 rows per tile), using the
+// chain-layout registers as A operand, and raw inputs are transposed with an identity-matrix MFMA
+// (exact).  Macro tile = 32 rows = chain tiles a=0,1 with row(a, i) = 8*(i>>2) + 4a + (i&3), which
+// makes the two orientation-2 tiles give the lane rows 8g .. 8g+7.
+// MFMA utilisation is irrelevant here (~2 % of peak at target rate); the doubled MFMA work
+// buys a kernel with no LDS traffic in the loop and no barriers.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define HID 64
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int perm_row(int mt, int i) { return 32 * (mt >> 1) + 8 * (i >> 2) + 4 * (mt & 1) + (i & 3); }
+
+// ---- fragment construction (once per block, into LDS) -----------------------------------------
+// value(row, k) of an A/B fragment: lane (i, g), element e -> k = 32*ks + 8g + e
+// kind 0: W[row_of(i)][k]          (forward A: rows = neurons of this layer, k = its inputs)
+// kind 1: W[k][row_of(i)]          (W^T: rows = inputs of the layer, k = its neurons)
+__device__ __forceinline__ h8 build_frag(const half_t* __restrict__ W, int R, int Cw, int kind, int row, int kbase) {
+  h8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = kbase + e;
+    float x = 0.0f;
+    if (kind == 0) {
+      if (row < R && k < Cw) x = h2f(W[row * Cw + k]);
+    } else {
+      if (k < R && row < Cw) x = h2f(W[k * Cw + row]);
+    }
+    v[e] = f2h(x);
+  }
+  return v;
+}
+
+__device__ __forceinline__ h8 ident_frag(int lane, int half_sel) {
+  const int j = lane & 15, g = lane >> 4;
+  h8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (8 * g + e == 16 * half_sel + j) ? (half_t)1.0f : (half_t)0.0f;
+  return v;
+}
+
+__device__ __forceinline__ h8 relu_pack(const f4& lo, const f4& hi) {
+  h8 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    v[r] = f2h(fmaxf(lo[r], 0.0f));
+    v[4 + r] = f2h(fmaxf(hi[r], 0.0f));
+  }
+  return v;
+}
+
+__device__ __forceinline__ float clamp_h(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
+
+// ================================================================================================
+// forward
+// ================================================================================================
+// weight layout (fp16): W1 [64, in_pad], (NH-1) x [64, 64], Wo [16, 64]
+template <int IN_TILES, int NH>
+__global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__ x, int64_t cap, const int32_t* __restrict__ n_rows,
+                                                     const half_t* __restrict__ weights, half_t* __restrict__ y,
+                                                     half_t* __restrict__ act) {
+  // cap = rows the buffers were sized for (stride of the act planes); P = rows actually present
+  const int64_t P = n_rows ? min((int64_t)*n_rows, cap) : cap;
+  constexpr int IN_PAD = IN_TILES * 16;
+  constexpr int KS_IN = (IN_TILES + 1) / 2;
+  constexpr int NF_L1 = 4 * KS_IN;
+  constexpr int NF = NF_L1 + (NH - 1) * 8 + 2;
+  __shared__ uint4 frags[NF][64];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+
+  // build A fragments cooperatively
+  for (int f = wave; f < NF; f += 4) {
+    h8 v;
+    if (f < NF_L1) {
+      const int mt = f / KS_IN, ks = f % KS_IN;
+      v = build_frag(weights, HID, IN_PAD, 0, perm_row(mt, i), 32 * ks + 8 * g);
+    } else if (f < NF_L1 + (NH - 1) * 8) {
+      const int q = f - NF_L1, layer = q / 8, mt = (q % 8) / 2, ks = q % 2;
+      v = build_frag(weights + HID * IN_PAD + layer * HID * HID, HID, HID, 0, perm_row(mt, i), 32 * ks + 8 * g);
+    } else {
+      const int ks = f - (NF_L1 + (NH - 1) * 8);
+      v = build_frag(weights + HID * IN_PAD + (NH - 1) * HID * HID, 16, HID, 0, i, 32 * ks + 8 * g);
+    }
+    frags[f][lane] = *reinterpret_cast<uint4*>(&v);
+  }
+  __syncthreads();
+  auto FR = [&](int f) -> h8 { uint4 u = frags[f][lane]; return *reinterpret_cast<h8*>(&u); };
+
+  const int64_t n_tiles = (P + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 16 + i;
+    const bool ok = row < P;
+    // input fragments
+    h8 xb[KS_IN];
+#pragma unroll
+    for (int ks = 0; ks < KS_IN; ++ks) {
+      const int k0 = 32 * ks + 8 * g;
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (ok && k0 < IN_PAD) u = *reinterpret_cast<const uint4*>(x + row * IN_PAD + k0);
+      xb[ks] = *reinterpret_cast<h8*>(&u);
+    }
+    // layer 1
+    f4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      acc[mt] = f4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < KS_IN; ++ks) acc[mt] = MFMA(FR(mt * KS_IN + ks), xb[ks], acc[mt]);
+    }
+    h8 hb[2];
+    hb[0] = relu_pack(acc[0], acc[1]);
+    hb[1] = relu_pack(acc[2], acc[3]);
+    if (act && ok) {
+      *reinterpret_cast<h8*>(act + row * HID + 8 * g) = hb[0];
+      *reinterpret_cast<h8*>(act + row * HID + 32 + 8 * g) = hb[1];
+    }
+    // further hidden layers
+#pragma unroll
+    for (int l = 1; l < NH; ++l) {
+      const int base = NF_L1 + (l - 1) * 8;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        acc[mt] = f4{0, 0, 0, 0};
+        acc[mt] = MFMA(FR(base + mt * 2 + 0), hb[0], acc[mt]);
+        acc[mt] = MFMA(FR(base + mt * 2 + 1), hb[1], acc[mt]);
+      }
+      hb[0] = relu_pack(acc[0], acc[1]);
+      hb[1] = relu_pack(acc[2], acc[3]);
+      if (act && ok) {
+        half_t* a_l = act + (int64_t)l * cap * HID;
+        *reinterpret_cast<h8*>(a_l + row * HID + 8 * g) = hb[0];
+        *reinterpret_cast<h8*>(a_l + row * HID + 32 + 8 * g) = hb[1];
+      }
+    }
+    // output layer: C[m = 4g + r][row i]
+    f4 o = f4{0, 0, 0, 0};
+    o = MFMA(FR(NF - 2), hb[0], o);
+    o = MFMA(FR(NF - 1), hb[1], o);
+    if (ok) {
+      h4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = f2h(clamp_h(o[r]));
+      *reinterpret_cast<h4*>(y + row * 16 + 4 * g) = ov;
+    }
+  }
+}
+
+// ================================================================================================
+// backward
+// ================================================================================================
+template <int IN_TILES, int NH>
+struct BwdFrags {
+  static constexpr int KS_IN = (IN_TILES + 1) / 2;
+  // W_o^T : chain (permuted rows) 4, orientation-2 (natural rows) 4
+  static constexpr int WOT_P = 0;
+  static constexpr int WOT_N = 4;
+  // hidden W_l^T, l = NH .. 2: per layer chain 8 + natural 8
+  static constexpr int WH = 8;
+  // W_1^T natural: IN_TILES x 2
+  static constexpr int W1T = WH + (NH - 1) * 16;
+  static constexpr int NF = W1T + IN_TILES * 2;
+};
+
+template <int IN_TILES, int NH>
+__global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
+                                                     const half_t* __restrict__ dy, int64_t cap,
+                                                     const int32_t* __restrict__ n_rows,
+                                                     const half_t* __restrict__ weights, half_t* __restrict__ dx,
+                                                     float* __restrict__ grad_w, float inv_scale) {
+  const int64_t P = n_rows ? min((int64_t)*n_rows, cap) : cap;
+  using L = BwdFrags<IN_TILES, NH>;
+  constexpr int IN_PAD = IN_TILES * 16;
+  constexpr int KS_IN = L::KS_IN;
+  __shared__ uint4 frags[L::NF][64];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const half_t* W1 = weights;
+  const half_t* Wo = weights + HID * IN_PAD + (NH - 1) * HID * HID;
+
+  for (int f = wave; f < L::NF; f += 4) {
+    h8 v;
+    if (f < L::WH) {
+      const int mt = f & 3;
+      const int row = (f < 4) ? perm_row(mt, i) : 16 * mt + i;
+      v = build_frag(Wo, 16, HID, 1, row, 8 * g);  // k = output index m (only 16 real)
+    } else if (f < L::W1T) {
+      const int q = f - L::WH, li = q / 16, r = q % 16;  // li = 0 -> layer NH, 1 -> NH-1 ...
+      const int layer = NH - li;                         // hidden layer index (>= 2)
+      const half_t* Wl = weights + HID * IN_PAD + (layer - 2) * HID * HID;
+      const int nat = r / 8, mt = (r % 8) / 2, ks = r % 2;
+      const int row = nat ? 16 * mt + i : perm_row(mt, i);
+      v = build_frag(Wl, HID, HID, 1, row, 32 * ks + 8 * g);
+    } else {
+      const int q = f - L::W1T, mt = q / 2, ks = q % 2;
+      v = build_frag(W1, HID, IN_PAD, 1, 16 * mt + i, 32 * ks + 8 * g);
+    }
+    frags[f][lane] = *reinterpret_cast<uint4*>(&v);
+  }
+  __syncthreads();
+  auto FR = [&](int f) -> h8 { uint4 u = frags[f][lane]; return *reinterpret_cast<h8*>(&u); };
+  const h8 I0 = ident_frag(lane, 0), I1 = ident_frag(lane, 1);
+
+  // dW accumulators, C layout: [m = 16*mt + 4g + r][k = 16*nt + i]
+  f4 dWo[4];
+  f4 dWh[(NH > 1 ? NH - 1 : 1)][4][4];
+  f4 dW1[4][IN_TILES];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) dWo[a] = f4{0, 0, 0, 0};
+#pragma unroll
+  for (int l = 0; l < (NH > 1 ? NH - 1 : 1); ++l)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) dWh[l][a][b] = f4{0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < IN_TILES; ++b) dW1[a][b] = f4{0, 0, 0, 0};
+
+  const int64_t n_macro = (P + 31) / 32;
+  for (int64_t mtile = (int64_t)blockIdx.x * 4 + wave; mtile < n_macro; mtile += (int64_t)gridDim.x * 4) {
+    int64_t rows[2];
+    bool ok[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      rows[a] = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
+      ok[a] = rows[a] < P;
+    }
+    // ---- output layer ----------------------------------------------------------------------
+    h8 dzf[2][2];  // chain B fragments of the current layer's dZ: [a][ks]
+    h8 dzT[4];     // orientation-2: lane = feature 16*nt + i, 8 rows
+    h8 dyT;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (ok[a] && g < 2) u = *reinterpret_cast<const uint4*>(dy + rows[a] * 16 + 8 * g);
+      dzf[a][0] = *reinterpret_cast<h8*>(&u);
+    }
+    {
+      f4 t0 = MFMA(dzf[0][0], I0, (f4{0, 0, 0, 0}));
+      f4 t1 = MFMA(dzf[1][0], I0, (f4{0, 0, 0, 0}));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dyT[r] = f2h(t0[r]);
+        dyT[4 + r] = f2h(t1[r]);
+      }
+    }
+    // activations of the last hidden layer, chain layout [a][ks]
+    h8 hf[2][2];
+    {
+      const half_t* a_l = act + (int64_t)(NH - 1) * cap * HID;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          uint4 u = make_uint4(0, 0, 0, 0);
+          if (ok[a]) u = *reinterpret_cast<const uint4*>(a_l + rows[a] * HID + 32 * ks + 8 * g);
+          hf[a][ks] = *reinterpret_cast<h8*>(&u);
+        }
+    }
+    h8 hT[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const h8 sel = (nt & 1) ? I1 : I0;
+      f4 t0 = MFMA(hf[0][nt >> 1], sel, (f4{0, 0, 0, 0}));
+      f4 t1 = MFMA(hf[1][nt >> 1], sel, (f4{0, 0, 0, 0}));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        hT[nt][r] = f2h(t0[r]);
+        hT[nt][4 + r] = f2h(t1[r]);
+      }
+      dWo[nt] = MFMA(dyT, hT[nt], dWo[nt]);
+    }
+    // dH_NH (chain) and dH_NH' (orientation 2), masked by ReLU
+    {
+      h8 nz[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        f4 c[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          c[mt] = MFMA(FR(L::WOT_P + mt), dzf[a][0], (f4{0, 0, 0, 0}));
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!(hf[a][mt >> 1][4 * (mt & 1) + r] > (half_t)0.0f)) c[mt][r] = 0.0f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            nz[a][ks][r] = f2h(clamp_h(c[2 * ks][r]));
+            nz[a][ks][4 + r] = f2h(clamp_h(c[2 * ks + 1][r]));
+          }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f4 t0 = MFMA(dzf[0][0], FR(L::WOT_N + nt), (f4{0, 0, 0, 0}));
+        f4 t1 = MFMA(dzf[1][0], FR(L::WOT_N + nt), (f4{0, 0, 0, 0}));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h(clamp_h(t0[r])) : (half_t)0.0f;
+          dzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h(clamp_h(t1[r])) : (half_t)0.0f;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dzf[a][ks] = nz[a][ks];
+    }
+    // ---- hidden layers NH .. 2 -------------------------------------------------------------
+#pragma unroll
+    for (int li = 0; li < NH - 1; ++li) {
+      const int layer = NH - li;  // current dZ belongs to hidden layer `layer`; its input is H_{layer-1}
+      const half_t* a_l = act + (int64_t)(layer - 2) * cap * HID;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          uint4 u = make_uint4(0, 0, 0, 0);
+          if (ok[a]) u = *reinterpret_cast<const uint4*>(a_l + rows[a] * HID + 32 * ks + 8 * g);
+          hf[a][ks] = *reinterpret_cast<h8*>(&u);
+        }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const h8 sel = (nt & 1) ? I1 : I0;
+        f4 t0 = MFMA(hf[0][nt >> 1], sel, (f4{0, 0, 0, 0}));
+        f4 t1 = MFMA(hf[1][nt >> 1], sel, (f4{0, 0, 0, 0}));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hT[nt][r] = f2h(t0[r]);
+          hT[nt][4 + r] = f2h(t1[r]);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) dWh[layer - 2][mt][nt] = MFMA(dzT[mt], hT[nt], dWh[layer - 2][mt][nt]);
+      const int fb = L::WH + li * 16;
+      h8 nz[2][2], nzT[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        f4 c[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          c[mt] = MFMA(FR(fb + mt * 2 + 0), dzf[a][0], (f4{0, 0, 0, 0}));
+          c[mt] = MFMA(FR(fb + mt * 2 + 1), dzf[a][1], c[mt]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!(hf[a][mt >> 1][4 * (mt & 1) + r] > (half_t)0.0f)) c[mt][r] = 0.0f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            nz[a][ks][r] = f2h(clamp_h(c[2 * ks][r]));
+            nz[a][ks][4 + r] = f2h(clamp_h(c[2 * ks + 1][r]));
+          }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f4 t0 = MFMA(dzf[0][0], FR(fb + 8 + nt * 2 + 0), (f4{0, 0, 0, 0}));
+        t0 = MFMA(dzf[0][1], FR(fb + 8 + nt * 2 + 1), t0);
+        f4 t1 = MFMA(dzf[1][0], FR(fb + 8 + nt * 2 + 0), (f4{0, 0, 0, 0}));
+        t1 = MFMA(dzf[1][1], FR(fb + 8 + nt * 2 + 1), t1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          nzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h(clamp_h(t0[r])) : (half_t)0.0f;
+          nzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h(clamp_h(t1[r])) : (half_t)0.0f;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dzf[a][ks] = nz[a][ks];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) dzT[nt] = nzT[nt];
+    }
+    // ---- first layer: dW1 = dZ1^T X, dX = dZ1 W1 ---------------------------------------------
+    {
+      h8 xf[2][KS_IN];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < KS_IN; ++ks) {
+          const int k0 = 32 * ks + 8 * g;
+          uint4 u = make_uint4(0, 0, 0, 0);
+          if (ok[a] && k0 < IN_PAD) u = *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
+          xf[a][ks] = *reinterpret_cast<h8*>(&u);
+        }
+#pragma unroll
+      for (int nt = 0; nt < IN_TILES; ++nt) {
+        const h8 sel = (nt & 1) ? I1 : I0;
+        f4 t0 = MFMA(xf[0][nt >> 1], sel, (f4{0, 0, 0, 0}));
+        f4 t1 = MFMA(xf[1][nt >> 1], sel, (f4{0, 0, 0, 0}));
+        h8 xT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          xT[r] = f2h(t0[r]);
+          xT[4 + r] = f2h(t1[r]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) dW1[mt][nt] = MFMA(dzT[mt], xT, dW1[mt][nt]);
+      }
+      if (dx) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int mt = 0; mt < IN_TILES; ++mt) {
+            f4 c = MFMA(FR(L::W1T + mt * 2 + 0), dzf[a][0], (f4{0, 0, 0, 0}));
+            c = MFMA(FR(L::W1T + mt * 2 + 1), dzf[a][1], c);
+            if (ok[a]) {
+              h4 ov;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ov[r] = f2h(clamp_h(c[r]));
+              *reinterpret_cast<h4*>(dx + rows[a] * IN_PAD + 16 * mt + 4 * g) = ov;
+            }
+          }
+      }
+    }
+  }
+
+  // ---- flush dW (fp32 atomics; one add per element per wave) ----------------------------------
+  float* gW1 = grad_w;
+  float* gWo = grad_w + HID * IN_PAD + (NH - 1) * HID * HID;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < IN_TILES; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = dW1[mt][nt][r] * inv_scale;
+        if (v != 0.0f) atomicAdd(gW1 + (16 * mt + 4 * g + r) * IN_PAD + 16 * nt + i, v);
+      }
+#pragma unroll
+  for (int l = 0; l < NH - 1; ++l) {
+    float* gWl = grad_w + HID * IN_PAD + l * HID * HID;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = dWh[l][mt][nt][r] * inv_scale;
+          if (v != 0.0f) atomicAdd(gWl + (16 * mt + 4 * g + r) * HID + 16 * nt + i, v);
+        }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = dWo[nt][r] * inv_scale;
+      if (v != 0.0f) atomicAdd(gWo + (4 * g + r) * HID + 16 * nt + i, v);
+    }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+static int grid_for(int64_t tiles) {
+  int64_t blocks = (tiles + 3) / 4;
+  if (blocks > 2048) blocks = 2048;  // 256 CUs x 8; waves grid-stride over the rest
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+#define FOR_EACH_CFG(X) X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3) X(4, 1) X(4, 2) X(4, 3) X(6, 1) X(6, 2) X(6, 3) X(8, 1) X(8, 2) X(8, 3)
+
+extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad, int32_t n_hidden,
+                           const void* weights, void* y, void* act, void* stream) {
+  if (P == 0) return 0;
+  const int in_tiles = in_pad / 16;
+  const int grid = grid_for((P + 15) / 16);
+  bool done = false;
+#define X(IT, NHH)                                                                                                   \
+  if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
+    hipLaunchKernelGGL((mlp_fwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, P, \
+                       n_rows, (const half_t*)weights, (half_t*)y, (half_t*)act);                                           \
+    done = true;                                                                                                     \
+  }
+  FOR_EACH_CFG(X)
+#undef X
+  if (!done) {
+    l4d_set_error(1, "l4d_mlp_fwd: unsupported (in_pad, n_hidden); in_pad in {16,32,64,96,128}, n_hidden in 1..3");
+    return 1;
+  }
+  L4D_LAUNCH_CHECK("l4d_mlp_fwd");
+  return 0;
+}
+
+extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64_t P, const int32_t* n_rows, int32_t in_pad,
+                           int32_t n_hidden, const void* weights, void* dx, float* grad_w, float inv_loss_scale,
+                           void* stream) {
+  if (P == 0) return 0;
+  const int in_tiles = in_pad / 16;
+  int grid = grid_for((P + 31) / 32);
+  if (grid > 512) grid = 512;  // each wave flushes a full dW with atomics: keep the wave count bounded
+  bool done = false;
+#define X(IT, NHH)                                                                                                   \
+  if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
+    hipLaunchKernelGGL((mlp_bwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,   \
+                       (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights, (half_t*)dx, grad_w, \
+                       inv_loss_scale);                                                                              \
+    done = true;                                                                                                     \
+  }
+  FOR_EACH_CFG(X)
+#undef X
+  if (!done) {
+    l4d_set_error(1, "l4d_mlp_bwd: unsupported (in_pad, n_hidden)");
+    return 1;
+  }
+  L4D_LAUNCH_CHECK("l4d_mlp_bwd");
+  return 0;
+}

@@ -1,0 +1,171 @@
+"""Fused HIP render pipeline behind ``LiDAR4D.run`` (reference call stack SURVEY.md 3.1:
+renderer.py:44-140 -> lidar4d.py:139-223).
+
+Forward, 14 launches, no host synchronisation (the reference needs 4: lidar4d.py:143,201,203, hash_field.py:82):
+
+  time_setup -> sample_rays_xt -> flow grid+interpT -> flow MLP -> fused field encode -> sigma MLP -> trunc_exp
+  -> composite (weights, depth, wave-level mask compaction) -> frequency encode (per ray) -> attribute gather
+  -> raydrop MLP, intensity MLP (device-sized work list) -> sigmoid+scatter -> image
+
+Backward is the exact adjoint, accumulating parameter gradients straight into the model's flat gradient arena
+(ParamStore); autograd sees one node.  fp16 adjoint operands carry ``model.loss_scale`` (tiny-cuda-nn uses the
+same device: SURVEY A.1/A.3, loss_scale 128).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import FieldDesc, FieldGrads
+
+
+def _field_desc(model):
+    store = model._store
+    f16 = store.refresh16()
+    arena = model.planes_encoder._arena()
+    key = (f16.data_ptr(), arena.data_ptr())
+    if getattr(model, "_fd_key", None) == key:
+        return model._fd
+    he, pe = model.hash_encoder, model.planes_encoder
+    fd = FieldDesc()
+    fd.hash_static = he.hash_static.meta.desc()
+    fd.hash_static_table = store.half(he.hash_static.params).data_ptr()
+    fd.n_slices = he.hash_dynamic[0].time_resolution
+    for p in range(3):
+        fd.hash_dynamic[p] = he.hash_dynamic[p].meta.desc()
+        for s in range(fd.n_slices):
+            fd.hash_dynamic_tables[p][s] = store.half(he.hash_dynamic[p].hash_t[s].params).data_ptr()
+    lay = pe.layout
+    fd.n_scales, fd.plane_channels = lay.n_scales, lay.C
+    for i, v in enumerate([v for r in lay.res for v in r]):
+        fd.plane_res[i] = v
+    for i, v in enumerate(lay.off):
+        fd.plane_off[i] = v
+    fd.planes_cl = arena.data_ptr()
+    model._fd, model._fd_key = fd, key
+    return fd
+
+
+def _field_grads(model, planes_grad_cl):
+    store = model._store
+    he = model.hash_encoder
+    fg = FieldGrads()
+    fg.hash_static_table = store.grad_view(he.hash_static.params).data_ptr()
+    for p in range(3):
+        for s in range(he.hash_dynamic[p].time_resolution):
+            fg.hash_dynamic_tables[p][s] = store.grad_view(he.hash_dynamic[p].hash_t[s].params).data_ptr()
+    fg.planes_cl = planes_grad_cl.data_ptr()
+    return fg
+
+
+def _flow_w16(model):
+    store = model._store
+    w0 = model.flow_net.linears()[0].weight
+    off, _ = store.by_param[id(w0)]
+    return store.refresh16()[off:off + model.flow_net.weight_numel16()]
+
+
+def _flow_wgrad(model):
+    store = model._store
+    w0 = model.flow_net.linears()[0].weight
+    off, _ = store.by_param[id(w0)]
+    return store.flat_grad[off:off + model.flow_net.weight_numel16()]
+
+
+class RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, t_dev, noise, num_steps, train, *params):
+        store = model._store
+        N, T = rays_o.shape[0], int(num_steps)
+        P = N * T
+        dev = rays_o.device
+        near32, far32 = np.float32(model.near_lidar), np.float32(model.far_lidar)
+        sample_dist = float(np.float32(far32 - near32) / np.float32(T))
+        lin = model._lin(T, dev)
+
+        tinfo = ops.time_setup(t_dev, model.num_frames)
+        z_vals, xt = ops.sample_rays_xt(rays_o, rays_d, lin, noise, t_dev, float(near32), float(far32), model.bound)
+
+        # flow field (flow_field.py:113-130)
+        fn = model.flow_net
+        xf = ops.hashgrid_t_fwd(fn.grid_enc.meta, xt, (0, 1, 2), [store.half(fn.grid_enc.params)], t_dev, half_out=True)
+        flow16, act_f = ops.mlp_fwd(xf, _flow_w16(model), fn.n_hidden, save_act=train)
+
+        # density (lidar4d.py:139-188)
+        fd = _field_desc(model)
+        X = ops.density_encode_fwd(fd, xt, flow16, tinfo, model.sigma_net.in_pad)
+        h, act_s = ops.mlp_fwd(X, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers, save_act=train)
+        sigma = ops.sigma_from_h(h)
+
+        # compositing + mask compaction (renderer.py:98-110)
+        weights, wsum, depth, _, idx, count = ops.composite_fwd(sigma, z_vals, sample_dist, model.density_scale,
+                                                                model.active_sensor, want_mask=False, want_idx=True)
+
+        # attribute (lidar4d.py:191-223) on the compacted work list
+        denc = ops.freq_fwd(((rays_d + 1) / 2).contiguous(), model.view_encoder.n_frequencies)
+        an = model.intensity_net
+        XA = ops.attr_gather(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad)
+        yR, actR = ops.mlp_fwd(XA, store.half(model.raydrop_net.params), an.n_hidden_layers, save_act=train, n_rows=count)
+        yI, actI = ops.mlp_fwd(XA, store.half(model.intensity_net.params), an.n_hidden_layers, save_act=train, n_rows=count)
+        attr = torch.zeros(P, 2, dtype=torch.float32, device=dev)
+        attr_c = torch.empty(P, 2, dtype=torch.float32, device=dev)
+        ops.attr_scatter(idx, count, P, yR, yI, attr, attr_c)
+        image = ops.composite_image(weights, attr, 2)
+
+        if train:
+            ctx.model, ctx.T, ctx.sample_dist = model, T, sample_dist
+            ctx.save_for_backward(t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count,
+                                  XA, actR, actI, attr, attr_c)
+        ctx.mark_non_differentiable(z_vals, idx, count)
+        return depth, image, wsum, weights, z_vals, idx, count
+
+    @staticmethod
+    def backward(ctx, d_depth, d_image, d_wsum, d_weights, _dz, _di, _dc):
+        model, T, sample_dist = ctx.model, ctx.T, ctx.sample_dist
+        (t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count, XA, actR, actI, attr,
+         attr_c) = ctx.saved_tensors
+        store = model._store
+        store.prepare_grads()
+        ls = float(model.loss_scale)
+        inv = 1.0 / ls
+        P = xt.shape[0]
+        dev = xt.device
+        c = lambda t: None if t is None else t.float().contiguous()
+
+        d_sigma, d_attr = ops.composite_bwd(sigma, z_vals, weights, attr, 2, sample_dist, model.density_scale,
+                                            model.active_sensor, c(d_depth), c(d_wsum), c(d_image), c(d_weights))
+        # attribute networks
+        an = model.intensity_net
+        dyR = torch.empty(P, 16, dtype=torch.float16, device=dev)
+        dyI = torch.empty(P, 16, dtype=torch.float16, device=dev)
+        ops.attr_scatter_bwd(idx, count, P, d_attr, attr_c, ls, dyR, dyI)
+        dxaR = ops.mlp_bwd(XA, actR, dyR, store.half(model.raydrop_net.params), an.n_hidden_layers,
+                           store.grad_view(model.raydrop_net.params), inv, n_rows=count)
+        dxaI = ops.mlp_bwd(XA, actI, dyI, store.half(model.intensity_net.params), an.n_hidden_layers,
+                           store.grad_view(model.intensity_net.params), inv, n_rows=count)
+        dh = torch.zeros(P, 16, dtype=torch.float16, device=dev)
+        ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad, model.view_encoder.n_output_dims, model.geo_feat_dim, dh)
+        ops.sigma_bwd(h, d_sigma.view(-1), ls, dh)
+        # sigma network
+        dX = ops.mlp_bwd(X, act_s, dh, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,
+                         store.grad_view(model.sigma_net.params), inv)
+        # field
+        pe = model.planes_encoder
+        gcl = torch.zeros(pe.layout.numel, dtype=torch.float32, device=dev)
+        fd = _field_desc(model)
+        dflow16 = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv)
+        tmp = torch.empty(pe.layout.numel, dtype=torch.float32, device=dev)
+        planes = pe._flat_planes()
+        views, o = [], 0
+        for p in planes:
+            views.append(tmp[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        ops.planes_relayout(pe.layout, views, gcl, to_channel_last=False)
+        for p, v in zip(planes, views):
+            store.grad_view(p).add_(v.reshape(-1))
+        # flow network + grid
+        fn = model.flow_net
+        dxf = ops.mlp_bwd(xf, act_f, dflow16, _flow_w16(model), fn.n_hidden, _flow_wgrad(model), inv)
+        ops.hashgrid_t_bwd(fn.grid_enc.meta, xt, (0, 1, 2), 1, t_dev, dxf, [store.grad_view(fn.grid_enc.params)], inv)
+        return (None,) * 7 + (None,) * (len(ctx.needs_input_grad) - 7)

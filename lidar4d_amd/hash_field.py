@@ -1,0 +1,100 @@
+"""4-D hash field: one static 3-D hash grid + three 2-D x time stacks (xy, xz, yz).
+
+Mirror of the reference's model/hash_field.py (HashGridT :30-88, HashGrid4D :91-172): same constructor
+arguments, attribute names and state-dict keys (``hash_static.params``, ``hash_dynamic.{p}.hash_t.{k}.params``).
+HashGridT.forward is ONE kernel (two time slices + linear blend + cubic-Lagrange interpT,
+l4d_hashgrid_t_fwd) instead of two tcnn launches and ~20 elementwise kernels.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import tcnn
+
+
+def _t_device(t, device):
+    """1-element fp32 device tensor holding the call's time (python float, 0-dim CPU tensor or [1,1] tensor)."""
+    if torch.is_tensor(t):
+        return t.detach().to(device=device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+    return torch.tensor([float(t)], dtype=torch.float32, device=device)
+
+
+def _slice_pair_host(t, n_slices):
+    """(i1, i2) exactly as the kernels derive them from *t (fp32 arithmetic; hash_field.py:79-81)."""
+    idx = np.float32(t) * np.float32(n_slices - 1)
+    return int(np.floor(idx)), int(np.ceil(idx))
+
+
+class _HashGridTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t_dev, mod, i1, i2, p1, p2):
+        x = x.detach().to(torch.float32).contiguous()
+        tables = [enc._half_params() for enc in mod.hash_t]
+        out = ops.hashgrid_t_fwd(mod.meta, x, (0, 1), tables, t_dev)
+        ctx.mod, ctx.i1, ctx.i2 = mod, i1, i2
+        ctx.save_for_backward(x, t_dev)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, t_dev = ctx.saved_tensors
+        mod, i1, i2 = ctx.mod, ctx.i1, ctx.i2
+        g1 = torch.zeros_like(mod.hash_t[i1].params)
+        g2 = g1 if i2 == i1 else torch.zeros_like(mod.hash_t[i2].params)
+        grads = [None] * mod.time_resolution
+        grads[i1], grads[i2] = g1, g2
+        ops.hashgrid_t_bwd(mod.meta, x, (0, 1), mod.time_resolution, t_dev, dout.float().contiguous(), grads, 1.0)
+        return None, None, None, None, None, g1, (None if i2 == i1 else g2)
+
+
+class HashGridT(nn.Module):
+    def __init__(self, time_resolution=8, base_resolution=512, max_resolution=32768, n_levels=8,
+                 n_features_per_level=4, log2_hashmap_size=14, num_basis=4):
+        super().__init__()
+        if num_basis != 4 or n_features_per_level != 4:
+            raise ValueError("HashGridT: the HIP kernel implements num_basis = n_features_per_level = 4 (reference default)")
+        self.time_resolution = time_resolution
+        per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
+        cfg = {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
+               "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution,
+               "per_level_scale": per_level_scale}
+        self.hash_t = nn.ModuleList([tcnn.Encoding(n_input_dims=2, encoding_config=cfg) for _ in range(time_resolution)])
+        self.meta = self.hash_t[0].meta
+        self.n_levels, self.n_features_per_level, self.num_basis = n_levels, n_features_per_level, num_basis
+        self.n_output_dims = n_levels * n_features_per_level // num_basis
+
+    def forward(self, x, t):
+        t_dev = _t_device(t, x.device)
+        i1, i2 = _slice_pair_host(float(t_dev), self.time_resolution)  # host sync, as the reference's `if idx1 == idx2`
+        return _HashGridTFn.apply(x, t_dev, self, i1, i2, self.hash_t[i1].params, self.hash_t[i2].params)
+
+
+class HashGrid4D(nn.Module):
+    def __init__(self, base_resolution=512, max_resolution=32768, time_resolution=8, n_levels=8,
+                 n_features_per_level=4, log2_hashmap_size=19, hash_size_dynamic=(15, 13, 13), decompose=True,
+                 reduction="concat"):
+        super().__init__()
+        if reduction != "concat" or not decompose:
+            raise ValueError("HashGrid4D: only the reference defaults decompose=True, reduction='concat' are implemented")
+        per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
+        self.hash_static = tcnn.Encoding(n_input_dims=3, encoding_config={
+            "otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
+            "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution,
+            "per_level_scale": per_level_scale})
+        self.hash_dynamic = nn.ModuleList([
+            HashGridT(time_resolution=time_resolution, base_resolution=base_resolution, max_resolution=max_resolution,
+                      n_levels=n_levels, n_features_per_level=n_features_per_level,
+                      log2_hashmap_size=hash_size_dynamic[i]) for i in range(3)])
+        self.decompose, self.reduction = decompose, reduction
+        self.n_output_dims = self.hash_static.n_output_dims + 3 * self.hash_dynamic[0].n_output_dims
+
+    def forward_static(self, x):
+        return self.hash_static(x)
+
+    def forward_dynamic(self, x, t):
+        xy, xz, yz = x[:, [0, 1]], x[:, [0, 2]], x[:, [1, 2]]
+        return torch.cat([self.hash_dynamic[0](xy, t), self.hash_dynamic[1](xz, t), self.hash_dynamic[2](yz, t)], dim=-1)
+
+    def forward(self, x, t):
+        return [self.forward_static(x), self.forward_dynamic(x, t)]

@@ -1,0 +1,323 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/lidar4d_hip.h).
+
+Every wrapper checks device / dtype / contiguity, allocates nothing it was not asked to, and launches
+on the current torch stream.  Tensors must live on a HIP device: there is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.HipExtensionError(
+            f"{name} is on {t.device}: the lidar4d_amd hot path runs only on a HIP device (no CPU fallback; "
+            "the CPU restatement is oracle/, test infrastructure)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def _i32s(vals):
+    return (C.c_int32 * len(vals))(*vals)
+
+
+def _i64s(vals):
+    return (C.c_int64 * len(vals))(*vals)
+
+
+def _ptrs(tensors):
+    return (C.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+# ---- hash grid -----------------------------------------------------------------------------------
+def hashgrid_fwd(meta, x, cols, table16, out=None, out_col=0):
+    """x [P, S] fp32 (grid coords = columns ``cols``), table16 fp16 flat -> out [P, >= L*F] fp16."""
+    _chk(x, torch.float32, "x"), _chk(table16, torch.float16, "table")
+    P = x.shape[0]
+    if out is None:
+        out = torch.empty(P, meta.n_output_dims, dtype=torch.float16, device=x.device)
+    _chk(out, torch.float16, "out")
+    d = meta.desc()
+    call("l4d_hashgrid_fwd", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _p(table16),
+         C.c_void_p(out.data_ptr() + 2 * out_col), out.stride(0), _stream())
+    return out
+
+
+def hashgrid_bwd(meta, x, cols, dout, grad_table, grad_scale=1.0, dout_col=0):
+    _chk(x, torch.float32, "x"), _chk(dout, None, "dout"), _chk(grad_table, torch.float32, "grad_table")
+    is_half = dout.dtype == torch.float16
+    if not is_half and dout.dtype != torch.float32:
+        raise TypeError("dout must be fp16 or fp32")
+    d = meta.desc()
+    call("l4d_hashgrid_bwd", C.byref(d), _p(x), x.shape[0], x.stride(0), _i32s(list(cols)),
+         C.c_void_p(dout.data_ptr() + dout.element_size() * dout_col), dout.stride(0), int(is_half), float(grad_scale),
+         _p(grad_table), _stream())
+
+
+def hashgrid_t_fwd(meta, x, cols, tables16, t_dev, out=None, out_col=0, half_out=False):
+    """Fused time-blend + interpT.  tables16: list of fp16 tables (1 = no blend); t_dev: 1-element fp32 device tensor."""
+    _chk(x, torch.float32, "x"), _chk(t_dev, torch.float32, "t")
+    for tb in tables16:
+        _chk(tb, torch.float16, "table")
+    P = x.shape[0]
+    width = meta.n_levels * meta.n_features // 4
+    if out is None:
+        out = torch.empty(P, width, dtype=torch.float16 if half_out else torch.float32, device=x.device)
+    _chk(out, None, "out")
+    d = meta.desc()
+    call("l4d_hashgrid_t_fwd", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _ptrs(tables16), len(tables16),
+         _p(t_dev), C.c_void_p(out.data_ptr() + out.element_size() * out_col), out.stride(0),
+         int(out.dtype == torch.float16), _stream())
+    return out
+
+
+def hashgrid_t_bwd(meta, x, cols, n_slices, t_dev, dout, grad_tables, grad_scale=1.0, dout_col=0):
+    """grad_tables: list of n_slices fp32 tensors or None (slices that *t does not select are never touched)."""
+    _chk(x, torch.float32, "x"), _chk(dout, None, "dout")
+    d = meta.desc()
+    call("l4d_hashgrid_t_bwd", C.byref(d), _p(x), x.shape[0], x.stride(0), _i32s(list(cols)), n_slices, _p(t_dev),
+         C.c_void_p(dout.data_ptr() + dout.element_size() * dout_col), dout.stride(0), int(dout.dtype == torch.float16),
+         float(grad_scale), _ptrs(grad_tables), _stream())
+
+
+# ---- planes ----------------------------------------------------------------------------------------
+class PlaneLayout:
+    """Channel-last arena geometry for Planes4D (comb order of itertools.combinations(range(4), 2))."""
+    COMBS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+
+    def __init__(self, resolutions, channels):
+        self.res = [list(r) for r in resolutions]  # per scale (x, y, z, t)
+        self.n_scales = len(self.res)
+        self.C = channels
+        self.off = []
+        o = 0
+        for r in self.res:
+            for a, b in self.COMBS:
+                self.off.append(o)
+                o += r[a] * r[b] * channels
+        self.numel = o
+        self.res_flat = _i32s([v for r in self.res for v in r])
+        self.off_flat = _i64s(self.off)
+
+    def plane_shape(self, s, c):
+        a, b = self.COMBS[c]
+        return (1, self.C, self.res[s][b], self.res[s][a])
+
+
+def planes_relayout(layout, planes, arena, to_channel_last=True):
+    """planes: list (scale-major, 6 per scale) of [1,C,H,W] fp32 tensors <-> arena (flat fp32 channel-last)."""
+    for pl in planes:
+        _chk(pl, torch.float32, "plane")
+    _chk(arena, torch.float32, "arena")
+    call("l4d_planes_relayout", _ptrs(planes), layout.res_flat, layout.n_scales, layout.C, _p(arena), layout.off_flat,
+         int(to_channel_last), _stream())
+
+
+def planes_fwd(layout, arena, xt, which=0):
+    _chk(arena, torch.float32, "arena"), _chk(xt, torch.float32, "xt")
+    P = xt.shape[0]
+    n_out = layout.n_scales * layout.C
+    out_s = torch.empty(P, n_out, dtype=torch.float32, device=xt.device) if which != 2 else None
+    out_d = torch.empty(P, n_out, dtype=torch.float32, device=xt.device) if which != 1 else None
+    call("l4d_planes_fwd", _p(arena), layout.off_flat, layout.res_flat, layout.n_scales, layout.C, _p(xt), P, which,
+         _p(out_s), _p(out_d), _stream())
+    return out_s, out_d
+
+
+def planes_bwd(layout, arena, xt, which, dout_s, dout_d, grad_arena, want_dxt):
+    _chk(arena, torch.float32, "arena"), _chk(xt, torch.float32, "xt"), _chk(grad_arena, torch.float32, "grad_arena")
+    _chk(dout_s, torch.float32, "dout_s"), _chk(dout_d, torch.float32, "dout_d")
+    dxt = torch.empty_like(xt) if want_dxt else None
+    call("l4d_planes_bwd", _p(arena), layout.off_flat, layout.res_flat, layout.n_scales, layout.C, _p(xt), xt.shape[0],
+         which, _p(dout_s), _p(dout_d), _p(grad_arena), _p(dxt), _stream())
+    return dxt
+
+
+# ---- frequency encoding / MLP ----------------------------------------------------------------------
+def freq_fwd(x, n_freq=12, out=None):
+    _chk(x, torch.float32, "x")
+    P, D = x.shape
+    if out is None:
+        out = torch.empty(P, D * n_freq * 2, dtype=torch.float16, device=x.device)
+    call("l4d_freq_fwd", _p(x), P, D, n_freq, _p(out), out.stride(0), _stream())
+    return out
+
+
+def mlp_fwd(x16, weights16, n_hidden, save_act=True, n_rows=None, y=None, act=None):
+    """x16 [P, in_pad] fp16 -> y [P,16] fp16 (+ act [n_hidden, P, 64] fp16)."""
+    _chk(x16, torch.float16, "x"), _chk(weights16, torch.float16, "weights"), _chk(n_rows, torch.int32, "n_rows")
+    P, in_pad = x16.shape
+    if y is None:
+        y = torch.empty(P, 16, dtype=torch.float16, device=x16.device)
+    if save_act and act is None:
+        act = torch.empty(n_hidden, P, 64, dtype=torch.float16, device=x16.device)
+    call("l4d_mlp_fwd", _p(x16), P, _p(n_rows), in_pad, n_hidden, _p(weights16), _p(y), _p(act), _stream())
+    return y, act
+
+
+def mlp_bwd(x16, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale, n_rows=None, want_dx=True, dx=None):
+    _chk(x16, torch.float16, "x"), _chk(act, torch.float16, "act"), _chk(dy16, torch.float16, "dy")
+    _chk(weights16, torch.float16, "weights"), _chk(grad_w, torch.float32, "grad_w"), _chk(n_rows, torch.int32, "n_rows")
+    P, in_pad = x16.shape
+    if want_dx and dx is None:
+        dx = torch.empty(P, in_pad, dtype=torch.float16, device=x16.device)
+    call("l4d_mlp_bwd", _p(x16), _p(act), _p(dy16), P, _p(n_rows), in_pad, n_hidden, _p(weights16), _p(dx), _p(grad_w),
+         float(inv_loss_scale), _stream())
+    return dx
+
+
+# ---- renderer --------------------------------------------------------------------------------------
+def sample_rays(rays_o, rays_d, lin, noise, near, far, bound, want_xyz=True):
+    _chk(rays_o, torch.float32, "rays_o"), _chk(rays_d, torch.float32, "rays_d"), _chk(lin, torch.float32, "lin")
+    _chk(noise, torch.float32, "noise")
+    N, T = rays_o.shape[0], lin.shape[0]
+    z = torch.empty(N, T, dtype=torch.float32, device=rays_o.device)
+    xyz = torch.empty(N * T, 3, dtype=torch.float32, device=rays_o.device) if want_xyz else None
+    call("l4d_sample_rays", _p(rays_o), _p(rays_d), _p(lin), _p(noise), N, T, float(near), float(far), float(bound),
+         _p(z), _p(xyz), _stream())
+    return z, xyz
+
+
+def sample_rays_xt(rays_o, rays_d, lin, noise, t_dev, near, far, bound):
+    _chk(rays_o, torch.float32, "rays_o"), _chk(rays_d, torch.float32, "rays_d"), _chk(lin, torch.float32, "lin")
+    _chk(noise, torch.float32, "noise"), _chk(t_dev, torch.float32, "t")
+    N, T = rays_o.shape[0], lin.shape[0]
+    z = torch.empty(N, T, dtype=torch.float32, device=rays_o.device)
+    xt = torch.empty(N * T, 4, dtype=torch.float32, device=rays_o.device)
+    call("l4d_sample_rays_xt", _p(rays_o), _p(rays_d), _p(lin), _p(noise), _p(t_dev), N, T, float(near), float(far),
+         float(bound), _p(z), _p(xt), _stream())
+    return z, xt
+
+
+def composite_fwd(sigma, z_vals, sample_dist, density_scale, active_sensor, want_mask=True, want_idx=True):
+    _chk(sigma, torch.float32, "sigma"), _chk(z_vals, torch.float32, "z_vals")
+    N, T = z_vals.shape
+    dev = z_vals.device
+    weights = torch.empty(N, T, dtype=torch.float32, device=dev)
+    wsum = torch.empty(N, dtype=torch.float32, device=dev)
+    depth = torch.empty(N, dtype=torch.float32, device=dev)
+    mask = torch.empty(N, T, dtype=torch.uint8, device=dev) if want_mask else None
+    idx = torch.empty(N * T, dtype=torch.int32, device=dev) if want_idx else None
+    count = torch.empty(1, dtype=torch.int32, device=dev) if want_idx else None
+    call("l4d_composite_fwd", _p(sigma), _p(z_vals), N, T, float(sample_dist), float(density_scale), int(active_sensor),
+         _p(weights), _p(wsum), _p(depth), _p(mask), _p(idx), _p(count), _stream())
+    return weights, wsum, depth, mask, idx, count
+
+
+def composite_image(weights, attr, C_out):
+    _chk(weights, torch.float32, "weights"), _chk(attr, torch.float32, "attr")
+    N, T = weights.shape
+    image = torch.empty(N, C_out, dtype=torch.float32, device=weights.device)
+    call("l4d_composite_image", _p(weights), _p(attr), N, T, C_out, _p(image), _stream())
+    return image
+
+
+def composite_bwd(sigma, z_vals, weights, attr, C_out, sample_dist, density_scale, active_sensor, d_depth, d_wsum,
+                  d_image, d_weights, want_d_attr=True):
+    for nm, t in (("sigma", sigma), ("z_vals", z_vals), ("weights", weights), ("attr", attr), ("d_depth", d_depth),
+                  ("d_wsum", d_wsum), ("d_image", d_image), ("d_weights", d_weights)):
+        _chk(t, torch.float32, nm)
+    N, T = z_vals.shape
+    d_sigma = torch.empty(N, T, dtype=torch.float32, device=z_vals.device)
+    d_attr = torch.empty(N * T, C_out, dtype=torch.float32, device=z_vals.device) if want_d_attr else None
+    call("l4d_composite_bwd", _p(sigma), _p(z_vals), _p(weights), _p(attr), N, T, C_out, float(sample_dist),
+         float(density_scale), int(active_sensor), _p(d_depth), _p(d_wsum), _p(d_image), _p(d_weights), _p(d_sigma),
+         _p(d_attr), _stream())
+    return d_sigma, d_attr
+
+
+def attr_gather(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, xa=None):
+    _chk(idx, torch.int32, "idx"), _chk(count, torch.int32, "count"), _chk(dir_enc16, torch.float16, "dir_enc")
+    _chk(h16, torch.float16, "h")
+    if xa is None:
+        xa = torch.empty(cap, in_pad, dtype=torch.float16, device=h16.device)
+    call("l4d_attr_gather", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, _p(xa), in_pad,
+         _stream())
+    return xa
+
+
+def attr_scatter(idx, count, cap, y_raydrop, y_intensity, attr_dense, attr_compact):
+    call("l4d_attr_scatter", _p(idx), _p(count), cap, _p(y_raydrop), _p(y_intensity), _p(attr_dense), _p(attr_compact),
+         _stream())
+
+
+def attr_scatter_bwd(idx, count, cap, d_attr, attr_compact, loss_scale, dy_r, dy_i):
+    call("l4d_attr_scatter_bwd", _p(idx), _p(count), cap, _p(d_attr), _p(attr_compact), float(loss_scale), _p(dy_r),
+         _p(dy_i), _stream())
+
+
+def attr_gather_bwd(idx, count, cap, dxa_r, dxa_i, in_pad, n_enc, n_geo, dh16):
+    call("l4d_attr_gather_bwd", _p(idx), _p(count), cap, _p(dxa_r), _p(dxa_i), in_pad, n_enc, n_geo, _p(dh16), _stream())
+
+
+def sigma_from_h(h16):
+    _chk(h16, torch.float16, "h")
+    sigma = torch.empty(h16.shape[0], dtype=torch.float32, device=h16.device)
+    call("l4d_sigma_from_h", _p(h16), h16.shape[0], _p(sigma), _stream())
+    return sigma
+
+
+def sigma_bwd(h16, d_sigma, loss_scale, dh16):
+    _chk(h16, torch.float16, "h"), _chk(d_sigma, torch.float32, "d_sigma"), _chk(dh16, torch.float16, "dh")
+    call("l4d_sigma_bwd", _p(h16), _p(d_sigma), h16.shape[0], float(loss_scale), _p(dh16), _stream())
+
+
+# ---- fused field -----------------------------------------------------------------------------------
+def time_setup(t_dev, num_frames, tinfo=None):
+    _chk(t_dev, torch.float32, "t")
+    if tinfo is None:
+        tinfo = torch.empty(8, dtype=torch.float32, device=t_dev.device)
+    call("l4d_time_setup", _p(t_dev), num_frames, _p(tinfo), _stream())
+    return tinfo
+
+
+def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
+    _chk(xt, torch.float32, "xt"), _chk(flow16, torch.float16, "flow16"), _chk(tinfo, torch.float32, "tinfo")
+    P = xt.shape[0]
+    if X is None:
+        X = torch.empty(P, in_pad, dtype=torch.float16, device=xt.device)
+    call("l4d_density_encode_fwd", C.byref(field_desc), _p(xt), _p(flow16), _p(tinfo), P, _p(X), in_pad, _stream())
+    return X
+
+
+def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_scale, dflow16=None):
+    _chk(dX, torch.float16, "dX")
+    P, in_pad = dX.shape
+    if dflow16 is None:
+        dflow16 = torch.empty(P, 16, dtype=torch.float16, device=dX.device)
+    call("l4d_density_encode_bwd", C.byref(field_desc), C.byref(field_grads), _p(xt), _p(flow16), _p(tinfo), P, _p(dX),
+         in_pad, float(param_scale), _p(dflow16), _stream())
+    return dflow16
+
+
+# ---- optimiser / casts -------------------------------------------------------------------------------
+def cast_f32_to_f16(src, dst=None):
+    _chk(src, torch.float32, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float16, device=src.device)
+    _chk(dst, torch.float16, "dst")
+    call("l4d_cast_f32_to_f16", _p(src), _p(dst), src.numel(), _stream())
+    return dst
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, param16, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    for nm, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _chk(t, torch.float32, nm)
+    _chk(param16, torch.float16, "param16")
+    call("l4d_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param16), param.numel(), float(lr),
+         float(beta1), float(beta2), float(eps), 1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), _stream())

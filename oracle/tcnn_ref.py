@@ -115,7 +115,8 @@ def hashgrid_corner_indices(x, meta, lvl, n_dims):
     scale = torch.tensor(meta["scale"][lvl], dtype=torch.float32)
     res = meta["res"][lvl]
     n = meta["size"][lvl]
-    pos = x.float() * scale + 0.5  # fmaf(scale, x, 0.5)
+    # fmaf(scale, x, 0.5): the fp32 x fp32 product is exact in fp64, so this is the fused result
+    pos = (x.double() * scale.double() + 0.5).float()
     cell = torch.floor(pos)
     frac = pos - cell
     cell_u = cell.to(torch.int64) & 0xFFFFFFFF  # (uint32)(int)floor: negatives wrap

@@ -1,0 +1,240 @@
+"""GPU parity tests, operator level: every HIP entry point (called through the C ABI via lidar4d_amd.ops)
+against the oracle with tiny-cuda-nn's rounding points, on seeded inputs.  Run with ``-m gpu`` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields_ref, tcnn_ref
+from oracle.detparams import det_uniform
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_close(got, ref, rtol, atol, what="", frac_ok=0.0):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    bad = (got - ref).abs() > atol + rtol * ref.abs()
+    nbad = int(bad.sum())
+    assert nbad <= frac_ok * bad.numel(), (
+        f"{what}: {nbad}/{bad.numel()} out of tolerance; max abs err {(got - ref).abs().max():.3e}, ref max {ref.abs().max():.3e}")
+
+
+HALF_ULP = 2.0 ** -10  # one fp16 ulp, relative
+
+
+@pytest.fixture(autouse=True)
+def _tcnn_mode():
+    prev = tcnn_ref.get_precision()
+    tcnn_ref.set_precision("tcnn")
+    yield
+    tcnn_ref.set_precision(prev)
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,F,L,log2T,base,maxres", [(3, 4, 8, 19, 512, 32768), (2, 4, 8, 13, 512, 32768),
+                                                      (3, 8, 8, 18, 32, 8192), (3, 2, 4, 10, 4, 32), (2, 8, 3, 8, 8, 64),
+                                                      (3, 4, 16, 15, 512, 32768)])
+def test_hashgrid_fwd_bwd(D, F, L, log2T, base, maxres):
+    from lidar4d_amd import tcnn
+    cfg = {"otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": log2T,
+           "base_resolution": base, "per_level_scale": np.exp2(np.log2(maxres / base) / (L - 1))}
+    ref = tcnn_ref.Encoding(D, cfg)
+    mod = tcnn.Encoding(D, cfg)
+    assert mod.params.numel() == ref.params.numel()
+    assert mod.meta.res == ref.meta["res"] and mod.meta.size == ref.meta["size"] and mod.meta.hashed == ref.meta["hashed"]
+    with torch.no_grad():
+        ref.params.copy_(det_uniform((ref.params.numel(),), f"hg{D}{F}{L}", -0.5, 0.5))
+        mod.params.copy_(ref.params)
+    mod = mod.to(DEV)
+    P = 20000
+    x = det_uniform((P, D), f"x{D}{F}", -0.02, 1.02)  # a few points outside [0,1]: indices wrap like tiny-cuda-nn
+    x[:50] = x[:50].clamp(0, 1).round()
+    out_ref = ref(x)
+    out = mod(x.to(DEV))
+    assert out.dtype == torch.float16 and out.shape == (P, L * F)
+    # identical rounding points; fp32 accumulation order may differ -> at most one fp16 ulp, rarely
+    rel_close(out.float(), out_ref.float(), rtol=2 * HALF_ULP, atol=1e-6, what="hashgrid fwd")
+    exact = (out.cpu() == out_ref).float().mean().item()
+    assert exact > 0.98, f"only {exact:.4f} of outputs bit-identical"
+    g = det_uniform((P, L * F), "g", -1, 1)
+    out_ref.float().backward(g)
+    out.backward(g.to(DEV).half())
+    rel_close(mod.params.grad, ref.params.grad, rtol=2e-3, atol=2e-3 * ref.params.grad.abs().max().item(), what="hashgrid bwd")
+
+
+@pytest.mark.parametrize("t", [0.0, 0.3, 1.0, 26 / 51, 0.62])
+def test_hashgrid_t(t):
+    from lidar4d_amd.hash_field import HashGridT
+    ref = fields_ref.HashGridT(time_resolution=8, base_resolution=512, max_resolution=32768, n_levels=8,
+                               n_features_per_level=4, log2_hashmap_size=13)
+    mod = HashGridT(time_resolution=8, base_resolution=512, max_resolution=32768, n_levels=8, n_features_per_level=4,
+                    log2_hashmap_size=13)
+    with torch.no_grad():
+        for (n, p), (_, q) in zip(ref.named_parameters(), mod.named_parameters()):
+            p.copy_(det_uniform(tuple(p.shape), "ht" + n, -0.5, 0.5))
+            q.copy_(p)
+    mod = mod.to(DEV)
+    x = det_uniform((8192, 2), "htx", 0, 1)
+    tt = torch.tensor(t, dtype=torch.float32)
+    out_ref = ref(x, tt)
+    out = mod(x.to(DEV), tt)
+    assert out.dtype == torch.float32 and out.shape == (8192, 8)
+    rel_close(out, out_ref, rtol=1e-4, atol=3e-4, what="hashgrid_t fwd")  # fp16-ulp flips of slice features, scaled by basis
+    g = det_uniform((8192, 8), "htg", -1, 1)
+    out_ref.backward(g)
+    out.backward(g.to(DEV))
+    for (n, p), (_, q) in zip(ref.named_parameters(), mod.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None or float(q.grad.abs().sum()) == 0.0, n
+        else:
+            rel_close(q.grad, p.grad, rtol=1e-3, atol=1e-4 * max(p.grad.abs().max().item(), 1e-9), what="hashgrid_t bwd " + n)
+
+
+def test_planes_vs_reference_golden(golden):
+    """Planes4D against fixtures produced by the reference's own F.grid_sample code (make_golden.py (3))."""
+    from lidar4d_amd.planes_field import Planes4D
+    g = golden("planes4d")
+    mod = Planes4D(output_dim=8, resolution=(8, 8, 8, 8), multiscale_res=(1, 2, 4))
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            p.copy_(T(g["param." + n]))
+    mod = mod.to(DEV)
+    xt = T(g["xt"]).to(DEV).requires_grad_(True)
+    fs, fd = mod(xt)
+    rel_close(fs, T(g["feat_static"]), 2e-5, 1e-6, "planes static")
+    rel_close(fd, T(g["feat_dynamic"]), 2e-5, 1e-6, "planes dynamic")
+    rel_close(mod.forward_static(xt), T(g["feat_static_only"]), 2e-5, 1e-6, "planes static-only")
+    rel_close(mod.forward_dynamic(xt), T(g["feat_dynamic_only"]), 2e-5, 1e-6, "planes dynamic-only")
+    ((fs * T(g["gs"]).to(DEV)).sum() + (fd * T(g["gd"]).to(DEV)).sum()).backward()
+    rel_close(xt.grad, T(g["grad_xt"]), 1e-4, 1e-4, "planes d/dxt")
+    for n, p in mod.named_parameters():
+        rel_close(p.grad, T(g["grad." + n]), 1e-4, 1e-4, "planes grad " + n)
+
+
+def test_frequency():
+    from lidar4d_amd import tcnn
+    ref = tcnn_ref.Encoding(3, {"otype": "Frequency", "degree": 12})
+    mod = tcnn.Encoding(3, {"otype": "Frequency", "degree": 12})
+    x = det_uniform((4096, 3), "fx", 0, 1)
+    x[:8] = torch.tensor([[0.0, 0.5, 1.0]] * 8)
+    out = mod(x.to(DEV))
+    assert out.shape == (4096, 72) and out.dtype == torch.float16
+    rel_close(out.float(), ref(x).float(), rtol=2 * HALF_ULP, atol=2e-6, what="frequency")
+
+
+@pytest.mark.parametrize("n_in,n_out,n_hidden", [(120, 16, 1), (87, 1, 2), (120, 16, 2), (16, 6, 2), (40, 3, 3)])
+def test_mlp_fwd_bwd(n_in, n_out, n_hidden):
+    from lidar4d_amd import tcnn
+    cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+           "n_hidden_layers": n_hidden}
+    ref = tcnn_ref.Network(n_in, n_out, cfg)
+    mod = tcnn.Network(n_in, n_out, cfg)
+    with torch.no_grad():
+        ref.params.copy_(det_uniform((ref.params.numel(),), f"mlp{n_in}", -0.3, 0.3))
+        mod.params.copy_(ref.params)
+    mod = mod.to(DEV)
+    P = 5000  # not a multiple of 16/32: exercises the ragged tail
+    x = det_uniform((P, n_in), "mx", -1, 1).requires_grad_(True)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y_ref = ref(x)
+    y = mod(xg)
+    assert y.dtype == torch.float16 and y.shape == (P, n_out)
+    rel_close(y.float(), y_ref.float(), rtol=4 * HALF_ULP, atol=2e-3, what="mlp fwd", frac_ok=1e-3)
+    g = det_uniform((P, n_out), "mg", -1, 1)
+    y_ref.float().backward(g)
+    y.backward(g.to(DEV).half())
+    gmax = ref.params.grad.abs().max().item()
+    rel_close(mod.params.grad, ref.params.grad, rtol=2e-2, atol=2e-3 * gmax, what="mlp dW")
+    rel_close(xg.grad, x.grad, rtol=2e-2, atol=2e-3 * x.grad.abs().max().item(), what="mlp dX")
+
+
+def test_mlp_empty_and_row_count():
+    from lidar4d_amd import ops
+    w = torch.randn(64 * 96 + 64 * 64 + 16 * 64, device=DEV).half() * 0.1
+    x = torch.randn(1000, 96, device=DEV).half()
+    y_all, _ = ops.mlp_fwd(x, w, 2, save_act=False)
+    n = torch.tensor([333], dtype=torch.int32, device=DEV)
+    y = torch.full((1000, 16), 7.0, dtype=torch.float16, device=DEV)
+    ops.mlp_fwd(x, w, 2, save_act=False, n_rows=n, y=y)
+    assert torch.equal(y[:333], y_all[:333]) and bool((y[333:] == 7.0).all())
+    y0, _ = ops.mlp_fwd(x[:0], w, 2, save_act=False)
+    assert y0.shape == (0, 16)
+
+
+@pytest.mark.parametrize("tag", ["plain", "active_perturb", "tightbound"])
+def test_sample_and_composite_vs_reference_golden(golden, tag):
+    """l4d_sample_rays + l4d_composite_fwd against LiDAR_Renderer.run of the reference (make_golden.py (2))."""
+    from lidar4d_amd import ops
+    g = golden("run_analytic_" + tag)
+    ro, rd = T(g["rays_o"]).view(-1, 3).to(DEV), T(g["rays_d"]).view(-1, 3).to(DEV)
+    lin = torch.linspace(0.0, 1.0, 768).to(DEV)  # the reference's torch.linspace bits
+    noise = T(g["noise"]).to(DEV) if bool(g["perturb"]) else None
+    z, xyz = ops.sample_rays(ro, rd, lin, noise, float(g["near"]), float(g["far"]), float(g["bound"]))
+    assert torch.equal(z.cpu(), T(g["z_vals"])), "z_vals must be bit-exact"
+    r2 = ((xyz.cpu() - torch.tensor([0.2, 0.1, -0.05])) ** 2).sum(-1)
+    sigma = (400.0 * torch.exp(-r2 / 0.02) + 0.3).view(-1, 768).to(DEV)  # the fixture's analytic density, CPU torch
+    sd = float(np.float32(np.float32(g["far"]) - np.float32(g["near"])) / np.float32(768))
+    w, wsum, depth, mask, idx, cnt = ops.composite_fwd(sigma, z, sd, float(g["density_scale"]), bool(g["active"]))
+    rel_close(w, T(g["weights"]), 2e-5, 1e-10, "weights")
+    rel_close(depth, T(g["depth"]).view(-1), 2e-5, 1e-8, "depth")
+    rel_close(wsum, T(g["weights_sum"]), 2e-5, 1e-8, "weights_sum")
+    want = set(g["mask_idx"].tolist())
+    got_mask = set(torch.nonzero(mask.view(-1)).view(-1).tolist())
+    got_idx = set(idx[: int(cnt)].tolist())
+    assert got_mask == got_idx, "compacted index list != dense mask"
+    wref = T(g["weights"]).reshape(-1)
+    for i in got_mask ^ want:
+        assert abs(float(wref[i]) - 1e-4) < 2e-9, (i, float(wref[i]))
+    xn = xyz.cpu()
+    geo = torch.stack([xn[:, 0], xn[:, 1] * 2], -1)
+    dirs = rd.cpu().view(-1, 1, 3).expand(-1, 768, 3).reshape(-1, 3)
+    a = torch.stack([torch.sigmoid(geo[:, 0] * 3 + dirs[:, 0]), torch.sigmoid(geo[:, 1] - dirs[:, 2])], -1)
+    attr = torch.zeros_like(a)
+    m = mask.view(-1).bool().cpu()
+    attr[m] = a[m]
+    image = ops.composite_image(w, attr.to(DEV).contiguous(), 2)
+    rel_close(image, T(g["image"]).view(-1, 2), 3e-5, 1e-8, "image")
+
+
+@pytest.mark.parametrize("active,T_steps", [(False, 768), (True, 100), (False, 1500)])
+def test_composite_bwd(active, T_steps):
+    from lidar4d_amd import ops
+    N = 37
+    sigma = (det_uniform((N, T_steps), "cs", 0, 1) ** 4 * 300).requires_grad_(True)
+    z, sd = fields_ref.sample_z(N, 0.0105, 0.851, T_steps, det_uniform((N, T_steps), "cn", 0, 1))
+    attr = det_uniform((N * T_steps, 2), "ca", 0, 1).requires_grad_(True)
+    w = fields_ref.composite(sigma, z, sd, 1.3, active)
+    depth, wsum, image = (w * z).sum(-1), w.sum(-1), (w.unsqueeze(-1) * attr.view(N, T_steps, 2)).sum(-2)
+    gd, gs, gi, gw = (det_uniform((N,), "gd", -1, 1), det_uniform((N,), "gs", -1, 1), det_uniform((N, 2), "gi", -1, 1),
+                      det_uniform((N, T_steps), "gw", -1, 1))
+    ((depth * gd).sum() + (wsum * gs).sum() + (image * gi).sum() + (w * gw).sum()).backward()
+    sdv = float(sd.reshape(-1)[0])
+    wg, _, _, _, _, _ = ops.composite_fwd(sigma.detach().to(DEV), z.to(DEV).contiguous(), sdv, 1.3, active)
+    rel_close(wg, w, 3e-5, 1e-10, "weights")
+    d_sigma, d_attr = ops.composite_bwd(sigma.detach().to(DEV), z.to(DEV).contiguous(), wg, attr.detach().to(DEV), 2, sdv, 1.3,
+                                        active, gd.to(DEV), gs.to(DEV), gi.to(DEV), gw.to(DEV))
+    rel_close(d_sigma, sigma.grad, 2e-3, 1e-6 * sigma.grad.abs().max().item(), "d_sigma")
+    rel_close(d_attr, attr.grad, 1e-4, 1e-9, "d_attr")
+
+
+def test_adam_matches_torch():
+    from lidar4d_amd import ops
+    n = 100003
+    p = torch.randn(n, device=DEV)
+    p_ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    p16 = torch.empty(n, dtype=torch.float16, device=DEV)
+    for step in range(1, 4):
+        g = torch.randn(n, device=DEV)
+        p_ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g, m, v, p16, 1e-2, 0.9, 0.99, 1e-15, step)
+        rel_close(p, p_ref, 1e-5, 1e-6, f"adam step {step}")
+    assert torch.equal(p16, p.half())
