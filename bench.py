@@ -1,0 +1,197 @@
+"""bench.py -- training rays/s of the LiDAR4D ray-rendering hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2-like ...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward + backward + Adam of ``render(staged=False, perturb=True)`` with the reference's three primary
+losses (runner.py:179-213) on one batch of synthetic KITTI-360-shaped rays (64 x 1024 panorama, T = 768 samples per
+ray).  Default workload = BASELINE.json configs[2] ("C3": full 4D field -- hash + hex-planes + flow --
+16,384 rays/batch/GPU), whose 8-GPU weak-scaled form is configs[3] (131,072 rays/step), the configuration the
+headline ">= 10 M training rays/s on 8 x MI355X" is quoted on.  Rank r draws its own frames and ray indices; the
+flat gradient buffer is SUM-all-reduced over RCCL once per step.  Inputs are resident in HBM before the timed region.
+
+The JSON line also carries `roofline` (dominant kernel: algorithmic bytes / measured launch time vs the 8 TB/s HBM
+peak; per-kernel times come from HIP events recorded around every launch on the launch stream in a separate
+profiling pass after the timed region) and, on rank 0 at N = 1, `cpu_baseline` (the oracle, i.e. a port, timed on
+the host cores over a bounded ray sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (model kwargs, rays per GPU per step, description)
+    "c3": (dict(), 16384, "C3: KITTI-360 seq-4950-shaped full 4D (L=8 hash + hex-planes + flow_field), 16384 rays/batch/GPU training"),
+    "c3-4k": (dict(), 4096, "full 4D, 4096 rays/batch/GPU training (staged-chunk size)"),
+    "c3-1k": (dict(), 1024, "full 4D, 1024 rays/batch/GPU training (the reference's own num_rays_lidar)"),
+}
+
+
+def algorithmic_bytes_per_sample(model):
+    """SURVEY.md 8(d) per-sample table-entry traffic of the fused kernels at this model's configuration.
+    fwd: fp16 hash entries (8 B at F=4), fp32 channel-last plane texels (32 B);
+    bwd: plane values are re-read for the product rule, gradients are fp32 read-modify-write (x2)."""
+    he, pe = model.hash_encoder, model.planes_encoder
+    L = he.hash_static.meta.n_levels
+    nS = pe.layout.n_scales
+    static = L * 8 * 8
+    dyn_eval = 3 * 2 * L * 4 * 8
+    planes_full = 6 * nS * 4 * 32
+    planes_dyn = 3 * nS * 4 * 32
+    flow = model.flow_net.n_levels * 8 * 16
+    fwd = static + 3 * dyn_eval + planes_full + 2 * planes_dyn
+    bwd = (planes_full + 2 * planes_dyn) + 2 * ((L * 8 * 16) + (3 * 2 * L * 4 * 16) + (planes_full + 2 * planes_dyn))
+    return {"l4d_density_encode_fwd": fwd, "l4d_density_encode_bwd": bwd, "l4d_hashgrid_t_fwd": flow,
+            "l4d_hashgrid_t_bwd": 2 * model.flow_net.n_levels * 8 * 32, "hash_static_fwd_only": static}
+
+
+def cpu_baseline(num_frames, scale, n_rays=96):
+    """Oracle (CPU restatement = a port of the reference path, tiny-cuda-nn rounding points) fwd+bwd on the host."""
+    from oracle import fields_ref, tcnn_ref
+    tcnn_ref.set_precision("tcnn")
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = fields_ref.LiDAR4D(near_lidar=1.0 * scale, far_lidar=81.0 * scale, num_frames=num_frames)
+    g = torch.Generator().manual_seed(0)
+    ro = torch.zeros(1, n_rays, 3)
+    rd = torch.nn.functional.normalize(torch.randn(1, n_rays, 3, generator=g), dim=-1)
+    t = torch.tensor([[0.5]])
+
+    def step(n):
+        out = m.render(ro[:, :n], rd[:, :n], t, num_steps=768, perturb=True)
+        (out["depth_lidar"].sum() + out["image_lidar"].sum()).backward()
+
+    step(8)  # warm-up
+    t0 = time.time()
+    step(n_rays)
+    dt = time.time() - t0
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch CPU, tiny-cuda-nn rounding points) forward+backward of render() on {n_rays} rays x 768 "
+                      f"samples, full 4D default config, no optimizer step; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from lidar4d_amd import LiDAR4D, _lib
+    from lidar4d_amd.data import KITTI360_SCALE, SyntheticKitti360
+    from lidar4d_amd.trainer import Trainer
+
+    model_kw, n_rays, desc = WORKLOADS[args.workload]
+    torch.manual_seed(0)  # identical initial replicas on every rank
+    model = LiDAR4D(near_lidar=1.0 * KITTI360_SCALE, far_lidar=81.0 * KITTI360_SCALE, num_frames=51, **model_kw).to(dev)
+    data = SyntheticKitti360(dev, num_rays=n_rays, seed=1000 + rank)
+    trainer = Trainer(model, data)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+
+    # ---- per-kernel timing pass (HIP events on the launch stream), outside the timed region ----
+    roofline = None
+    kernels = {}
+    if rank == 0 and args.profile_steps > 0:
+        _lib.PROFILE = []
+        for _ in range(args.profile_steps):
+            trainer.train_step()
+        torch.cuda.synchronize()
+        for name, s, e in _lib.PROFILE:
+            k = kernels.setdefault(name, [0, 0.0])
+            k[0] += 1
+            k[1] += s.elapsed_time(e)
+        _lib.PROFILE = None
+        per_step = {k: v[1] / args.profile_steps for k, v in kernels.items()}
+        dominant = max(per_step, key=per_step.get)
+        launches = kernels[dominant][0] / args.profile_steps
+        avg_ms = kernels[dominant][1] / kernels[dominant][0]
+        P = n_rays * 768
+        bps = algorithmic_bytes_per_sample(model)
+        alg = bps.get(dominant)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dominant)
+        if alg is not None:
+            achieved = alg * P / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": alg * P, "avg_launch_ms": round(avg_ms, 4),
+                        "launches_per_step": launches,
+                        "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
+        else:
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": None, "traffic": traffic,
+                        "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
+
+    if rank == 0:
+        total_rays = n_rays * world * args.steps
+        line = {
+            "metric": "training rays/sec (64x1024 LiDAR panorama)",
+            "value": total_rays / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16 tables/MFMA operands, f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": desc, "rays_per_gpu_per_step": n_rays, "samples_per_ray": 768,
+                       "global_rays_per_step": n_rays * world, "parallelism": f"ray-sharded dp{world}, 1 RCCL all-reduce/step",
+                       "step": "forward + backward + Adam, losses L1 depth + MSE raydrop + MSE intensity (no chamfer/flow loss)"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(51, KITTI360_SCALE)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

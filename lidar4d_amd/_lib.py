@@ -122,5 +122,16 @@ def check(status, name):
         raise HipExtensionError(f"{name} failed: {lib().l4d_last_error().decode()}")
 
 
+PROFILE = None  # set to a list to record (name, start_event, end_event) around every launch (bench.py)
+
+
 def call(name, *args):
+    if PROFILE is None:
+        check(getattr(lib(), name)(*args), name)
+        return
+    import torch
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
     check(getattr(lib(), name)(*args), name)
+    e.record()
+    PROFILE.append((name, s, e))

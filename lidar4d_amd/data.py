@@ -1,0 +1,107 @@
+"""LiDAR ray generation and a synthetic KITTI-360-shaped dataset.
+
+``get_lidar_rays`` restates the reference's data/base_dataset.py:15-102 (same direction convention as
+utils/convert.py:115-124) on whatever device the pose lives on.  ``SyntheticKitti360`` stands in for
+data/kitti360_dataset.py (the KITTI-360 files are not available): same per-step dict keys
+(kitti360_dataset.py:177-187), 64 x 1024 panorama, ``fov_lidar = (2.0, 26.9)``, 51 frames on a straight
+1 m/frame track, scale/offset convention of configs/kitti360_4950.txt, ground truth from an analytic scene
+(ground plane + boxes, 10 % random ray drops); SURVEY.md section 8(d).
+"""
+import math
+
+import numpy as np
+import torch
+
+KITTI360_SCALE = 0.010504329815187737  # configs/kitti360_4950.txt:6
+KITTI360_FOV = (2.0, 26.9)
+
+
+def get_lidar_rays(poses, intrinsics, H, W, N=-1, patch_size=1, generator=None):
+    """poses [B,4,4] sensor-to-world, intrinsics (fov_up, fov) in degrees -> dict(rays_o, rays_d [B,n,3], inds [B,n]).
+    N > 0 draws N random pixels the way the reference does for patch_size == 1: row in [0, H-1), column in [0, W)
+    (base_dataset.py:50-53 -- the last row is never sampled)."""
+    device = poses.device
+    B = poses.shape[0]
+    if N > 0:
+        N = min(N, H * W)
+        if patch_size != 1:
+            raise NotImplementedError("get_lidar_rays: patch sampling other than patch_size=1 is not implemented")
+        rows = torch.randint(0, H - 1, size=[N], device=device, generator=generator)
+        cols = torch.randint(0, W, size=[N], device=device, generator=generator)
+        inds = (rows * W + cols).expand([B, N])
+    else:
+        inds = torch.arange(H * W, device=device).expand([B, H * W])
+    i = (inds % W).float()
+    j = torch.div(inds, W, rounding_mode="floor").float()
+    fov_up, fov = intrinsics
+    beta = -(i - W / 2) / W * 2 * np.pi
+    alpha = (fov_up - j / H * fov) / 180 * np.pi
+    directions = torch.stack([torch.cos(alpha) * torch.cos(beta), torch.cos(alpha) * torch.sin(beta), torch.sin(alpha)], -1)
+    rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
+    rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
+    return {"rays_o": rays_o, "rays_d": rays_d, "inds": inds}
+
+
+def _analytic_scene_depth(origin, dirs):
+    """Metric range along unit ``dirs`` [n,3] from ``origin`` [3] to a ground plane z = -1.7 and five boxes."""
+    inf = torch.full(dirs.shape[:1], float("inf"), device=dirs.device)
+    dz = dirs[:, 2]
+    t_ground = torch.where(dz < -1e-6, (-1.7 - origin[2]) / dz, inf)
+    best = t_ground
+    boxes = [((8, -3, -1.7), (12, 1, 0.3)), ((-20, 6, -1.7), (-14, 10, 2.5)), ((15, 12, -1.7), (40, 14, 6.0)),
+             ((-5, -16, -1.7), (30, -14, 4.0)), ((30, -4, -1.7), (34, 0, 0.0))]
+    for lo, hi in boxes:
+        lo = torch.tensor(lo, dtype=torch.float32, device=dirs.device)
+        hi = torch.tensor(hi, dtype=torch.float32, device=dirs.device)
+        inv = 1.0 / torch.where(dirs.abs() < 1e-9, torch.full_like(dirs, 1e-9), dirs)
+        t0, t1 = (lo - origin) * inv, (hi - origin) * inv
+        tmin = torch.minimum(t0, t1).amax(-1)
+        tmax = torch.maximum(t0, t1).amin(-1)
+        hit = (tmax >= tmin) & (tmin > 0)
+        best = torch.minimum(best, torch.where(hit, tmin, inf))
+    return best
+
+
+class SyntheticKitti360:
+    """Pre-loads ``num_frames`` synthetic range images [H,W,3] = (ray-drop mask, intensity, depth*scale) on ``device``
+    and serves per-step ray batches like KITTI360Dataset.collate (one frame per step)."""
+
+    def __init__(self, device, H=64, W=1024, num_frames=51, num_rays=4096, scale=KITTI360_SCALE, fov=KITTI360_FOV, seed=0):
+        self.device, self.H, self.W, self.num_frames, self.num_rays = device, H, W, num_frames, num_rays
+        self.scale, self.fov = scale, fov
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed)
+        self.frame_gen = torch.Generator().manual_seed(seed)  # host-side frame choice: no device sync
+        g_cpu = torch.Generator().manual_seed(1234)
+        self.poses, self.images = [], []
+        for k in range(num_frames):
+            pose_m = torch.eye(4)
+            pose_m[0, 3] = float(k - num_frames // 2)  # 1 m per frame along x, centred on the scene offset
+            rays = get_lidar_rays(pose_m[None], fov, H, W, -1)
+            depth = _analytic_scene_depth(pose_m[:3, 3], rays["rays_d"][0])
+            valid = (depth < 80.0) & (torch.rand(H * W, generator=g_cpu) > 0.1)
+            depth = torch.where(valid, depth, torch.zeros_like(depth))
+            hit = pose_m[:3, 3] + rays["rays_d"][0] * depth[:, None]
+            intensity = (0.5 + 0.5 * torch.sin(0.7 * hit[:, 0]) * torch.cos(0.5 * hit[:, 1])).clamp(0, 1) * valid
+            img = torch.stack([valid.float(), intensity, depth * scale], -1).view(H, W, 3)
+            pose = pose_m.clone()
+            pose[:3, 3] = pose[:3, 3] * scale
+            self.poses.append(pose.to(device))
+            self.images.append(img.to(device))
+        self.poses = torch.stack(self.poses)
+        self.images = torch.stack(self.images)
+
+    def batch(self, frame=None):
+        """Dict with the reference's keys for one training step (random frame unless given)."""
+        if frame is None:
+            frame = int(torch.randint(0, self.num_frames, [1], generator=self.frame_gen))
+        return self.batch_for(frame)
+
+    def batch_for(self, frame):
+        pose = self.poses[frame:frame + 1]
+        rays = get_lidar_rays(pose, self.fov, self.H, self.W, self.num_rays, generator=self.gen)
+        inds = rays["inds"]
+        images = torch.gather(self.images[frame].view(1, -1, 3), 1, inds[..., None].expand(-1, -1, 3))
+        t = torch.tensor([[frame / (self.num_frames - 1)]], dtype=torch.float32, device=self.device)
+        return {"rays_o_lidar": rays["rays_o"], "rays_d_lidar": rays["rays_d"], "time": t, "images_lidar": images,
+                "poses_lidar": pose, "H_lidar": self.H, "W_lidar": self.W, "index": [frame]}

@@ -8,7 +8,10 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import call
+
+
+def call(name, *args):
+    _lib.call(name, *args)
 
 
 def _stream():

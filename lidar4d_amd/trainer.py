@@ -1,0 +1,81 @@
+"""Training step around the render path: the reference's three primary losses, Adam with its two lr groups and
+schedule, and ray-sharded data parallelism with one RCCL all-reduce of the flat gradient arena.
+
+Restates only what `training rays/s` needs from the reference's Trainer (model/runner.py:166-213,474-551;
+optimizer main_lidar4d.py:298-305); chamfer / flow losses, EMA, checkpoints and logging are out of scope
+(SURVEY.md section 2 row 8, section 8f).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .params import bump_epoch
+
+
+def lidar_loss(outputs, images_lidar, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, smooth=0.2):
+    """runner.py:179-213: L1 depth + MSE ray-drop (label-smoothed) + MSE intensity, masked by the GT ray-drop, summed."""
+    gt_raydrop = images_lidar[:, :, 0]
+    gt_intensity = images_lidar[:, :, 1] * gt_raydrop
+    gt_depth = images_lidar[:, :, 2] * gt_raydrop
+    pred_raydrop = outputs["image_lidar"][:, :, 0]
+    pred_intensity = outputs["image_lidar"][:, :, 1] * gt_raydrop
+    pred_depth = outputs["depth_lidar"] * gt_raydrop
+    gt_smooth = gt_raydrop.clamp(smooth, 1 - smooth)
+    loss = (alpha_d * (pred_depth - gt_depth).abs() + alpha_r * (pred_raydrop - gt_smooth) ** 2 +
+            alpha_i * (pred_intensity - gt_intensity) ** 2)
+    return loss.sum()
+
+
+class FlatAdam:
+    """torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) over the model's flat arenas: one l4d_adam_step launch per lr
+    group (encoders at lr, networks at 0.1 lr: lidar4d.py:226-237), which also refreshes the fp16 compute copies.
+    lr follows the reference's LambdaLR: lr0 * 0.1 ** min(it / iters, 1) (main_lidar4d.py:303-305)."""
+
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, iters=30000):
+        self.model, self.store = model, model._store
+        self.lr0, self.betas, self.eps, self.iters = lr, betas, eps, iters
+        self.group_lr = [1.0, 0.1]
+        self.step_count = 0
+        self.exp_avg = torch.zeros_like(self.store.flat)
+        self.exp_avg_sq = torch.zeros_like(self.store.flat)
+
+    def lr(self):
+        return self.lr0 * 0.1 ** min(self.step_count / self.iters, 1.0)
+
+    def zero_grad(self):
+        self.store.zero_grad() if self.store.flat_grad is not None else self.store.prepare_grads()
+
+    def step(self, grad_scale=1.0):
+        st = self.store
+        lr = self.lr()
+        self.step_count += 1
+        f16 = st.flat16 if st.flat16 is not None else st.refresh16()
+        for (a, b), mult in zip(st.group_ranges, self.group_lr):
+            ops.adam_step(st.flat[a:b], st.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], f16[a:b], lr * mult,
+                          self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale)
+        bump_epoch()          # parameters changed behind torch's version counters ...
+        st.mark16_current()   # ... and the fp16 copies were refreshed by the same kernel
+        self.model.planes_encoder._cl_key = None  # channel-last plane copy must be rebuilt
+
+
+class Trainer:
+    """One process per GPU.  Rays (whole frames) are sharded across ranks -- each rank draws its own frame and ray
+    indices -- parameters are replicated and the flat gradient buffer is SUM-all-reduced once per step (the primary
+    loss is a sum over rays, so the result equals one big batch)."""
+
+    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768):
+        self.model, self.dataset, self.num_steps = model, dataset, num_steps
+        self.opt = FlatAdam(model, lr=lr, iters=iters)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def train_step(self, data=None):
+        data = data if data is not None else self.dataset.batch()
+        self.opt.zero_grad()
+        out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
+                                num_steps=self.num_steps)
+        loss = lidar_loss(out, data["images_lidar"])
+        loss.backward()
+        if self.world > 1:
+            dist.all_reduce(self.model._store.flat_grad, op=dist.ReduceOp.SUM)
+        self.opt.step()
+        return loss
