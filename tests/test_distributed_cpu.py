@@ -1,0 +1,69 @@
+"""world_size-2 gloo test of the data-parallel path (bench.py --gpus N / lidar4d_amd.trainer.Trainer): each rank
+renders its own ray shard, the flat gradient arena is SUM-all-reduced once, and the result equals the gradient of
+one process rendering the concatenated batch.  Runs on CPU: the render itself is the oracle (the HIP path needs a
+GPU); what is under test is the sharding + flat-buffer all-reduce + optimizer-group layout logic."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.make_golden import SMALL_MODEL
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from lidar4d_amd import LiDAR4D
+    from lidar4d_amd.trainer import lidar_loss
+    from oracle import fields_ref, tcnn_ref
+    from oracle.detparams import det_uniform, fill_model
+    from oracle.make_golden import test_rays
+    tcnn_ref.set_precision("fp32")
+    cfg = dict(SMALL_MODEL, density_scale=40.0)
+    ref = fill_model(fields_ref.LiDAR4D(**cfg), seed=7)      # compute stand-in for the (GPU-only) HIP model
+    shell = fill_model(LiDAR4D(**cfg), seed=7)               # the product's parameter store / grad arena
+    store = shell._store
+    n_total, steps = 16, 32
+    ro, rd = test_rays(n_total, 5)
+    noise = det_uniform((n_total, steps), "dn", 0, 1)
+    images = torch.stack([(det_uniform((1, n_total), "ia", 0, 1) > 0.2).float(), det_uniform((1, n_total), "ib", 0, 1),
+                          det_uniform((1, n_total), "ic", 0.01, 0.8)], -1)
+    t = torch.tensor([[0.5]])
+
+    def grads_for(lo, hi):
+        ref.zero_grad()
+        o = ref.render(ro[:, lo:hi], rd[:, lo:hi], t, num_steps=steps, perturb=True, noise=noise[lo:hi])
+        lidar_loss(o, images[:, lo:hi]).backward()
+        g = store.prepare_grads()
+        g.zero_()
+        pr = dict(ref.named_parameters())
+        for name, p, off, n, _ in store.entries:
+            if n and pr[name].grad is not None:
+                g[off:off + n] = pr[name].grad.reshape(-1)
+        return g
+
+    shard = n_total // world
+    g = grads_for(rank * shard, (rank + 1) * shard).clone()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM)  # what Trainer.train_step does on flat_grad
+    if rank == 0:
+        full = grads_for(0, n_total)
+        err = float((g - full).abs().max() / full.abs().max())
+        out.put(("err", err, int(full.numel()), [list(r) for r in store.group_ranges]))
+    dist.destroy_process_group()
+
+
+def test_ray_sharded_allreduce_equals_single_batch():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    tag, err, numel, ranges = out.get(timeout=10)
+    assert tag == "err" and err < 1e-5, err
+    assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == numel  # two contiguous lr groups

@@ -1,0 +1,152 @@
+"""CPU tests of the host-side logic: C-ABI library loads and exports every declared symbol (no compute calls),
+grid geometry agrees with the oracle's, state-dict contract, flat parameter arenas, ray generation against the
+reference-generated fixture, the loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_declared_abi():
+    from lidar4d_amd import _lib
+    header = open(os.path.join(ROOT, "include", "lidar4d_hip.h")).read()
+    declared = set(re.findall(r"\b(l4d_[a-z0-9_]+)\s*\(", header))
+    assert {"l4d_version", "l4d_last_error"} <= declared
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("liblidar4d_hip.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/lidar4d_hip.h but not exported"
+    bound = set(_lib.SIGNATURES) | {"l4d_version", "l4d_last_error"}
+    assert declared == bound, (declared - bound, bound - declared)
+    assert _lib.lib().l4d_version() == _lib.ABI_VERSION
+
+
+def test_ctypes_structs_match_header_layout():
+    from lidar4d_amd import _lib
+    assert ctypes.sizeof(_lib.GridDesc) == 16 + 4 * 16 * 4
+    fd = _lib.FieldDesc
+    assert fd.hash_static_table.offset == ctypes.sizeof(_lib.GridDesc)
+    assert ctypes.sizeof(_lib.FieldGrads) == 8 * (1 + 24 + 1)
+
+
+@pytest.mark.parametrize("D,L,F,log2T,base,maxres", [(3, 8, 4, 19, 512, 32768), (2, 8, 4, 15, 512, 32768),
+                                                      (3, 8, 8, 18, 32, 8192), (3, 16, 4, 19, 512, 32768),
+                                                      (3, 4, 4, 19, 512, 32768), (2, 8, 4, 13, 512, 32768)])
+def test_gridmeta_matches_oracle_and_survey(D, L, F, log2T, base, maxres):
+    from lidar4d_amd.gridmeta import GridMeta
+    from oracle.tcnn_ref import grid_level_meta
+    pls = np.exp2(np.log2(maxres / base) / (L - 1))
+    m = GridMeta(D, L, F, log2T, base, pls)
+    o = grid_level_meta(D, L, log2T, base, pls)
+    assert m.res == o["res"] and m.size == o["size"] and m.offset == o["offset"] and m.hashed == o["hashed"]
+    assert m.scale == o["scale"]
+    if (D, L, base) == (3, 8, 512):
+        assert m.res == [512, 928, 1681, 3044, 5513, 9987, 18090, 32768] and all(m.hashed)
+        assert m.n_params == 16777216
+    if (D, L, base) == (3, 8, 32):
+        assert m.res == [32, 71, 157, 345, 761, 1681, 3710, 8192] and m.hashed == [False] + [True] * 7
+        assert m.n_params == 14942208
+
+
+def test_state_dict_contract_and_param_counts():
+    from lidar4d_amd import LiDAR4D
+    m = LiDAR4D()
+    sd = m.state_dict()
+    want = {"aabb", "hash_encoder.hash_static.params", "view_encoder.params", "flow_net.grid_enc.params",
+            "flow_net.mlp.0.weight", "flow_net.mlp.2.weight", "flow_net.mlp.4.weight", "sigma_net.params",
+            "intensity_net.params", "raydrop_net.params"}
+    want |= {f"planes_encoder.planes.{s}.{c}" for s in range(4) for c in range(6)}
+    want |= {f"hash_encoder.hash_dynamic.{p}.hash_t.{k}.params" for p in range(3) for k in range(8)}
+    assert set(sd.keys()) == want
+    assert tuple(sd["planes_encoder.planes.3.0"].shape) == (1, 8, 256, 256)
+    assert tuple(sd["planes_encoder.planes.1.2"].shape) == (1, 8, 8, 64)  # time plane: [1,8,8,R]
+    assert sd["hash_encoder.hash_static.params"].numel() == 16777216
+    assert sd["hash_encoder.hash_dynamic.0.hash_t.0.params"].numel() == 1048576
+    assert sd["hash_encoder.hash_dynamic.1.hash_t.7.params"].numel() == 262144
+    assert sd["flow_net.grid_enc.params"].numel() == 14942208
+    assert sd["sigma_net.params"].numel() == 9216 and sd["intensity_net.params"].numel() == 11264
+    assert tuple(sd["flow_net.mlp.4.weight"].shape) == (6, 64) and sd["view_encoder.params"].numel() == 0
+    n = sum(p.numel() for p in m.parameters())
+    assert n == 2181120 + 16777216 + 12582912 + 14942208 + 5504 + 31744
+    # optimizer groups as lidar4d.py:226-237
+    groups = m.get_params(1e-2)
+    assert [g["lr"] for g in groups] == [1e-2, 1e-2, 1e-2, 1e-3, 1e-3, 1e-3, 1e-3]
+    assert sum(p.numel() for g in groups for p in g["params"]) == n
+
+
+def test_param_store_views_and_reload():
+    from lidar4d_amd import LiDAR4D
+    from oracle.detparams import fill_model
+    from oracle.make_golden import SMALL_MODEL
+    m = LiDAR4D(**SMALL_MODEL)
+    st = m._store
+    base = st.flat.data_ptr()
+    for _, p, off, n, _ in st.entries:
+        if n:
+            assert p.data_ptr() == base + 4 * off and off % 8 == 0
+    # the flow MLP's [6,64] output layer owns a zero-padded [16,64] slot read by the MFMA kernel
+    w = m.flow_net.linears()
+    o0 = st.by_param[id(w[0].weight)][0]
+    assert st.by_param[id(w[1].weight)][0] == o0 + 1024 and st.by_param[id(w[2].weight)][0] == o0 + 1024 + 4096
+    assert float(st.flat[o0 + 5120 + 384: o0 + 6144].abs().sum()) == 0.0
+    fill_model(m, seed=3)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m2 = LiDAR4D(**SMALL_MODEL)
+    m2.load_state_dict(sd)
+    assert torch.equal(m2._store.flat, m._store.flat)  # load_state_dict writes through the views
+    g = st.prepare_grads()
+    assert m.sigma_net.params.grad.data_ptr() == g.data_ptr() + 4 * st.by_param[id(m.sigma_net.params)][0]
+    m.sigma_net.params.grad.fill_(2.0)
+    assert float(st.grad_view(m.sigma_net.params).sum()) == 2.0 * m.sigma_net.params.numel()
+    m.zero_grad(set_to_none=False)
+    assert float(st.flat_grad.abs().sum()) == 0.0
+
+
+def test_get_lidar_rays_matches_reference_fixture(golden):
+    from lidar4d_amd.data import get_lidar_rays
+    g = golden("rays_64x1024")
+    r = get_lidar_rays(torch.from_numpy(g["poses"]), tuple(g["fov"]), int(g["H"]), int(g["W"]), -1)
+    sel = torch.from_numpy(g["sel"])
+    assert torch.allclose(r["rays_d"][:, sel], torch.from_numpy(g["rays_d"]), rtol=0, atol=1e-6)
+    assert torch.allclose(r["rays_o"][:, sel], torch.from_numpy(g["rays_o"]), rtol=0, atol=0)
+    assert np.allclose(r["rays_d"].double().abs().sum(1).numpy(), g["rays_d_abs_sum"], rtol=1e-6)
+
+
+def test_synthetic_dataset_contract():
+    from lidar4d_amd.data import SyntheticKitti360
+    ds = SyntheticKitti360("cpu", H=16, W=64, num_frames=5, num_rays=100)
+    b = ds.batch()
+    assert set(b) >= {"rays_o_lidar", "rays_d_lidar", "time", "images_lidar", "poses_lidar", "H_lidar", "W_lidar"}
+    assert b["rays_o_lidar"].shape == (1, 100, 3) and b["images_lidar"].shape == (1, 100, 3) and b["time"].shape == (1, 1)
+    assert float((b["rays_d_lidar"].norm(dim=-1) - 1).abs().max()) < 1e-5
+    img = ds.images
+    assert set(img[..., 0].unique().tolist()) <= {0.0, 1.0} and float(img[..., 1].max()) <= 1.0
+    assert 0 < float(img[..., 2].max()) < 81 * ds.scale
+
+
+def test_no_cpu_fallback():
+    from lidar4d_amd import LiDAR4D, _lib
+    from oracle.make_golden import SMALL_MODEL
+    m = LiDAR4D(**SMALL_MODEL)
+    with pytest.raises(_lib.HipExtensionError):
+        m.render(torch.zeros(1, 4, 3), torch.ones(1, 4, 3), torch.tensor([[0.3]]))
+    with pytest.raises(_lib.HipExtensionError):
+        m.density(torch.zeros(4, 3), torch.tensor([[0.3]]))
+
+
+def test_product_does_not_import_oracle():
+    import subprocess
+    import sys
+    code = "import sys; import lidar4d_amd, lidar4d_amd.trainer, lidar4d_amd.data; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'product imports oracle'"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+    for root, _, files in os.walk(os.path.join(ROOT, "lidar4d_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
