@@ -72,11 +72,12 @@ int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc /*host*/, const float* x, int64
                        const int32_t* cols /*host*/, const void* const* tables /*host*/, int32_t n_slices,
                        const float* t, void* out, int32_t out_stride, int32_t out_is_half, void* stream);
 /* dout [P, dout_stride] fp32 or fp16, multiplied by grad_scale; grad_tables host array of n_slices device
- * pointers to fp32 tables (accumulated into).  Only the slices selected by *t are touched. */
+ * pointers to fp32 tables (accumulated into).  Only the slices selected by *t are touched.
+ * scratch: n_entries * F/4 floats of device memory (the per-entry scalar accumulators; zeroed here). */
 int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
                        const int32_t* cols /*host*/, int32_t n_slices, const float* t, const void* dout,
                        int32_t dout_stride, int32_t dout_is_half, float grad_scale,
-                       float* const* grad_tables /*host*/, void* stream);
+                       float* const* grad_tables /*host*/, float* scratch, void* stream);
 
 /* ---- Planes4D : model/planes_field.py:87-141,198-239 --------------------------------------------
  * planes_cl  channel-last copy of the hex-plane parameters: for scale s, plane c (comb order
@@ -197,11 +198,15 @@ int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, const float* li
 /* flow16 [P,16] fp16: flow network output (cols 0-2 forward, 3-5 backward); X [P,in_pad] fp16 */
 int l4d_density_encode_fwd(const l4d_field_desc* f /*host*/, const float* xt, const void* flow16,
                            const float* tinfo, int64_t P, void* X, int32_t in_pad, void* stream);
-/* dX [P,in_pad] fp16 (loss-scaled); parameter gradients are accumulated multiplied by param_scale
- * (= 1/loss_scale); dflow16 [P,16] fp16 stays in dX's scaled domain */
+/* Adjoint.  dX [P,in_pad] fp16 (loss-scaled); parameter gradients are accumulated multiplied by param_scale
+ * (= 1/loss_scale); dflow16 [P,16] fp16 stays in dX's scaled domain.  plane_abs_max: device fp32 = max |plane
+ * parameter| (bounds the fixed-point LDS accumulators); workspace: l4d_density_encode_bwd_workspace() bytes of
+ * device scratch.  Several launches: see lidar4d_amd/csrc/field_bwd.hip. */
+int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f /*host*/, int64_t P);
 int l4d_density_encode_bwd(const l4d_field_desc* f /*host*/, const l4d_field_grads* g /*host*/, const float* xt,
                            const void* flow16, const float* tinfo, int64_t P, const void* dX, int32_t in_pad,
-                           float param_scale, void* dflow16, void* stream);
+                           float param_scale, const float* plane_abs_max, void* workspace, void* dflow16,
+                           void* stream);
 
 /* ---- optimiser + casts (runner.py:506-508 Adam step; tcnn's per-forward fp32->fp16 param cast) ---- */
 int l4d_cast_f32_to_f16(const float* src, void* dst, int64_t n, void* stream);

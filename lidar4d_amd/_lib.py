@@ -62,7 +62,7 @@ SIGNATURES = {
     "l4d_hashgrid_fwd": [GD, P, I64, I32, PI32, P, P, I32, P],
     "l4d_hashgrid_bwd": [GD, P, I64, I32, PI32, P, I32, I32, F32, P, P],
     "l4d_hashgrid_t_fwd": [GD, P, I64, I32, PI32, PP, I32, P, P, I32, I32, P],
-    "l4d_hashgrid_t_bwd": [GD, P, I64, I32, PI32, I32, P, P, I32, I32, F32, PP, P],
+    "l4d_hashgrid_t_bwd": [GD, P, I64, I32, PI32, I32, P, P, I32, I32, F32, PP, P, P],
     "l4d_planes_relayout": [PP, PI32, I32, I32, P, PI64, I32, P],
     "l4d_planes_fwd": [P, PI64, PI32, I32, I32, P, I64, I32, P, P, P],
     "l4d_planes_bwd": [P, PI64, PI32, I32, I32, P, I64, I32, P, P, P, P, P],
@@ -82,7 +82,8 @@ SIGNATURES = {
     "l4d_sigma_bwd": [P, P, I64, F32, P, P],
     "l4d_time_setup": [P, I32, P, P],
     "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P],
-    "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, P],
+    "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, P, P, P],
+    "l4d_density_encode_bwd_workspace": [FD, I64],
     "l4d_field_width": [FD],
     "l4d_cast_f32_to_f16": [P, P, I64, P],
     "l4d_adam_step": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, F32, F32, P],
@@ -112,7 +113,7 @@ def lib():
     for name, args in SIGNATURES.items():
         fn = getattr(l, name)
         fn.argtypes = args
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name.endswith("_workspace") else C.c_int
     _lib = l
     return l
 

@@ -1,0 +1,560 @@
+// Backward of the fused field evaluation (adjoint of fused.hip:density_encode_fwd_kernel; reference
+// model/lidar4d.py:139-179 under autograd) for gfx950.
+//
+// Why this is not one scatter kernel: on MI355X scattered global fp32 atomics sustain only ~20 G lane-ops/s
+// (profiles/r01_ubench_global_atomics.txt) while one training step of 16,384 rays needs ~32 G gradient
+// scatter-adds; hex-planes and the 2-D dynamic hash tables are small and hot, so their gradients are accumulated in
+// LDS as fixed-point integers (ds_add_u32 / ds_add_u64 run 24x faster than ds_add_f32 and are order-independent,
+// i.e. deterministic) and flushed once per workgroup with coalesced atomics.
+//
+//   1. prep (one thread per sample): reads dX; writes the static planes' per-plane gradient factors
+//      gvs[p][scale][plane][8] (product rule already applied), the dynamic-hash upstream gradient transposed
+//      gdynT[col][p], column maxima for the fixed-point scales; scatters the static 3-D hash gradient (run-length
+//      pre-reduced along the ray, then global atomics); computes d(flow) from the time planes' coordinate adjoint.
+//   2. planes_dyn (one pass): all time planes of all scales fit in LDS as the 3 rows around t -> int32 accumulation.
+//   3. planes_static (passes over <=128 KB row bands of each plane): int32 accumulation from gvs.
+//   4. dynhash (passes over (plane, level, entry range)): the 2 slices x 4 features of an entry all receive
+//      basis[f] * w_slice * H[entry], so only the scalar H is accumulated (int64), then expanded.
+#include "field_dev.h"
+#include "wave_dev.h"
+#include <algorithm>
+
+#define ST_GVS_MAX 0     // [0..8)  max |gvs| per plane scale
+#define ST_GD_MAX 8      // max |dX dynamic-plane columns|
+#define ST_VMAX 9        // max |plane parameter| (written by the host side before the launch)
+#define ST_DYN_MAX 16    // [16 .. 16 + 3L) max |gdynT| per column
+#define ST_SIZE 80
+
+template <int C>
+__device__ __forceinline__ void group_taps(const FieldDesc& fd, int s, const float coord[4], bool time_group, Tap taps[3],
+                                           float v[3][C], int cis[3]) {
+  int n = 0;
+#pragma unroll
+  for (int ci = 0; ci < NPLANES; ++ci) {
+    const int a = COMB_A[ci], b = COMB_B[ci];
+    if ((b == 3) != time_group) continue;
+    const int W = fd.planes.res[s][a], H = fd.planes.res[s][b];
+    axis_tap(coord[a], W, taps[n].x0, taps[n].x1, taps[n].wx0, taps[n].wx1, taps[n].mx);
+    axis_tap(coord[b], H, taps[n].y0, taps[n].y1, taps[n].wy0, taps[n].wy1, taps[n].my);
+    sample_plane<C>(fd.planes_cl + fd.planes.off[s][ci], W, taps[n], v[n]);
+    cis[n] = ci;
+    ++n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. prep
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, float* __restrict__ g_hs, const float* __restrict__ xt,
+                                                            const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
+                                                            int64_t P, const half_t* __restrict__ dX, int in_pad, float pscale,
+                                                            half_t* __restrict__ gvs, half_t* __restrict__ gdynT,
+                                                            float* __restrict__ stats, half_t* __restrict__ dflow16) {
+  constexpr int C = 8;
+  const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = pr < P;
+  const int64_t p = valid ? pr : P - 1;  // every lane runs the whole body: the wave helpers need all 64 lanes
+  const int lane = __lane_id();
+  const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
+  const float t0 = tinfo[0], t1 = tinfo[1], t2 = tinfo[2];
+  const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
+  float fl[8];
+  {
+    uint4 u = *reinterpret_cast<const uint4*>(flow16 + p * 16);
+    const half_t* h = reinterpret_cast<const half_t*>(&u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
+  }
+  const float x0[4] = {c4[0], c4[1], c4[2], t0};
+  const float x1[4] = {c4[0] + fl[0], c4[1] + fl[1], c4[2] + fl[2], t1};
+  const float x2[4] = {c4[0] + fl[3], c4[1] + fl[4], c4[2] + fl[5], t2};
+  const half_t* row = dX + p * in_pad;
+  const int nS = fd.planes.n_scales;
+  const float c0 = 0.5f + (has_fwd ? 0.0f : 0.25f) + (has_bwd ? 0.0f : 0.25f);
+  float g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f};
+  float gd_max = 0.0f;
+
+  // ---- hex-planes: static factors + coordinate adjoint of the warped time-plane lookups ----
+  for (int s = 0; s < nS; ++s) {
+    float gs[C], gd[C];
+    {
+      uint4 u = *reinterpret_cast<const uint4*>(row + s * C);
+      const half_t* h = reinterpret_cast<const half_t*>(&u);
+#pragma unroll
+      for (int k = 0; k < C; ++k) gs[k] = valid ? h2f(h[k]) : 0.0f;
+      u = *reinterpret_cast<const uint4*>(row + (nS + s) * C);
+      h = reinterpret_cast<const half_t*>(&u);
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        gd[k] = valid ? h2f(h[k]) : 0.0f;
+        gd_max = fmaxf(gd_max, fabsf(gd[k]));
+      }
+    }
+    Tap taps[3];
+    float v[3][C];
+    int cis[3];
+    group_taps<C>(fd, s, x0, false, taps, v, cis);
+    float smax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      half_t hv[C];
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const float gv = gs[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
+        hv[k] = f2h(fminf(fmaxf(gv, -65504.f), 65504.f));
+        smax = fmaxf(smax, fabsf(h2f(hv[k])));
+      }
+      if (valid) *reinterpret_cast<uint4*>(gvs + ((p * nS + s) * 3 + j) * C) = *reinterpret_cast<uint4*>(hv);
+    }
+    smax = wave_max(smax);
+    if (lane == 0 && smax > 0.0f) atomic_max_nonneg(stats + ST_GVS_MAX + s, smax);
+#pragma unroll
+    for (int e = 1; e <= 2; ++e) {
+      if (!(e == 1 ? has_fwd : has_bwd)) continue;
+      const float* xe = e == 1 ? x1 : x2;
+      float* ge = e == 1 ? g1 : g2;
+      group_taps<C>(fd, s, xe, true, taps, v, cis);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float gv[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) gv[k] = 0.25f * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
+        float gix = 0.0f, giy = 0.0f;
+        const int ci = cis[j];
+        plane_coord_grad<C>(fd.planes_cl + fd.planes.off[s][ci], fd.planes.res[s][COMB_A[ci]], taps[j], gv, gix, giy);
+        ge[COMB_A[ci]] += gix * taps[j].mx;
+        ge[COMB_B[ci]] += giy * taps[j].my;
+      }
+    }
+  }
+  gd_max = wave_max(gd_max);
+  if (lane == 0 && gd_max > 0.0f) atomic_max_nonneg(stats + ST_GD_MAX, gd_max);
+  int col = 2 * nS * C;
+
+  // ---- static 3-D hash: run-length pre-reduced scatter ----
+  {
+    const float xs[3] = {x0[0], x0[1], x0[2]};
+    for (int lvl = 0; lvl < fd.hs.n_levels; ++lvl) {
+      const half4_t h = *reinterpret_cast<const half4_t*>(row + col + lvl * 4);
+      float g[4];
+      bool any = false;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        g[f] = valid ? h2f(h[f]) * pscale : 0.0f;
+        any |= g[f] != 0.0f;
+      }
+      if (!__any(any)) continue;  // wave-uniform
+      Cell<3> c = locate<3>(xs, fd.hs.scale[lvl]);
+      float* gt = g_hs + (size_t)fd.hs.offset[lvl] * 4;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        uint32_t gv[3];
+        const float w = corner<3>(c, k, gv);
+        const uint32_t idx = grid_index<3>(gv, fd.hs.res[lvl], fd.hs.size[lvl], (fd.hs.hashed_mask >> lvl) & 1u);
+        float vals[4] = {w * g[0], w * g[1], w * g[2], w * g[3]};
+        if (wave_run_reduce<4>(idx, any, vals)) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            if (vals[f] != 0.0f) atomicAdd(gt + (size_t)idx * 4 + f, vals[f]);
+        }
+      }
+    }
+    col += fd.hs.n_levels * 4;
+  }
+
+  // ---- dynamic hash: transposed upstream gradient (current frame only; neighbours are no_grad) ----
+  {
+    int cidx = 0;
+#pragma unroll
+    for (int plane = 0; plane < 3; ++plane) {
+      const int L = fd.hd[plane].n_levels;
+      for (int lvl = 0; lvl < L; ++lvl, ++cidx) {
+        const half_t hv = f2h(fminf(fmaxf(h2f(row[col + lvl]) * c0, -65504.f), 65504.f));
+        const float a = valid ? fabsf(h2f(hv)) : 0.0f;
+        if (valid) gdynT[(int64_t)cidx * P + p] = hv;
+        const float m = wave_max(a);
+        if (lane == 0 && m > 0.0f) atomic_max_nonneg(stats + ST_DYN_MAX + cidx, m);
+      }
+      col += L;
+    }
+  }
+
+  if (valid) {
+    half_t out[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k] = (half_t)0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      out[k] = f2h(fminf(fmaxf(g1[k], -65504.f), 65504.f));
+      out[3 + k] = f2h(fminf(fmaxf(g2[k], -65504.f), 65504.f));
+    }
+    uint4* dst = reinterpret_cast<uint4*>(dflow16 + p * 16);
+    dst[0] = reinterpret_cast<uint4*>(out)[0];
+    dst[1] = reinterpret_cast<uint4*>(out)[1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. time planes: all scales, all three frames, one pass; LDS window = 3 rows around t per plane
+// ------------------------------------------------------------------------------------------------
+#define TROWS 3
+__global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
+                                                            const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
+                                                            int64_t P, int64_t chunk, const half_t* __restrict__ dX, int in_pad,
+                                                            float pscale, const float* __restrict__ stats) {
+  constexpr int C = 8;
+  extern __shared__ int lds_i[];
+  const int nS = fd.planes.n_scales;
+  const float t0 = tinfo[0], t1 = tinfo[1], t2 = tinfo[2];
+  const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
+  const float c0 = 0.5f + (has_fwd ? 0.0f : 0.25f) + (has_bwd ? 0.0f : 0.25f);
+  // LDS layout: [scale][time plane j][TROWS][W][C]; window start row per scale (time res is shared by x/y/z-t planes)
+  int lds_off[MAX_SCALES][3], r_lo[MAX_SCALES];
+  int total = 0;
+  for (int s = 0; s < nS; ++s) {
+    const int Ht = fd.planes.res[s][3];
+    int i0, i1;
+    float w0, w1, m;
+    axis_tap(t0, Ht, i0, i1, w0, w1, m);
+    int lo = i0;
+    if (has_fwd) { axis_tap(t1, Ht, i0, i1, w0, w1, m); lo = min(lo, i0); }
+    if (has_bwd) { axis_tap(t2, Ht, i0, i1, w0, w1, m); lo = min(lo, i0); }
+    r_lo[s] = lo;
+    for (int j = 0; j < 3; ++j) {
+      lds_off[s][j] = total;
+      total += TROWS * fd.planes.res[s][j] * C;  // time plane j pairs spatial axis j with t
+    }
+  }
+  for (int i = threadIdx.x; i < total; i += blockDim.x) lds_i[i] = 0;
+  __syncthreads();
+  const float vmax = stats[ST_VMAX];
+  const float fxs = fx_scale((float)chunk * stats[ST_GD_MAX] * vmax * vmax * 1.01f + 1e-30f, 30);
+
+  const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
+  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {
+    const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
+    float fl[8];
+    {
+      uint4 u = *reinterpret_cast<const uint4*>(flow16 + p * 16);
+      const half_t* h = reinterpret_cast<const half_t*>(&u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
+    }
+    const half_t* row = dX + p * in_pad;
+    for (int s = 0; s < nS; ++s) {
+      float gd[C];
+      {
+        uint4 u = *reinterpret_cast<const uint4*>(row + (nS + s) * C);
+        const half_t* h = reinterpret_cast<const half_t*>(&u);
+#pragma unroll
+        for (int k = 0; k < C; ++k) gd[k] = h2f(h[k]);
+      }
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        if ((e == 1 && !has_fwd) || (e == 2 && !has_bwd)) continue;
+        const float coef = e == 0 ? c0 : 0.25f;
+        const float xe[4] = {c4[0] + (e == 1 ? fl[0] : e == 2 ? fl[3] : 0.0f), c4[1] + (e == 1 ? fl[1] : e == 2 ? fl[4] : 0.0f),
+                             c4[2] + (e == 1 ? fl[2] : e == 2 ? fl[5] : 0.0f), e == 0 ? t0 : e == 1 ? t1 : t2};
+        Tap taps[3];
+        float v[3][C];
+        int cis[3];
+        group_taps<C>(fd, s, xe, true, taps, v, cis);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const Tap& t = taps[j];
+          const int W = fd.planes.res[s][j];
+          const float wts[4] = {t.wx0 * t.wy0, t.wx1 * t.wy0, t.wx0 * t.wy1, t.wx1 * t.wy1};
+          const int ys[4] = {t.y0, t.y0, t.y1, t.y1}, xs_[4] = {t.x0, t.x1, t.x0, t.x1};
+#pragma unroll
+          for (int k = 0; k < C; ++k) {
+            const float gv = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
+            if (gv == 0.0f) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int rr = ys[q] - r_lo[s];
+              if (rr >= 0 && rr < TROWS) {
+                atomicAdd(&lds_i[lds_off[s][j] + (rr * W + xs_[q]) * C + k], __float2int_rn(gv * wts[q] * fxs));
+              } else {  // outside the LDS window (only for exotic num_frames / time_resolution): direct
+                atomicAdd(garena + fd.planes.off[s][cis[j]] + ((size_t)ys[q] * W + xs_[q]) * C + k, gv * wts[q] * pscale);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float inv = pscale / fxs;
+  for (int s = 0; s < nS; ++s) {
+    const int Ht = fd.planes.res[s][3];
+    int j = 0;
+    for (int ci = 0; ci < NPLANES; ++ci) {
+      if (COMB_B[ci] != 3) continue;
+      const int W = fd.planes.res[s][j];
+      float* g = garena + fd.planes.off[s][ci];
+      for (int i = threadIdx.x; i < TROWS * W * C; i += blockDim.x) {
+        const int rr = i / (W * C);
+        const int v = lds_i[lds_off[s][j] + i];
+        if (v != 0 && r_lo[s] + rr < Ht) atomicAdd(g + (size_t)(r_lo[s] + rr) * W * C + (i - rr * W * C), (float)v * inv);
+      }
+      ++j;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. static planes: passes over row bands
+// ------------------------------------------------------------------------------------------------
+#define MAX_TASKS 112
+struct BandTasks {
+  int n;
+  short s[MAX_TASKS], j[MAX_TASKS], row0[MAX_TASKS], nrows[MAX_TASKS];
+};
+
+__global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, BandTasks tasks, float* __restrict__ garena,
+                                                               const float* __restrict__ xt, int64_t P, int64_t chunk,
+                                                               const half_t* __restrict__ gvs, float pscale,
+                                                               const float* __restrict__ stats) {
+  constexpr int C = 8;
+  extern __shared__ int lds_i[];
+  const int task = blockIdx.y;
+  const int s = tasks.s[task], j = tasks.j[task], row0 = tasks.row0[task], nrows = tasks.nrows[task];
+  // static plane j of a scale: comb order (0,1)(0,2)(1,2) -> ci 0,1,3
+  const int ci = j == 0 ? 0 : j == 1 ? 1 : 3;
+  const int a = COMB_A[ci], b = COMB_B[ci];
+  const int W = fd.planes.res[s][a], H = fd.planes.res[s][b];
+  const int nS = fd.planes.n_scales;
+  const int n_el = nrows * W * C;
+  for (int i = threadIdx.x; i < n_el; i += blockDim.x) lds_i[i] = 0;
+  __syncthreads();
+  const float fxs = fx_scale((float)chunk * stats[ST_GVS_MAX + s] * 1.01f + 1e-30f, 30);
+  const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
+  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {
+    const float ca = xt[p * 4 + a], cb = xt[p * 4 + b];
+    Tap t;
+    axis_tap(cb, H, t.y0, t.y1, t.wy0, t.wy1, t.my);
+    const bool in0 = t.y0 >= row0 && t.y0 < row0 + nrows, in1 = t.y1 >= row0 && t.y1 < row0 + nrows && t.y1 != t.y0;
+    if (!in0 && !in1) continue;
+    axis_tap(ca, W, t.x0, t.x1, t.wx0, t.wx1, t.mx);
+    const uint4 u = *reinterpret_cast<const uint4*>(gvs + ((p * nS + s) * 3 + j) * C);
+    const half_t* h = reinterpret_cast<const half_t*>(&u);
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const float gv = h2f(h[k]) * fxs;
+      if (gv == 0.0f) continue;
+      if (in0) {
+        atomicAdd(&lds_i[((t.y0 - row0) * W + t.x0) * C + k], __float2int_rn(gv * (t.wx0 * t.wy0)));
+        atomicAdd(&lds_i[((t.y0 - row0) * W + t.x1) * C + k], __float2int_rn(gv * (t.wx1 * t.wy0)));
+      }
+      if (in1) {
+        atomicAdd(&lds_i[((t.y1 - row0) * W + t.x0) * C + k], __float2int_rn(gv * (t.wx0 * t.wy1)));
+        atomicAdd(&lds_i[((t.y1 - row0) * W + t.x1) * C + k], __float2int_rn(gv * (t.wx1 * t.wy1)));
+      }
+    }
+  }
+  __syncthreads();
+  const float inv = pscale / fxs;
+  float* g = garena + fd.planes.off[s][ci] + (size_t)row0 * W * C;
+  for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
+    const int v = lds_i[i];
+    if (v != 0) atomicAdd(g + i, (float)v * inv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. dynamic hash: scalar H per entry in LDS (int64 fixed point), then expansion into the two slices
+// ------------------------------------------------------------------------------------------------
+struct HashTasks {
+  int n;
+  short plane[MAX_TASKS], lvl[MAX_TASKS];
+  int lo[MAX_TASKS], cnt[MAX_TASKS];
+  int hoff[MAX_TASKS];  // offset of (plane, level) in Hbuf
+};
+
+__global__ void __launch_bounds__(512) dynhash_lds_kernel(FieldDesc fd, HashTasks tasks, const float* __restrict__ xt, int64_t P,
+                                                         int64_t chunk, const half_t* __restrict__ gdynT,
+                                                         const float* __restrict__ stats, float* __restrict__ Hbuf) {
+  extern __shared__ long long lds_l[];
+  const int task = blockIdx.y;
+  const int plane = tasks.plane[task], lvl = tasks.lvl[task], lo = tasks.lo[task], cnt = tasks.cnt[task];
+  const GridDesc& g = fd.hd[plane];
+  int cidx = lvl;
+  for (int q = 0; q < plane; ++q) cidx += fd.hd[q].n_levels;
+  const float gmax = stats[ST_DYN_MAX + cidx];
+  if (!(gmax > 0.0f)) return;  // no gradient reaches this level at all
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) lds_l[i] = 0;
+  __syncthreads();
+  const float fxs = fx_scale((float)chunk * gmax * 1.01f, 61);
+  const int ca = plane == 2 ? 1 : 0, cb = plane == 0 ? 1 : 2;
+  const float scale = g.scale[lvl];
+  const uint32_t res = g.res[lvl], size = g.size[lvl];
+  const bool hashed = (g.hashed_mask >> lvl) & 1u;
+  const half_t* gcol = gdynT + (int64_t)cidx * P;
+  const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
+  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {
+    const float go = h2f(gcol[p]);
+    if (go == 0.0f) continue;
+    const float q[2] = {xt[p * 4 + ca], xt[p * 4 + cb]};
+    Cell<2> c = locate<2>(q, scale);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t gv[2];
+      const float w = corner<2>(c, k, gv);
+      const int idx = (int)grid_index<2>(gv, res, size, hashed) - lo;
+      if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)__float2ll_rn(go * w * fxs));
+    }
+  }
+  __syncthreads();
+  const double inv = 1.0 / (double)fxs;
+  float* H = Hbuf + tasks.hoff[task] + lo;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const long long v = lds_l[i];
+    if (v != 0) atomicAdd(H + i, (float)((double)v * inv));
+  }
+}
+
+// grad[slice i1][entry][f] += w1 * basis[f] * H[entry] * pscale (and i2 with w2): hash_field.py:65-88 adjoint
+__global__ void __launch_bounds__(256) dynhash_expand_kernel(FieldDesc fd, FieldGrads fg, const float* __restrict__ tinfo,
+                                                            const float* __restrict__ Hbuf, int plane, int hoff0, float pscale) {
+  const GridDesc& g = fd.hd[plane];
+  const int lvl = blockIdx.y;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.size[lvl]) return;
+  const float h = Hbuf[hoff0 + g.offset[lvl] + i] * pscale;
+  if (h == 0.0f) return;
+  const TimeCoef tc = time_coef(tinfo[0], fd.n_slices);
+  float4_t* a = reinterpret_cast<float4_t*>(fg.hd_tables[plane][tc.sp.i1] + ((size_t)g.offset[lvl] + i) * 4);
+  float4_t va = *a;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) va[f] += h * tc.basis[f] * tc.sp.w1;
+  *a = va;
+  if (tc.sp.i1 != tc.sp.i2) {
+    float4_t* b = reinterpret_cast<float4_t*>(fg.hd_tables[plane][tc.sp.i2] + ((size_t)g.offset[lvl] + i) * 4);
+    float4_t vb = *b;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) vb[f] += h * tc.basis[f] * tc.sp.w2;
+    *b = vb;
+  }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+struct WorkLayout {
+  int64_t gvs, gdynT, stats, hbuf, total;
+  int64_t hbuf_floats;
+};
+static WorkLayout work_layout(const l4d_field_desc* f, int64_t P) {
+  WorkLayout w;
+  int64_t L3 = f->hash_dynamic[0].n_levels + f->hash_dynamic[1].n_levels + f->hash_dynamic[2].n_levels;
+  int64_t hb = 0;
+  for (int p = 0; p < 3; ++p)
+    for (int l = 0; l < f->hash_dynamic[p].n_levels; ++l) hb += f->hash_dynamic[p].size[l];
+  w.hbuf_floats = hb;
+  w.stats = 0;
+  w.hbuf = align256(ST_SIZE * 4);
+  w.gvs = w.hbuf + align256(hb * 4);
+  w.gdynT = w.gvs + align256(P * f->n_scales * 3 * 8 * 2);
+  w.total = w.gdynT + align256(L3 * P * 2);
+  return w;
+}
+
+extern "C" int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f, int64_t P) { return work_layout(f, P).total; }
+
+extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_grads* g, const float* xt, const void* flow16,
+                                      const float* tinfo, int64_t P, const void* dX, int32_t in_pad, float param_scale,
+                                      const float* plane_abs_max, void* workspace, void* dflow16, void* stream_) {
+  if (P == 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  FieldDesc d;
+  if (make_field(f, d)) return 1;
+  FieldGrads fg;
+  fg.hs_table = g->hash_static_table;
+  for (int p = 0; p < 3; ++p)
+    for (int s = 0; s < MAX_SLICES; ++s) fg.hd_tables[p][s] = s < f->n_slices ? g->hash_dynamic_tables[p][s] : nullptr;
+  fg.planes_cl = g->planes_cl;
+  const int L3 = d.hd[0].n_levels + d.hd[1].n_levels + d.hd[2].n_levels;
+  if (ST_DYN_MAX + L3 > ST_SIZE) { l4d_set_error(1, "l4d_density_encode_bwd: too many dynamic hash levels"); return 1; }
+  const WorkLayout w = work_layout(f, P);
+  char* ws = (char*)workspace;
+  float* stats = (float*)(ws + w.stats);
+  float* Hbuf = (float*)(ws + w.hbuf);
+  half_t* gvs = (half_t*)(ws + w.gvs);
+  half_t* gdynT = (half_t*)(ws + w.gdynT);
+  hipError_t e = hipMemsetAsync(ws, 0, w.gvs, stream);  // stats + Hbuf
+  if (e == hipSuccess) e = hipMemcpyAsync(stats + ST_VMAX, plane_abs_max, sizeof(float), hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
+
+  hipLaunchKernelGGL(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, stream, d, fg.hs_table, xt,
+                     (const half_t*)flow16, tinfo, P, (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, (half_t*)dflow16);
+
+  // chunking: one chunk per workgroup column; few enough chunks that the flush traffic stays small
+  int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, 8192)));
+  const int64_t chunk = ceil_div64(P, n_chunks);
+  n_chunks = (int)ceil_div64(P, chunk);
+
+  // time planes
+  {
+    int lds = 0;
+    for (int s = 0; s < d.planes.n_scales; ++s)
+      for (int j = 0; j < 3; ++j) lds += TROWS * d.planes.res[s][j] * 8 * 4;
+    if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
+    hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
+                       tinfo, P, chunk, (const half_t*)dX, in_pad, param_scale, stats);
+  }
+  // static planes
+  {
+    BandTasks t;
+    t.n = 0;
+    int max_lds = 0;
+    static const int CA[3] = {0, 0, 1}, CB[3] = {1, 2, 2};
+    for (int s = 0; s < d.planes.n_scales; ++s)
+      for (int j = 0; j < 3; ++j) {
+        const int W = d.planes.res[s][CA[j]], H = d.planes.res[s][CB[j]];
+        int rows = std::max(1, (128 * 1024) / (W * 8 * 4));
+        rows = std::min(rows, H);
+        for (int r0 = 0; r0 < H; r0 += rows) {
+          if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many plane bands"); return 1; }
+          t.s[t.n] = s; t.j[t.n] = j; t.row0[t.n] = r0; t.nrows[t.n] = std::min(rows, H - r0);
+          max_lds = std::max(max_lds, t.nrows[t.n] * W * 8 * 4);
+          ++t.n;
+        }
+      }
+    hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    hipLaunchKernelGGL(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(512), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
+                       gvs, param_scale, stats);
+  }
+  // dynamic hash
+  {
+    HashTasks t;
+    t.n = 0;
+    int hoff = 0, hoff_plane[3];
+    const int max_entries = (128 * 1024) / 8;
+    for (int p = 0; p < 3; ++p) {
+      hoff_plane[p] = hoff;
+      for (int l = 0; l < d.hd[p].n_levels; ++l) {
+        const int size = (int)d.hd[p].size[l];
+        for (int lo = 0; lo < size; lo += max_entries) {
+          if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many hash tasks"); return 1; }
+          t.plane[t.n] = p; t.lvl[t.n] = l; t.lo[t.n] = lo; t.cnt[t.n] = std::min(max_entries, size - lo);
+          t.hoff[t.n] = hoff_plane[p] + (int)d.hd[p].offset[l];
+          ++t.n;
+        }
+      }
+      hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
+    }
+    hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(512), 128 * 1024, stream, d, t, xt, P, chunk, gdynT, stats, Hbuf);
+    for (int p = 0; p < 3; ++p) {
+      unsigned max_size = 0;
+      for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);
+      hipLaunchKernelGGL(dynhash_expand_kernel, dim3((max_size + 255) / 256, d.hd[p].n_levels), dim3(256), 0, stream, d, fg, tinfo,
+                         Hbuf, p, hoff_plane[p], param_scale);
+    }
+  }
+  L4D_LAUNCH_CHECK("l4d_density_encode_bwd");
+  return 0;
+}

@@ -6,26 +6,7 @@
 // The backward kernel is the exact adjoint: scatters into plane / hash gradients and returns d(flow).
 //
 // This is the direct-gather formulation (every table entry is fetched through L1/L2).
-#include "hashgrid_dev.h"
-#include "planes_dev.h"
-
-#define MAX_SLICES 8
-
-struct FieldDesc {
-  GridDesc hs;               // static 3-D hash grid, F = 4
-  const half_t* hs_table;
-  GridDesc hd[3];            // xy / xz / yz 2-D grids, F = 4
-  const half_t* hd_tables[3][MAX_SLICES];
-  int n_slices;
-  PlaneDesc planes;
-  const float* planes_cl;
-};
-
-struct FieldGrads {
-  float* hs_table;
-  float* hd_tables[3][MAX_SLICES];
-  float* planes_cl;
-};
+#include "field_dev.h"
 
 // tinfo: [0]=t, [1]=t1, [2]=t2, [3]=has_fwd, [4]=has_bwd, [5]=frame_idx  (model/lidar4d.py:143,157-173)
 __global__ void time_setup_kernel(const float* __restrict__ t, int num_frames, float* __restrict__ tinfo) {
@@ -38,36 +19,6 @@ __global__ void time_setup_kernel(const float* __restrict__ t, int num_frames, f
   tinfo[3] = (f < num_frames - 1) ? 1.0f : 0.0f;
   tinfo[4] = (f > 0) ? 1.0f : 0.0f;
   tinfo[5] = (float)f;
-}
-
-struct TimeCoef {
-  SlicePair sp;
-  float basis[4];
-};
-__device__ __forceinline__ TimeCoef time_coef(float t, int n_slices) {
-  TimeCoef c;
-  c.sp = slice_pair(t, n_slices);
-  lagrange4(t, c.basis);
-  return c;
-}
-
-// one HashGridT level (F = 4): fp16-rounded slice features, fp32 blend, interpT
-__device__ __forceinline__ float hash_t_level(const FieldDesc& fd, int plane, int lvl, const TimeCoef& tc, const float xy[2]) {
-  const GridDesc& g = fd.hd[plane];
-  const size_t off = (size_t)g.offset[lvl] * 4;
-  const bool hashed = (g.hashed_mask >> lvl) & 1u;
-  float a[4], b[4];
-  level_lookup<2, 4>(fd.hd_tables[plane][tc.sp.i1] + off, g.scale[lvl], g.res[lvl], g.size[lvl], hashed, xy, a);
-  float r = 0.0f;
-  if (tc.sp.i1 != tc.sp.i2) {
-    level_lookup<2, 4>(fd.hd_tables[plane][tc.sp.i2] + off, g.scale[lvl], g.res[lvl], g.size[lvl], hashed, xy, b);
-#pragma unroll
-    for (int f = 0; f < 4; ++f) r += tc.basis[f] * (tc.sp.w1 * h2f(f2h(a[f])) + tc.sp.w2 * h2f(f2h(b[f])));
-  } else {
-#pragma unroll
-    for (int f = 0; f < 4; ++f) r += tc.basis[f] * h2f(f2h(a[f]));
-  }
-  return r;
 }
 
 template <int C>
@@ -167,164 +118,6 @@ __global__ void __launch_bounds__(256) density_encode_fwd_kernel(FieldDesc fd, c
   for (; col < in_pad; ++col) row[col] = (half_t)1.0f;  // tcnn pads the network input with ones
 }
 
-// ---- backward -------------------------------------------------------------------------------------
-template <int C>
-__device__ __forceinline__ void planes_group_bwd(const FieldDesc& fd, const FieldGrads& fg, int s, const float coord[4],
-                                                 bool time_group, const float g[C], float pscale, bool want_coord,
-                                                 float gcoord[4]) {
-  Tap taps[3];
-  float v[3][C];
-  int cis[3];
-  int n = 0;
-#pragma unroll
-  for (int ci = 0; ci < NPLANES; ++ci) {
-    const int a = COMB_A[ci], b = COMB_B[ci];
-    if ((b == 3) != time_group) continue;
-    const int W = fd.planes.res[s][a], H = fd.planes.res[s][b];
-    axis_tap(coord[a], W, taps[n].x0, taps[n].x1, taps[n].wx0, taps[n].wx1, taps[n].mx);
-    axis_tap(coord[b], H, taps[n].y0, taps[n].y1, taps[n].wy0, taps[n].wy1, taps[n].my);
-    sample_plane<C>(fd.planes_cl + fd.planes.off[s][ci], W, taps[n], v[n]);
-    cis[n] = ci;
-    ++n;
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    float gv[C];
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-      gv[k] = g[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
-      any |= gv[k] != 0.0f;
-    }
-    if (!any) continue;
-    const int ci = cis[j];
-    float gix = 0.0f, giy = 0.0f;
-    scatter_plane<C>(fg.planes_cl + fd.planes.off[s][ci], fd.planes_cl + fd.planes.off[s][ci], fd.planes.res[s][COMB_A[ci]],
-                     taps[j], gv, gix, giy, want_coord, pscale);
-    gcoord[COMB_A[ci]] += gix * taps[j].mx;
-    gcoord[COMB_B[ci]] += giy * taps[j].my;
-  }
-}
-
-__global__ void __launch_bounds__(256) density_encode_bwd_kernel(FieldDesc fd, FieldGrads fg, const float* __restrict__ xt,
-                                                                const half_t* __restrict__ flow16,
-                                                                const float* __restrict__ tinfo, int64_t P,
-                                                                const half_t* __restrict__ dX, int in_pad, float pscale,
-                                                                half_t* __restrict__ dflow16) {
-  constexpr int C = 8;
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
-  const float t0 = tinfo[0], t1 = tinfo[1], t2 = tinfo[2];
-  const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
-  float fl[8];
-  {
-    uint4 u = *reinterpret_cast<const uint4*>(flow16 + p * 16);
-    const half_t* h = reinterpret_cast<const half_t*>(&u);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
-  }
-  const float x0[4] = {c4[0], c4[1], c4[2], t0};
-  const float x1[4] = {c4[0] + fl[0], c4[1] + fl[1], c4[2] + fl[2], t1};
-  const float x2[4] = {c4[0] + fl[3], c4[1] + fl[4], c4[2] + fl[5], t2};
-  const half_t* row = dX + p * in_pad;
-  const int nS = fd.planes.n_scales;
-  // a missing neighbour re-uses the current frame's features, so its 0.25 flows to the current frame
-  const float c0 = 0.5f + (has_fwd ? 0.0f : 0.25f) + (has_bwd ? 0.0f : 0.25f);
-  float g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f}, gdummy[4] = {0.f, 0.f, 0.f, 0.f};
-
-  for (int s = 0; s < nS; ++s) {
-    float gs[C], gd[C], tmp[C];
-    {
-      uint4 u = *reinterpret_cast<const uint4*>(row + s * C);
-      const half_t* h = reinterpret_cast<const half_t*>(&u);
-#pragma unroll
-      for (int k = 0; k < C; ++k) gs[k] = h2f(h[k]);
-      u = *reinterpret_cast<const uint4*>(row + (nS + s) * C);
-      h = reinterpret_cast<const half_t*>(&u);
-#pragma unroll
-      for (int k = 0; k < C; ++k) gd[k] = h2f(h[k]);
-    }
-    planes_group_bwd<C>(fd, fg, s, x0, false, gs, pscale, false, gdummy);
-#pragma unroll
-    for (int k = 0; k < C; ++k) tmp[k] = c0 * gd[k];
-    planes_group_bwd<C>(fd, fg, s, x0, true, tmp, pscale, false, gdummy);
-#pragma unroll
-    for (int k = 0; k < C; ++k) tmp[k] = 0.25f * gd[k];
-    if (has_fwd) planes_group_bwd<C>(fd, fg, s, x1, true, tmp, pscale, true, g1);
-    if (has_bwd) planes_group_bwd<C>(fd, fg, s, x2, true, tmp, pscale, true, g2);
-  }
-  int col = 2 * nS * C;
-
-  {
-    const float xs[3] = {x0[0], x0[1], x0[2]};
-    for (int lvl = 0; lvl < fd.hs.n_levels; ++lvl) {
-      const half4_t h = *reinterpret_cast<const half4_t*>(row + col + lvl * 4);
-      float g[4];
-      bool any = false;
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        g[f] = h2f(h[f]) * pscale;
-        any |= g[f] != 0.0f;
-      }
-      if (!any) continue;
-      Cell<3> c = locate<3>(xs, fd.hs.scale[lvl]);
-      float* gt = fg.hs_table + (size_t)fd.hs.offset[lvl] * 4;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        uint32_t gv[3];
-        const float w = corner<3>(c, k, gv);
-        const uint32_t idx = grid_index<3>(gv, fd.hs.res[lvl], fd.hs.size[lvl], (fd.hs.hashed_mask >> lvl) & 1u);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) atomicAdd(gt + (size_t)idx * 4 + f, w * g[f]);
-      }
-    }
-    col += fd.hs.n_levels * 4;
-  }
-
-  const TimeCoef tc0 = time_coef(t0, fd.n_slices);
-#pragma unroll
-  for (int plane = 0; plane < 3; ++plane) {
-    const int ca = plane == 2 ? 1 : 0, cb = plane == 0 ? 1 : 2;
-    const float q0[2] = {x0[ca], x0[cb]};
-    const GridDesc& gd = fd.hd[plane];
-    for (int lvl = 0; lvl < gd.n_levels; ++lvl) {
-      const float go = h2f(row[col + lvl]) * c0 * pscale;  // neighbour-frame hash lookups are no_grad (lidar4d.py:160,169)
-      if (go == 0.0f) continue;
-      Cell<2> c = locate<2>(q0, gd.scale[lvl]);
-      const size_t off = (size_t)gd.offset[lvl] * 4;
-      float* ga = fg.hd_tables[plane][tc0.sp.i1] + off;
-      float* gb = fg.hd_tables[plane][tc0.sp.i2] + off;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t gv[2];
-        const float w = corner<2>(c, k, gv);
-        const uint32_t idx = grid_index<2>(gv, gd.res[lvl], gd.size[lvl], (gd.hashed_mask >> lvl) & 1u);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          const float gf = go * tc0.basis[f] * w;
-          atomicAdd(ga + (size_t)idx * 4 + f, gf * tc0.sp.w1);
-          if (tc0.sp.i1 != tc0.sp.i2) atomicAdd(gb + (size_t)idx * 4 + f, gf * tc0.sp.w2);
-        }
-      }
-    }
-    col += gd.n_levels;
-  }
-
-  // d(flow): x1 = x + flow[:3], x2 = x + flow[3:]; stays in dX's (loss-scaled) domain
-  half_t out[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) out[k] = (half_t)0.0f;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    out[k] = f2h(fminf(fmaxf(g1[k], -65504.f), 65504.f));
-    out[3 + k] = f2h(fminf(fmaxf(g2[k], -65504.f), 65504.f));
-  }
-  uint4* dst = reinterpret_cast<uint4*>(dflow16 + p * 16);
-  dst[0] = reinterpret_cast<uint4*>(out)[0];
-  dst[1] = reinterpret_cast<uint4*>(out)[1];
-}
-
 // ---- sampling that also emits the normalised (x, t) rows the field kernels read --------------------
 __global__ void __launch_bounds__(256) sample_rays_xt_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                             const float* __restrict__ lin, const float* __restrict__ noise,
@@ -355,32 +148,6 @@ __global__ void __launch_bounds__(256) sample_rays_xt_kernel(const float* __rest
 // ================================================================================================
 // C ABI
 // ================================================================================================
-static int make_field(const l4d_field_desc* f, FieldDesc& d) {
-  if (f->n_slices > MAX_SLICES || f->n_scales > MAX_SCALES || f->plane_channels != 8 || f->hash_static.n_features != 4 ||
-      f->hash_static.n_dims != 3) {
-    l4d_set_error(1, "field: needs <= 8 time slices, <= 8 plane scales, 8 plane channels, F = 4 hash features");
-    return 1;
-  }
-  d.hs = make_grid_desc(&f->hash_static);
-  d.hs_table = (const half_t*)f->hash_static_table;
-  for (int p = 0; p < 3; ++p) {
-    if (f->hash_dynamic[p].n_features != 4 || f->hash_dynamic[p].n_dims != 2) {
-      l4d_set_error(1, "field: dynamic grids must be 2-D with F = 4");
-      return 1;
-    }
-    d.hd[p] = make_grid_desc(&f->hash_dynamic[p]);
-    for (int s = 0; s < MAX_SLICES; ++s) d.hd_tables[p][s] = s < f->n_slices ? (const half_t*)f->hash_dynamic_tables[p][s] : nullptr;
-  }
-  d.n_slices = f->n_slices;
-  d.planes.n_scales = f->n_scales;
-  for (int s = 0; s < f->n_scales; ++s) {
-    for (int k = 0; k < 4; ++k) d.planes.res[s][k] = f->plane_res[s * 4 + k];
-    for (int c = 0; c < NPLANES; ++c) d.planes.off[s][c] = f->plane_off[s * NPLANES + c];
-  }
-  d.planes_cl = f->planes_cl;
-  return 0;
-}
-
 extern "C" int l4d_field_width(const l4d_field_desc* f) {
   return 2 * f->n_scales * f->plane_channels + f->hash_static.n_levels * f->hash_static.n_features +
          f->hash_dynamic[0].n_levels + f->hash_dynamic[1].n_levels + f->hash_dynamic[2].n_levels;
@@ -417,19 +184,3 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
   return 0;
 }
 
-extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_grads* g, const float* xt, const void* flow16,
-                                      const float* tinfo, int64_t P, const void* dX, int32_t in_pad, float param_scale,
-                                      void* dflow16, void* stream) {
-  if (P == 0) return 0;
-  FieldDesc d;
-  if (make_field(f, d)) return 1;
-  FieldGrads fg;
-  fg.hs_table = g->hash_static_table;
-  for (int p = 0; p < 3; ++p)
-    for (int s = 0; s < MAX_SLICES; ++s) fg.hd_tables[p][s] = s < f->n_slices ? g->hash_dynamic_tables[p][s] : nullptr;
-  fg.planes_cl = g->planes_cl;
-  hipLaunchKernelGGL(density_encode_bwd_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, d, fg, xt,
-                     (const half_t*)flow16, tinfo, P, (const half_t*)dX, in_pad, param_scale, (half_t*)dflow16);
-  L4D_LAUNCH_CHECK("l4d_density_encode_bwd");
-  return 0;
-}

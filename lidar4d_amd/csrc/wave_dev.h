@@ -1,0 +1,50 @@
+// Wave64 cooperative helpers for gradient accumulation on gfx950.
+//
+// Measured on MI355X (profiles/r01_ubench_*.txt): scattered global fp32 atomics sustain ~20 G lane-ops/s no matter
+// the scope, coalesced ones 267 G/s; LDS integer atomics (ds_add_u32/u64) 4.8 / 2.9 T lane-ops/s, but LDS *float*
+// atomics (ds_add_f32, ds_pk_add_f16) only 0.2 T/s.  Hence: (1) pre-reduce runs of equal addresses inside a wave
+// before touching global memory, (2) accumulate in LDS as fixed-point integers (which is also order-independent,
+// i.e. deterministic), flush once, coalesced.
+#pragma once
+#include "common.h"
+
+// Run-length pre-reduction: consecutive lanes (consecutive samples of a ray) that target the same key are summed
+// into the first lane of the run.  Returns true for lanes that must issue the atomic (run heads; every active lane
+// when the wave's keys are mostly distinct and the shuffle work would be wasted).  All 64 lanes must call this.
+template <int K>
+__device__ __forceinline__ bool wave_run_reduce(uint32_t key, bool active, float v[K]) {
+  const int lane = __lane_id();
+  if (!active) key = 0xFFFFFF00u | (uint32_t)lane;  // unique, never merged
+  const uint32_t prev = __shfl_up(key, 1, 64);
+  const bool head = (lane == 0) || (key != prev);
+  const unsigned long long H = __ballot(head);
+  if (__popcll(H) > 40) return active;  // wave-uniform: little to merge
+  const unsigned long long above = (lane == 63) ? 0ull : (H & ~((2ull << lane) - 1ull));
+  const int end = above ? (__ffsll((long long)above) - 2) : 63;  // last lane of this lane's run
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float t = __shfl_down(v[k], d, 64);
+      if (lane + d <= end) v[k] += t;
+    }
+  }
+  return head && active;
+}
+
+// fixed-point scale: largest power of two s with bound * s < 2^bits (bound > 0)
+__device__ __forceinline__ float fx_scale(float bound, int bits) {
+  if (!(bound > 0.0f)) return 1.0f;
+  int e;
+  frexpf(bound, &e);  // bound < 2^e
+  return ldexpf(1.0f, bits - e);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+// non-negative floats order like their bit patterns
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) { atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v)); }

@@ -154,7 +154,8 @@ class RenderFn(torch.autograd.Function):
         pe = model.planes_encoder
         gcl = torch.zeros(pe.layout.numel, dtype=torch.float32, device=dev)
         fd = _field_desc(model)
-        dflow16 = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv)
+        vmax = pe._arena().abs().max().reshape(1)
+        dflow16 = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv, vmax)
         tmp = torch.empty(pe.layout.numel, dtype=torch.float32, device=dev)
         planes = pe._flat_planes()
         views, o = [], 0

@@ -93,9 +93,10 @@ def hashgrid_t_bwd(meta, x, cols, n_slices, t_dev, dout, grad_tables, grad_scale
     """grad_tables: list of n_slices fp32 tensors or None (slices that *t does not select are never touched)."""
     _chk(x, torch.float32, "x"), _chk(dout, None, "dout")
     d = meta.desc()
+    scratch = torch.empty(meta.n_entries * (meta.n_features // 4), dtype=torch.float32, device=x.device)
     call("l4d_hashgrid_t_bwd", C.byref(d), _p(x), x.shape[0], x.stride(0), _i32s(list(cols)), n_slices, _p(t_dev),
          C.c_void_p(dout.data_ptr() + dout.element_size() * dout_col), dout.stride(0), int(dout.dtype == torch.float16),
-         float(grad_scale), _ptrs(grad_tables), _stream())
+         float(grad_scale), _ptrs(grad_tables), _p(scratch), _stream())
 
 
 # ---- planes ----------------------------------------------------------------------------------------
@@ -298,13 +299,17 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
     return X
 
 
-def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_scale, dflow16=None):
-    _chk(dX, torch.float16, "dX")
+def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_scale, plane_abs_max, dflow16=None):
+    """Adjoint of density_encode_fwd (several launches, lidar4d_amd/csrc/field_bwd.hip).  plane_abs_max: 1-element fp32
+    device tensor, max |plane parameter| (bound for the fixed-point LDS accumulators)."""
+    _chk(dX, torch.float16, "dX"), _chk(plane_abs_max, torch.float32, "plane_abs_max")
     P, in_pad = dX.shape
     if dflow16 is None:
         dflow16 = torch.empty(P, 16, dtype=torch.float16, device=dX.device)
+    nbytes = _lib.lib().l4d_density_encode_bwd_workspace(C.byref(field_desc), P)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dX.device)
     call("l4d_density_encode_bwd", C.byref(field_desc), C.byref(field_grads), _p(xt), _p(flow16), _p(tinfo), P, _p(dX),
-         in_pad, float(param_scale), _p(dflow16), _stream())
+         in_pad, float(param_scale), _p(plane_abs_max), _p(ws), _p(dflow16), _stream())
     return dflow16
 
 
