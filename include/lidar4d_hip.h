@@ -73,11 +73,14 @@ int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc /*host*/, const float* x, int64
                        const float* t, void* out, int32_t out_stride, int32_t out_is_half, void* stream);
 /* dout [P, dout_stride] fp32 or fp16, multiplied by grad_scale; grad_tables host array of n_slices device
  * pointers to fp32 tables (accumulated into).  Only the slices selected by *t are touched.
- * scratch: n_entries * F/4 floats of device memory (the per-entry scalar accumulators; zeroed here). */
+ * scratch: n_entries * F/4 floats of device memory (the per-entry scalar accumulators; zeroed here).
+ * workspace: null, or l4d_hashgrid_t_bwd_workspace() bytes -> the hashed levels use the sorted (binned) scatter
+ * instead of global atomics (needs fp16 dout); worthwhile from ~1e6 points. */
+int64_t l4d_hashgrid_t_bwd_workspace(const l4d_grid_desc* desc /*host*/, int64_t P);
 int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
                        const int32_t* cols /*host*/, int32_t n_slices, const float* t, const void* dout,
                        int32_t dout_stride, int32_t dout_is_half, float grad_scale,
-                       float* const* grad_tables /*host*/, float* scratch, void* stream);
+                       float* const* grad_tables /*host*/, float* scratch, void* workspace, void* stream);
 
 /* ---- Planes4D : model/planes_field.py:87-141,198-239 --------------------------------------------
  * planes_cl  channel-last copy of the hex-plane parameters: for scale s, plane c (comb order

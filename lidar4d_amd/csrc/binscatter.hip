@@ -1,0 +1,249 @@
+// Sorted gradient scatter for the large 3-D hash tables (static grid 2^19 x 4, flow grid 2^18 x 8) on gfx950.
+//
+// Scattered global fp32 atomics sustain ~20 G lane-ops/s on MI355X (profiles/r01_ubench_global_atomics.txt);
+// a 16,384-ray step needs 3.2 G of them for the static grid alone (148 ms measured).  Tables of 8 MB per level do
+// not fit LDS, so contributions are first *binned* by table segment and then reduced segment by segment in LDS:
+//
+//   pass 1  (one thread per (sample, level)): the 2^D corner contributions {entry, w * g[0..NV)} (fp16 payload) are
+//           partitioned inside the workgroup by bin = entry >> shift (LDS histogram + ranks), bin space is reserved
+//           with ONE global atomic per (workgroup, bin), and each bin's records go out as a contiguous run.
+//           Coarse levels first merge runs of equal entries along the ray (wave_run_reduce).
+//   pass 2  (one workgroup per (level, bin)): streams the bin's records, accumulates them in LDS as int64 fixed
+//           point (ds_add_u64: 2.9 T lane-ops/s, exact and order independent), and adds the segment to the fp32
+//           gradient table with plain stores -- each segment has exactly one owner, no global atomics at all.
+//
+// Non-hashed (dense, coarse) levels and bin overflow fall back to run-reduced global atomics.
+#include <algorithm>
+
+#include "hashgrid_dev.h"
+#include "wave_dev.h"
+#include "binscatter.h"
+
+#define BS_THREADS 256
+#define BS_MAX_BINS 128
+
+template <int NV>
+struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
+
+template <int D, int NV>
+__global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
+                                                              BsCols cols, const half_t* __restrict__ g, int g_stride, int g_col,
+                                                              float pre_scale, int shift, int bpl, int64_t cap,
+                                                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ bins,
+                                                              float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
+  constexpr int NC = 1 << D;
+  constexpr int NW = RecWords<NV>::n;
+  __shared__ uint32_t hist[BS_MAX_BINS], boff[BS_MAX_BINS], bbase[BS_MAX_BINS];
+  __shared__ uint32_t stage[BS_THREADS * NC * NW];
+  __shared__ uint8_t rbin[BS_THREADS * NC];
+  __shared__ uint32_t total_s;
+  const int lvl = blockIdx.y;
+  const int lane = __lane_id();
+  const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = pr < P;
+  const int64_t p = valid ? pr : P - 1;
+  const bool hashed = (desc.hashed_mask >> lvl) & 1u;
+  const uint32_t size = desc.size[lvl];
+  const int nbins = (int)((size + (1u << shift) - 1) >> shift);
+  const bool binned = hashed && nbins <= BS_MAX_BINS && nbins > 1;
+
+  float gv[NV];
+  bool any = false;
+  float amax = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    gv[j] = valid ? h2f(g[p * g_stride + g_col + lvl * NV + j]) * pre_scale : 0.0f;
+    any |= gv[j] != 0.0f;
+    amax = fmaxf(amax, fabsf(gv[j]));
+  }
+  if (threadIdx.x < BS_MAX_BINS) hist[threadIdx.x] = 0;
+  __syncthreads();
+
+  float xin[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = x[p * x_stride + cols.c[d]];
+  Cell<D> c = locate<D>(xin, desc.scale[lvl]);
+  uint32_t keys[NC];
+  float vals[NC][NV];
+  bool emit[NC];
+  uint32_t pos[NC];
+  const bool wave_any = __any(any);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    uint32_t gg[D];
+    const float w = corner<D>(c, k, gg);
+    keys[k] = grid_index<D>(gg, desc.res[lvl], size, hashed);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) vals[k][j] = w * gv[j];
+    emit[k] = wave_any ? wave_run_reduce<NV>(keys[k], any, vals[k]) : false;
+    if (emit[k]) {
+      bool nz = false;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) nz |= vals[k][j] != 0.0f;
+      emit[k] = nz;
+    }
+  }
+  if (!binned) {  // dense / tiny level: run-reduced atomics straight into the output (block-uniform branch)
+    float* o = out + (size_t)desc.offset[lvl] * NV;
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (emit[k]) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+          if (vals[k][j] != 0.0f) atomicAdd(o + (size_t)keys[k] * NV + j, vals[k][j] * out_scale);
+      }
+    return;
+  }
+  amax = wave_max(amax);
+  if (lane == 0 && amax > 0.0f) atomic_max_nonneg(lvl_max + lvl, amax);
+
+  // rank inside the workgroup
+#pragma unroll
+  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[keys[k] >> shift], 1u) : 0u;
+  __syncthreads();
+  if (threadIdx.x < 64) {  // exclusive scan of <= 128 bins by one wave, global reservation per bin
+    uint32_t c0 = lane < nbins ? hist[lane] : 0u, c1 = lane + 64 < nbins ? hist[lane + 64] : 0u;
+    uint32_t inc0 = c0, inc1 = c1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t a = __shfl_up(inc0, d, 64), b = __shfl_up(inc1, d, 64);
+      if (lane >= d) { inc0 += a; inc1 += b; }
+    }
+    const uint32_t tot0 = __shfl(inc0, 63, 64);
+    if (lane < nbins) {
+      boff[lane] = inc0 - c0;
+      bbase[lane] = c0 ? atomicAdd(&cursor[lvl * BS_MAX_BINS + lane], c0) : 0u;
+    }
+    if (lane + 64 < nbins) {
+      boff[lane + 64] = tot0 + inc1 - c1;
+      bbase[lane + 64] = c1 ? atomicAdd(&cursor[lvl * BS_MAX_BINS + lane + 64], c1) : 0u;
+    }
+    if (lane == 63) total_s = tot0 + inc1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NC; ++k)
+    if (emit[k]) {
+      const uint32_t b = keys[k] >> shift;
+      const uint32_t r = boff[b] + pos[k];
+      rbin[r] = (uint8_t)b;
+      stage[r * NW] = keys[k];
+      half_t hv[2 * (NW - 1)];
+#pragma unroll
+      for (int j = 0; j < 2 * (NW - 1); ++j) hv[j] = j < NV ? f2h(fminf(fmaxf(vals[k][j], -65504.f), 65504.f)) : (half_t)0.0f;
+#pragma unroll
+      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = reinterpret_cast<uint32_t*>(hv)[q];
+    }
+  __syncthreads();
+  const uint32_t total = total_s;
+  for (uint32_t dw = threadIdx.x; dw < total * NW; dw += blockDim.x) {
+    const uint32_t r = dw / NW, wq = dw - r * NW;
+    const uint32_t b = rbin[r];
+    const uint64_t slot = (uint64_t)bbase[b] + (r - boff[b]);
+    if (slot < (uint64_t)cap) {
+      bins[(((uint64_t)lvl * bpl + b) * cap + slot) * NW + wq] = stage[dw];
+    } else if (wq == 0) {  // bin overflow (never with hashed keys and the default slack): direct atomics
+      const uint32_t key = stage[r * NW];
+      const half_t* hv = reinterpret_cast<const half_t*>(&stage[r * NW + 1]);
+      float* o = out + ((size_t)desc.offset[lvl] + key) * NV;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) atomicAdd(o + j, h2f(hv[j]) * out_scale);
+    }
+  }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(512) bin_pass2_kernel(GridDesc desc, int shift, int bpl, int64_t cap, int64_t P,
+                                                       const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ bins,
+                                                       const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
+  constexpr int NW = RecWords<NV>::n;
+  extern __shared__ long long acc[];
+  const int lvl = blockIdx.y, b = blockIdx.x;
+  const uint32_t size = desc.size[lvl];
+  const bool hashed = (desc.hashed_mask >> lvl) & 1u;
+  const int nbins = (int)((size + (1u << shift) - 1) >> shift);
+  if (!hashed || nbins > BS_MAX_BINS || nbins <= 1 || b >= nbins) return;
+  const uint32_t n = (uint32_t)min((int64_t)cursor[lvl * BS_MAX_BINS + b], cap);
+  if (n == 0) return;
+  const uint32_t lo = (uint32_t)b << shift;
+  const int n_el = (int)min(1u << shift, size - lo) * NV;
+  for (int i = threadIdx.x; i < n_el; i += blockDim.x) acc[i] = 0;
+  __syncthreads();
+  const float fxs = fx_scale((float)P * lvl_max[lvl] * 1.01f + 1e-30f, 61);
+  const uint32_t* rec = bins + ((uint64_t)lvl * bpl + b) * cap * NW;
+  for (uint32_t r = threadIdx.x; r < n; r += blockDim.x) {
+    const uint32_t key = rec[(uint64_t)r * NW] - lo;
+    uint32_t w[NW - 1];
+#pragma unroll
+    for (int q = 0; q < NW - 1; ++q) w[q] = rec[(uint64_t)r * NW + 1 + q];
+    const half_t* hv = reinterpret_cast<const half_t*>(w);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const float v = h2f(hv[j]);
+      if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[key * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
+    }
+  }
+  __syncthreads();
+  const double inv = (double)out_scale / (double)fxs;
+  float* o = out + ((size_t)desc.offset[lvl] + lo) * NV;
+  for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
+    const long long v = acc[i];
+    if (v != 0) o[i] += (float)((double)v * inv);  // sole owner of this segment
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+static int bs_shift(int NV) { return NV == 4 ? 12 : NV == 2 ? 13 : 14; }  // 128 KB of int64 per bin
+
+BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
+  BsPlan pl;
+  pl.shift = bs_shift(NV);
+  pl.rec_words = 1 + (NV + 1) / 2;
+  int64_t max_bins = 1;
+  for (int l = 0; l < d.n_levels; ++l) max_bins = std::max<int64_t>(max_bins, ((int64_t)d.size[l] + (1 << pl.shift) - 1) >> pl.shift);
+  max_bins = std::min<int64_t>(max_bins, BS_MAX_BINS);
+  const int64_t corners = 1 << n_dims;
+  pl.bins_per_level = (int)max_bins;
+  pl.cap = (P * corners + max_bins - 1) / max_bins * 3 / 2 + 4096;  // 50 % slack over the uniform share + headroom
+  pl.off_cursor = 0;
+  pl.off_max = (int64_t)d.n_levels * BS_MAX_BINS * 4;
+  pl.off_bins = (pl.off_max + 64 * 4 + 255) / 256 * 256;
+  pl.bytes = pl.off_bins + (int64_t)d.n_levels * max_bins * pl.cap * pl.rec_words * 4;
+  return pl;
+}
+
+int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t P, int x_stride, const int* cols, const half_t* g,
+               int g_stride, int g_col, float pre_scale, float* out, float out_scale, void* workspace, hipStream_t stream) {
+  if (P == 0) return 0;
+  const BsPlan pl = bs_plan(desc, n_dims, NV, P);
+  char* ws = (char*)workspace;
+  uint32_t* cursor = (uint32_t*)(ws + pl.off_cursor);
+  float* lvl_max = (float*)(ws + pl.off_max);
+  uint32_t* bins = (uint32_t*)(ws + pl.off_bins);
+  hipError_t e = hipMemsetAsync(ws, 0, pl.off_bins, stream);
+  if (e != hipSuccess) { l4d_set_error((int)e, "bs_scatter memset"); return (int)e; }
+  BsCols c;
+  for (int d = 0; d < 3; ++d) c.c[d] = d < n_dims ? cols[d] : 0;
+  dim3 grid1((unsigned)ceil_div64(P, BS_THREADS), desc.n_levels);
+  dim3 grid2(pl.bins_per_level, desc.n_levels);
+  const int lds2 = (1 << pl.shift) * NV * 8;
+#define BS_LAUNCH(D, V)                                                                                                      \
+  {                                                                                                                          \
+    hipLaunchKernelGGL((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
+                       g_col, pre_scale, pl.shift, pl.bins_per_level, pl.cap, cursor, bins, lvl_max, out, out_scale);                          \
+    hipFuncSetAttribute((const void*)bin_pass2_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);                 \
+    hipLaunchKernelGGL((bin_pass2_kernel<V>), grid2, dim3(512), lds2, stream, desc, pl.shift, pl.bins_per_level, pl.cap, P, cursor, bins,       \
+                       lvl_max, out, out_scale);                                                                            \
+  }
+  if (n_dims == 3 && NV == 4) BS_LAUNCH(3, 4)
+  else if (n_dims == 3 && NV == 2) BS_LAUNCH(3, 2)
+  else if (n_dims == 3 && NV == 1) BS_LAUNCH(3, 1)
+  else if (n_dims == 2 && NV == 4) BS_LAUNCH(2, 4)
+  else if (n_dims == 2 && NV == 2) BS_LAUNCH(2, 2)
+  else if (n_dims == 2 && NV == 1) BS_LAUNCH(2, 1)
+  else { l4d_set_error(1, "bs_scatter: unsupported dims / payload width"); return 1; }
+#undef BS_LAUNCH
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { l4d_set_error((int)le, "bs_scatter"); return (int)le; }
+  return 0;
+}

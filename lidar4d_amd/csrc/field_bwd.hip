@@ -17,6 +17,7 @@
 //      basis[f] * w_slice * H[entry], so only the scalar H is accumulated (int64), then expanded.
 #include "field_dev.h"
 #include "wave_dev.h"
+#include "binscatter.h"
 #include <algorithm>
 
 #define ST_GVS_MAX 0     // [0..8)  max |gvs| per plane scale
@@ -45,7 +46,7 @@ __device__ __forceinline__ void group_taps(const FieldDesc& fd, int s, const flo
 // ------------------------------------------------------------------------------------------------
 // 1. prep
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, float* __restrict__ g_hs, const float* __restrict__ xt,
+__global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
                                                             int64_t P, const half_t* __restrict__ dX, int in_pad, float pscale,
                                                             half_t* __restrict__ gvs, half_t* __restrict__ gdynT,
@@ -131,36 +132,7 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, float
   if (lane == 0 && gd_max > 0.0f) atomic_max_nonneg(stats + ST_GD_MAX, gd_max);
   int col = 2 * nS * C;
 
-  // ---- static 3-D hash: run-length pre-reduced scatter ----
-  {
-    const float xs[3] = {x0[0], x0[1], x0[2]};
-    for (int lvl = 0; lvl < fd.hs.n_levels; ++lvl) {
-      const half4_t h = *reinterpret_cast<const half4_t*>(row + col + lvl * 4);
-      float g[4];
-      bool any = false;
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        g[f] = valid ? h2f(h[f]) * pscale : 0.0f;
-        any |= g[f] != 0.0f;
-      }
-      if (!__any(any)) continue;  // wave-uniform
-      Cell<3> c = locate<3>(xs, fd.hs.scale[lvl]);
-      float* gt = g_hs + (size_t)fd.hs.offset[lvl] * 4;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        uint32_t gv[3];
-        const float w = corner<3>(c, k, gv);
-        const uint32_t idx = grid_index<3>(gv, fd.hs.res[lvl], fd.hs.size[lvl], (fd.hs.hashed_mask >> lvl) & 1u);
-        float vals[4] = {w * g[0], w * g[1], w * g[2], w * g[3]};
-        if (wave_run_reduce<4>(idx, any, vals)) {
-#pragma unroll
-          for (int f = 0; f < 4; ++f)
-            if (vals[f] != 0.0f) atomicAdd(gt + (size_t)idx * 4 + f, vals[f]);
-        }
-      }
-    }
-    col += fd.hs.n_levels * 4;
-  }
+  col += fd.hs.n_levels * 4;  // static 3-D hash columns: handled by the sorted scatter (binscatter.hip)
 
   // ---- dynamic hash: transposed upstream gradient (current frame only; neighbours are no_grad) ----
   {
@@ -194,14 +166,28 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, float
   }
 }
 
+// Lanes of a wave should not work on consecutive samples of one ray here: those hit the SAME texel, and same-address
+// LDS atomics serialise 64-way.  A stride permutation (i -> i * 769 mod n, 769 prime ~ samples per ray) makes the
+// lanes of a wave walk ~64 different rays instead; it is a bijection whenever gcd(769, n) = 1.
+__device__ __forceinline__ int64_t stride_perm(int64_t i, int64_t n, int64_t stride) { return (i * stride) % n; }
+static int64_t pick_stride(int64_t n) {
+  const int64_t cands[] = {769, 773, 761, 757, 751, 1};
+  for (int64_t c : cands) {
+    int64_t a = n, b = c;
+    while (b) { int64_t t = a % b; a = b; b = t; }
+    if (a == 1) return c;
+  }
+  return 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. time planes: all scales, all three frames, one pass; LDS window = 3 rows around t per plane
 // ------------------------------------------------------------------------------------------------
 #define TROWS 3
 __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
-                                                            int64_t P, int64_t chunk, const half_t* __restrict__ dX, int in_pad,
-                                                            float pscale, const float* __restrict__ stats) {
+                                                            int64_t P, int64_t chunk, int64_t stride, const half_t* __restrict__ dX,
+                                                            int in_pad, float pscale, const float* __restrict__ stats) {
   constexpr int C = 8;
   extern __shared__ int lds_i[];
   const int nS = fd.planes.n_scales;
@@ -209,29 +195,38 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
   const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
   const float c0 = 0.5f + (has_fwd ? 0.0f : 0.25f) + (has_bwd ? 0.0f : 0.25f);
   // LDS layout: [scale][time plane j][TROWS][W][C]; window start row per scale (time res is shared by x/y/z-t planes)
-  int lds_off[MAX_SCALES][3], r_lo[MAX_SCALES];
-  int total = 0;
-  for (int s = 0; s < nS; ++s) {
-    const int Ht = fd.planes.res[s][3];
-    int i0, i1;
-    float w0, w1, m;
-    axis_tap(t0, Ht, i0, i1, w0, w1, m);
-    int lo = i0;
-    if (has_fwd) { axis_tap(t1, Ht, i0, i1, w0, w1, m); lo = min(lo, i0); }
-    if (has_bwd) { axis_tap(t2, Ht, i0, i1, w0, w1, m); lo = min(lo, i0); }
-    r_lo[s] = lo;
-    for (int j = 0; j < 3; ++j) {
-      lds_off[s][j] = total;
-      total += TROWS * fd.planes.res[s][j] * C;  // time plane j pairs spatial axis j with t
+  __shared__ int lds_off_s[MAX_SCALES * 3], r_lo_s[MAX_SCALES], total_s;
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int s = 0; s < nS; ++s) {
+      const int Ht = fd.planes.res[s][3];
+      int i0, i1;
+      float w0, w1, m;
+      axis_tap(t0, Ht, i0, i1, w0, w1, m);
+      int lo = i0;
+      if (has_fwd) { axis_tap(t1, Ht, i0, i1, w0, w1, m); lo = min(lo, i0); }
+      if (has_bwd) { axis_tap(t2, Ht, i0, i1, w0, w1, m); lo = min(lo, i0); }
+      r_lo_s[s] = lo;
+      for (int j = 0; j < 3; ++j) {
+        lds_off_s[s * 3 + j] = tot;
+        tot += TROWS * fd.planes.res[s][j] * C;  // time plane j pairs spatial axis j with t
+      }
     }
+    total_s = tot;
   }
+  __syncthreads();
+  const int total = total_s;
+#define lds_off(s, j) lds_off_s[(s) * 3 + (j)]
+#define r_lo(s) r_lo_s[(s)]
   for (int i = threadIdx.x; i < total; i += blockDim.x) lds_i[i] = 0;
   __syncthreads();
   const float vmax = stats[ST_VMAX];
   const float fxs = fx_scale((float)chunk * stats[ST_GD_MAX] * vmax * vmax * 1.01f + 1e-30f, 30);
 
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {
+  for (int64_t ii = threadIdx.x; ii < chunk; ii += blockDim.x) {
+    const int64_t p = lo_p + stride_perm(ii, chunk, stride);
+    if (p >= hi_p) continue;
     const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
     float fl[8];
     {
@@ -271,9 +266,9 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
             if (gv == 0.0f) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const int rr = ys[q] - r_lo[s];
+              const int rr = ys[q] - r_lo(s);
               if (rr >= 0 && rr < TROWS) {
-                atomicAdd(&lds_i[lds_off[s][j] + (rr * W + xs_[q]) * C + k], __float2int_rn(gv * wts[q] * fxs));
+                atomicAdd(&lds_i[lds_off(s, j) + (rr * W + xs_[q]) * C + k], __float2int_rn(gv * wts[q] * fxs));
               } else {  // outside the LDS window (only for exotic num_frames / time_resolution): direct
                 atomicAdd(garena + fd.planes.off[s][cis[j]] + ((size_t)ys[q] * W + xs_[q]) * C + k, gv * wts[q] * pscale);
               }
@@ -294,8 +289,8 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
       float* g = garena + fd.planes.off[s][ci];
       for (int i = threadIdx.x; i < TROWS * W * C; i += blockDim.x) {
         const int rr = i / (W * C);
-        const int v = lds_i[lds_off[s][j] + i];
-        if (v != 0 && r_lo[s] + rr < Ht) atomicAdd(g + (size_t)(r_lo[s] + rr) * W * C + (i - rr * W * C), (float)v * inv);
+        const int v = lds_i[lds_off(s, j) + i];
+        if (v != 0 && r_lo(s) + rr < Ht) atomicAdd(g + (size_t)(r_lo(s) + rr) * W * C + (i - rr * W * C), (float)v * inv);
       }
       ++j;
     }
@@ -313,7 +308,7 @@ struct BandTasks {
 
 __global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, BandTasks tasks, float* __restrict__ garena,
                                                                const float* __restrict__ xt, int64_t P, int64_t chunk,
-                                                               const half_t* __restrict__ gvs, float pscale,
+                                                               int64_t stride, const half_t* __restrict__ gvs, float pscale,
                                                                const float* __restrict__ stats) {
   constexpr int C = 8;
   extern __shared__ int lds_i[];
@@ -329,7 +324,9 @@ __global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, Ba
   __syncthreads();
   const float fxs = fx_scale((float)chunk * stats[ST_GVS_MAX + s] * 1.01f + 1e-30f, 30);
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {
+  for (int64_t ii = threadIdx.x; ii < chunk; ii += blockDim.x) {
+    const int64_t p = lo_p + stride_perm(ii, chunk, stride);
+    if (p >= hi_p) continue;
     const float ca = xt[p * 4 + a], cb = xt[p * 4 + b];
     Tap t;
     axis_tap(cb, H, t.y0, t.y1, t.wy0, t.wy1, t.my);
@@ -372,7 +369,7 @@ struct HashTasks {
 };
 
 __global__ void __launch_bounds__(512) dynhash_lds_kernel(FieldDesc fd, HashTasks tasks, const float* __restrict__ xt, int64_t P,
-                                                         int64_t chunk, const half_t* __restrict__ gdynT,
+                                                         int64_t chunk, int64_t stride, const half_t* __restrict__ gdynT,
                                                          const float* __restrict__ stats, float* __restrict__ Hbuf) {
   extern __shared__ long long lds_l[];
   const int task = blockIdx.y;
@@ -391,7 +388,7 @@ __global__ void __launch_bounds__(512) dynhash_lds_kernel(FieldDesc fd, HashTask
   const bool hashed = (g.hashed_mask >> lvl) & 1u;
   const half_t* gcol = gdynT + (int64_t)cidx * P;
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {
+  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {  // hashed 2-D cells: no same-address pile-up
     const float go = h2f(gcol[p]);
     if (go == 0.0f) continue;
     const float q[2] = {xt[p * 4 + ca], xt[p * 4 + cb]};
@@ -443,7 +440,7 @@ __global__ void __launch_bounds__(256) dynhash_expand_kernel(FieldDesc fd, Field
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WorkLayout {
-  int64_t gvs, gdynT, stats, hbuf, total;
+  int64_t gvs, gdynT, stats, hbuf, bins, total;
   int64_t hbuf_floats;
 };
 static WorkLayout work_layout(const l4d_field_desc* f, int64_t P) {
@@ -457,7 +454,8 @@ static WorkLayout work_layout(const l4d_field_desc* f, int64_t P) {
   w.hbuf = align256(ST_SIZE * 4);
   w.gvs = w.hbuf + align256(hb * 4);
   w.gdynT = w.gvs + align256(P * f->n_scales * 3 * 8 * 2);
-  w.total = w.gdynT + align256(L3 * P * 2);
+  w.bins = w.gdynT + align256(L3 * P * 2);
+  w.total = w.bins + align256(bs_plan(make_grid_desc(&f->hash_static), 3, 4, P).bytes);
   return w;
 }
 
@@ -487,13 +485,22 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   if (e == hipSuccess) e = hipMemcpyAsync(stats + ST_VMAX, plane_abs_max, sizeof(float), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
 
-  hipLaunchKernelGGL(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, stream, d, fg.hs_table, xt,
+  hipLaunchKernelGGL(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, stream, d, xt,
                      (const half_t*)flow16, tinfo, P, (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, (half_t*)dflow16);
+
+  // static 3-D hash grid: sorted scatter of dX[:, 2*nS*8 + lvl*4 ..] (binscatter.hip)
+  {
+    const int cols3[3] = {0, 1, 2};
+    int rc = bs_scatter(d.hs, 3, 4, xt, P, 4, cols3, (const half_t*)dX, in_pad, 2 * d.planes.n_scales * 8, 1.0f, fg.hs_table,
+                        param_scale, ws + w.bins, stream);
+    if (rc) return rc;
+  }
 
   // chunking: one chunk per workgroup column; few enough chunks that the flush traffic stays small
   int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, 8192)));
   const int64_t chunk = ceil_div64(P, n_chunks);
   n_chunks = (int)ceil_div64(P, chunk);
+  const int64_t stride = pick_stride(chunk);
 
   // time planes
   {
@@ -503,7 +510,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
     hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
-                       tinfo, P, chunk, (const half_t*)dX, in_pad, param_scale, stats);
+                       tinfo, P, chunk, stride, (const half_t*)dX, in_pad, param_scale, stats);
   }
   // static planes
   {
@@ -525,7 +532,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       }
     hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     hipLaunchKernelGGL(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(512), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
-                       gvs, param_scale, stats);
+                       stride, gvs, param_scale, stats);
   }
   // dynamic hash
   {
@@ -547,7 +554,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
     hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(512), 128 * 1024, stream, d, t, xt, P, chunk, gdynT, stats, Hbuf);
+    hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(512), 128 * 1024, stream, d, t, xt, P, chunk, (int64_t)1, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);

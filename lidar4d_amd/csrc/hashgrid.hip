@@ -10,6 +10,7 @@
 
 #include "hashgrid_dev.h"
 #include "wave_dev.h"
+#include "binscatter.h"
 
 struct Cols {
   int c[3];
@@ -296,10 +297,14 @@ extern "C" int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc, const float* x, int
   return 0;
 }
 
+extern "C" int64_t l4d_hashgrid_t_bwd_workspace(const l4d_grid_desc* desc, int64_t P) {
+  return bs_plan(make_grid_desc(desc), desc->n_dims, desc->n_features / 4, P).bytes;
+}
+
 extern "C" int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride,
                                   const int32_t* cols, int32_t n_slices, const float* t, const void* dout,
                                   int32_t dout_stride, int32_t dout_is_half, float grad_scale,
-                                  float* const* grad_tables, float* scratch, void* stream) {
+                                  float* const* grad_tables, float* scratch, void* workspace, void* stream) {
   if (P == 0) return 0;
   if (check_t(desc, n_slices)) return 1;
   GridDesc g = make_grid_desc(desc);
@@ -311,12 +316,20 @@ extern "C" int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc, const float* x, int
   const int FO = desc->n_features / 4;
   hipError_t e = hipMemsetAsync(scratch, 0, (size_t)n_entries * FO * sizeof(float), (hipStream_t)stream);
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_hashgrid_t_bwd memset"); return (int)e; }
-  dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels), block(256);
+  dim3 block(256);
+  if (workspace && dout_is_half) {
+    // sorted scatter (binscatter.hip): no scattered global atomics on the hashed levels
+    int rc = bs_scatter(g, desc->n_dims, FO, x, P, x_stride, cols, (const half_t*)dout, dout_stride, 0, 1.0f, scratch, grad_scale,
+                        workspace, (hipStream_t)stream);
+    if (rc) return rc;
+  } else {
+    dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels);
 #define CALL(D, F, B)                                                                                                \
   hipLaunchKernelGGL((hashgrid_t_bwd_kernel<D, F, B>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c,    \
                      dout, dout_stride, grad_scale, scratch);
-  DISPATCH_T(desc->n_dims, desc->n_features, dout_is_half, CALL)
+    DISPATCH_T(desc->n_dims, desc->n_features, dout_is_half, CALL)
 #undef CALL
+  }
   dim3 egrid((unsigned)ceil_div64(n_entries, 256));
   if (desc->n_features == 4)
     hipLaunchKernelGGL((hashgrid_t_expand_kernel<4>), egrid, block, 0, (hipStream_t)stream, n_entries, n_slices, t, scratch, gr);

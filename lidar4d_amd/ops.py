@@ -14,6 +14,9 @@ def call(name, *args):
     _lib.call(name, *args)
 
 
+BINNED_SCATTER_MIN_RECORDS = 1 << 16  # below this the global-atomic path is cheaper than two extra launches
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -94,9 +97,12 @@ def hashgrid_t_bwd(meta, x, cols, n_slices, t_dev, dout, grad_tables, grad_scale
     _chk(x, torch.float32, "x"), _chk(dout, None, "dout")
     d = meta.desc()
     scratch = torch.empty(meta.n_entries * (meta.n_features // 4), dtype=torch.float32, device=x.device)
+    ws = None
+    if dout.dtype == torch.float16 and x.shape[0] * (1 << meta.n_dims) >= BINNED_SCATTER_MIN_RECORDS:
+        ws = torch.empty(_lib.lib().l4d_hashgrid_t_bwd_workspace(C.byref(d), x.shape[0]), dtype=torch.uint8, device=x.device)
     call("l4d_hashgrid_t_bwd", C.byref(d), _p(x), x.shape[0], x.stride(0), _i32s(list(cols)), n_slices, _p(t_dev),
          C.c_void_p(dout.data_ptr() + dout.element_size() * dout_col), dout.stride(0), int(dout.dtype == torch.float16),
-         float(grad_scale), _ptrs(grad_tables), _p(scratch), _stream())
+         float(grad_scale), _ptrs(grad_tables), _p(scratch), _p(ws), _stream())
 
 
 # ---- planes ----------------------------------------------------------------------------------------
