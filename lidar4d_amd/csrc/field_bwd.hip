@@ -114,7 +114,21 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
       if (!(e == 1 ? has_fwd : has_bwd)) continue;
       const float* xe = e == 1 ? x1 : x2;
       float* ge = e == 1 ? g1 : g2;
-      group_taps<C>(fd, s, xe, true, taps, v, cis);
+      TapVals<C> tv[3];
+      {
+        int n = 0;
+#pragma unroll
+        for (int ci = 0; ci < NPLANES; ++ci) {
+          const int a = COMB_A[ci], b = COMB_B[ci];
+          if (b != 3) continue;
+          const int W = fd.planes.res[s][a], H = fd.planes.res[s][b];
+          axis_tap(xe[a], W, taps[n].x0, taps[n].x1, taps[n].wx0, taps[n].wx1, taps[n].mx);
+          axis_tap(xe[b], H, taps[n].y0, taps[n].y1, taps[n].wy0, taps[n].wy1, taps[n].my);
+          load_taps<C>(fd.planes_cl + fd.planes.off[s][ci], W, taps[n], tv[n], v[n]);
+          cis[n] = ci;
+          ++n;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float gv[C];
@@ -122,7 +136,7 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
         for (int k = 0; k < C; ++k) gv[k] = 0.25f * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
         float gix = 0.0f, giy = 0.0f;
         const int ci = cis[j];
-        plane_coord_grad<C>(fd.planes_cl + fd.planes.off[s][ci], fd.planes.res[s][COMB_A[ci]], taps[j], gv, gix, giy);
+        coord_grad_from_taps<C>(tv[j], taps[j], gv, gix, giy);
         ge[COMB_A[ci]] += gix * taps[j].mx;
         ge[COMB_B[ci]] += giy * taps[j].my;
       }
@@ -223,10 +237,14 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
   const float vmax = stats[ST_VMAX];
   const float fxs = fx_scale((float)chunk * stats[ST_GD_MAX] * vmax * vmax * 1.01f + 1e-30f, 30);
 
+  // consecutive lanes = consecutive samples of a ray: the plane gathers stay coherent, and the equal-texel runs this
+  // creates are merged in registers (wave_run_reduce) before they reach the LDS atomics
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  for (int64_t ii = threadIdx.x; ii < chunk; ii += blockDim.x) {
-    const int64_t p = lo_p + stride_perm(ii, chunk, stride);
-    if (p >= hi_p) continue;
+  const int64_t n_iter = (chunk + blockDim.x - 1) / blockDim.x;
+  for (int64_t it = 0; it < n_iter; ++it) {
+    const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
+    const bool active = pr < hi_p;
+    const int64_t p = active ? pr : hi_p - 1;
     const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
     float fl[8];
     {
@@ -242,7 +260,7 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
         uint4 u = *reinterpret_cast<const uint4*>(row + (nS + s) * C);
         const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
-        for (int k = 0; k < C; ++k) gd[k] = h2f(h[k]);
+        for (int k = 0; k < C; ++k) gd[k] = active ? h2f(h[k]) : 0.0f;
       }
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
@@ -260,18 +278,28 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
           const int W = fd.planes.res[s][j];
           const float wts[4] = {t.wx0 * t.wy0, t.wx1 * t.wy0, t.wx0 * t.wy1, t.wx1 * t.wy1};
           const int ys[4] = {t.y0, t.y0, t.y1, t.y1}, xs_[4] = {t.x0, t.x1, t.x0, t.x1};
+          float gv[C];
 #pragma unroll
-          for (int k = 0; k < C; ++k) {
-            const float gv = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
-            if (gv == 0.0f) continue;
+          for (int k = 0; k < C; ++k) gv[k] = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int rr = ys[q] - r_lo(s);
-              if (rr >= 0 && rr < TROWS) {
-                atomicAdd(&lds_i[lds_off(s, j) + (rr * W + xs_[q]) * C + k], __float2int_rn(gv * wts[q] * fxs));
-              } else {  // outside the LDS window (only for exotic num_frames / time_resolution): direct
-                atomicAdd(garena + fd.planes.off[s][cis[j]] + ((size_t)ys[q] * W + xs_[q]) * C + k, gv * wts[q] * pscale);
-              }
+          for (int q = 0; q < 4; ++q) {
+            const int rr = ys[q] - r_lo(s);
+            const bool in_win = rr >= 0 && rr < TROWS;
+            const uint32_t key = (uint32_t)(ys[q] * W + xs_[q]);
+            float vals[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) vals[k] = gv[k] * wts[q];
+            if (!wave_run_reduce<C>(key, active && wts[q] != 0.0f, vals)) continue;
+            if (in_win) {
+              int* dst = &lds_i[lds_off(s, j) + (rr * W + xs_[q]) * C];
+#pragma unroll
+              for (int k = 0; k < C; ++k)
+                if (vals[k] != 0.0f) atomicAdd(dst + k, __float2int_rn(vals[k] * fxs));
+            } else {  // outside the LDS window (only for exotic num_frames / time_resolution): direct
+              float* dst = garena + fd.planes.off[s][cis[j]] + ((size_t)ys[q] * W + xs_[q]) * C;
+#pragma unroll
+              for (int k = 0; k < C; ++k)
+                if (vals[k] != 0.0f) atomicAdd(dst + k, vals[k] * pscale);
             }
           }
         }
@@ -324,29 +352,38 @@ __global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, Ba
   __syncthreads();
   const float fxs = fx_scale((float)chunk * stats[ST_GVS_MAX + s] * 1.01f + 1e-30f, 30);
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  for (int64_t ii = threadIdx.x; ii < chunk; ii += blockDim.x) {
-    const int64_t p = lo_p + stride_perm(ii, chunk, stride);
-    if (p >= hi_p) continue;
+  const int64_t n_iter = (chunk + blockDim.x - 1) / blockDim.x;
+  for (int64_t it = 0; it < n_iter; ++it) {
+    const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
+    const bool active = pr < hi_p;
+    const int64_t p = active ? pr : hi_p - 1;
     const float ca = xt[p * 4 + a], cb = xt[p * 4 + b];
     Tap t;
     axis_tap(cb, H, t.y0, t.y1, t.wy0, t.wy1, t.my);
-    const bool in0 = t.y0 >= row0 && t.y0 < row0 + nrows, in1 = t.y1 >= row0 && t.y1 < row0 + nrows && t.y1 != t.y0;
-    if (!in0 && !in1) continue;
+    const bool in0 = active && t.y0 >= row0 && t.y0 < row0 + nrows;
+    const bool in1 = active && t.y1 >= row0 && t.y1 < row0 + nrows && t.y1 != t.y0;
+    if (!__any(in0 || in1)) continue;  // wave-uniform
     axis_tap(ca, W, t.x0, t.x1, t.wx0, t.wx1, t.mx);
-    const uint4 u = *reinterpret_cast<const uint4*>(gvs + ((p * nS + s) * 3 + j) * C);
-    const half_t* h = reinterpret_cast<const half_t*>(&u);
+    float gv[C];
+    {
+      const uint4 u = *reinterpret_cast<const uint4*>(gvs + ((p * nS + s) * 3 + j) * C);
+      const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
-    for (int k = 0; k < C; ++k) {
-      const float gv = h2f(h[k]) * fxs;
-      if (gv == 0.0f) continue;
-      if (in0) {
-        atomicAdd(&lds_i[((t.y0 - row0) * W + t.x0) * C + k], __float2int_rn(gv * (t.wx0 * t.wy0)));
-        atomicAdd(&lds_i[((t.y0 - row0) * W + t.x1) * C + k], __float2int_rn(gv * (t.wx1 * t.wy0)));
-      }
-      if (in1) {
-        atomicAdd(&lds_i[((t.y1 - row0) * W + t.x0) * C + k], __float2int_rn(gv * (t.wx0 * t.wy1)));
-        atomicAdd(&lds_i[((t.y1 - row0) * W + t.x1) * C + k], __float2int_rn(gv * (t.wx1 * t.wy1)));
-      }
+      for (int k = 0; k < C; ++k) gv[k] = h2f(h[k]);
+    }
+    const float wts[4] = {t.wx0 * t.wy0, t.wx1 * t.wy0, t.wx0 * t.wy1, t.wx1 * t.wy1};
+    const int ys[4] = {t.y0, t.y0, t.y1, t.y1}, xs_[4] = {t.x0, t.x1, t.x0, t.x1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool in = q < 2 ? in0 : in1;
+      float vals[C];
+#pragma unroll
+      for (int k = 0; k < C; ++k) vals[k] = gv[k] * wts[q];
+      if (!wave_run_reduce<C>((uint32_t)(ys[q] * W + xs_[q]), in && wts[q] != 0.0f, vals)) continue;
+      int* dst = &lds_i[((ys[q] - row0) * W + xs_[q]) * C];
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+        if (vals[k] != 0.0f) atomicAdd(dst + k, __float2int_rn(vals[k] * fxs));
     }
   }
   __syncthreads();

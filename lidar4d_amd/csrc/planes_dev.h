@@ -108,3 +108,42 @@ __device__ __forceinline__ void plane_coord_grad(const float* __restrict__ base,
     giy += v11 * t.wx1 * g;
   }
 }
+
+// Bilinear sample that also returns d(sample . gv)/d(ix), d/d(iy) pieces: loads the four taps ONCE (8 x 16 B) and
+// gives the interpolated value; call coord_grad_from_taps afterwards with the same tap registers.
+template <int C>
+struct TapVals {
+  float v00[C], v01[C], v10[C], v11[C];
+};
+template <int C>
+__device__ __forceinline__ void load_taps(const float* __restrict__ base, int W, const Tap& t, TapVals<C>& tv, float out[C]) {
+  const float nw = t.wx0 * t.wy0, ne = t.wx1 * t.wy0, sw = t.wx0 * t.wy1, se = t.wx1 * t.wy1;
+  const float4_t* p00 = reinterpret_cast<const float4_t*>(base + ((size_t)t.y0 * W + t.x0) * C);
+  const float4_t* p01 = reinterpret_cast<const float4_t*>(base + ((size_t)t.y0 * W + t.x1) * C);
+  const float4_t* p10 = reinterpret_cast<const float4_t*>(base + ((size_t)t.y1 * W + t.x0) * C);
+  const float4_t* p11 = reinterpret_cast<const float4_t*>(base + ((size_t)t.y1 * W + t.x1) * C);
+#pragma unroll
+  for (int q = 0; q < C / 4; ++q) {
+    const float4_t a = p00[q], b = p01[q], c = p10[q], d = p11[q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tv.v00[q * 4 + j] = a[j]; tv.v01[q * 4 + j] = b[j]; tv.v10[q * 4 + j] = c[j]; tv.v11[q * 4 + j] = d[j];
+      out[q * 4 + j] = ((a[j] * nw + b[j] * ne) + c[j] * sw) + d[j] * se;
+    }
+  }
+}
+template <int C>
+__device__ __forceinline__ void coord_grad_from_taps(const TapVals<C>& tv, const Tap& t, const float gv[C], float& gix, float& giy) {
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const float g = gv[k];
+    gix -= tv.v00[k] * t.wy0 * g;
+    giy -= tv.v00[k] * t.wx0 * g;
+    gix += tv.v01[k] * t.wy0 * g;
+    giy -= tv.v01[k] * t.wx1 * g;
+    gix -= tv.v10[k] * t.wy1 * g;
+    giy += tv.v10[k] * t.wx0 * g;
+    gix += tv.v11[k] * t.wy1 * g;
+    giy += tv.v11[k] * t.wx1 * g;
+  }
+}
