@@ -7,11 +7,10 @@ struct BsCols {
 };
 
 struct BsPlan {
-  int shift;           // bin = entry >> shift
-  int bins_per_level;  // storage stride (max bins of any level, <= 128)
-  int rec_words;       // dwords per record
-  int64_t cap;         // records per bin
-  int64_t off_cursor, off_max, off_bins, bytes;
+  int shift;      // bin = entry >> shift
+  int rec_words;  // dwords per record
+  int64_t n_wg;   // pass-1 workgroups per level; each owns a fixed slot of 256 * 2^D records + 129 bin offsets
+  int64_t off_max, off_offs, off_bins, bytes;
 };
 
 BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P);

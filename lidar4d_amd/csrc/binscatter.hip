@@ -5,14 +5,15 @@
 // not fit LDS, so contributions are first *binned* by table segment and then reduced segment by segment in LDS:
 //
 //   pass 1  (one thread per (sample, level)): the 2^D corner contributions {entry, w * g[0..NV)} (fp16 payload) are
-//           partitioned inside the workgroup by bin = entry >> shift (LDS histogram + ranks), bin space is reserved
-//           with ONE global atomic per (workgroup, bin), and each bin's records go out as a contiguous run.
-//           Coarse levels first merge runs of equal entries along the ray (wave_run_reduce).
-//   pass 2  (one workgroup per (level, bin)): streams the bin's records, accumulates them in LDS as int64 fixed
-//           point (ds_add_u64: 2.9 T lane-ops/s, exact and order independent), and adds the segment to the fp32
-//           gradient table with plain stores -- each segment has exactly one owner, no global atomics at all.
+//           partitioned inside the workgroup by bin = entry >> shift (LDS histogram + ranks) and written, sorted by
+//           bin, into the workgroup's own fixed slot of the record buffer together with its bin offsets -- no global
+//           atomics, no overflow, deterministic layout.  Coarse levels first merge runs of equal entries along the
+//           ray (wave_run_reduce).
+//   pass 2  (one workgroup per (level, bin)): walks every pass-1 workgroup's run for its bin (16 lanes per run),
+//           accumulates in LDS as int64 fixed point (ds_add_u64: 2.9 T lane-ops/s, exact and order independent), and
+//           adds the segment to the fp32 gradient table with plain stores -- each segment has exactly one owner.
 //
-// Non-hashed (dense, coarse) levels and bin overflow fall back to run-reduced global atomics.
+// Non-hashed (dense, coarse) levels fall back to run-reduced global atomics.
 #include <algorithm>
 
 #include "hashgrid_dev.h"
@@ -28,14 +29,13 @@ struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed
 template <int D, int NV>
 __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
                                                               BsCols cols, const half_t* __restrict__ g, int g_stride, int g_col,
-                                                              float pre_scale, int shift, int bpl, int64_t cap,
-                                                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ bins,
+                                                              float pre_scale, int shift,
+                                                              uint16_t* __restrict__ offs, uint32_t* __restrict__ bins,
                                                               float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
   constexpr int NW = RecWords<NV>::n;
-  __shared__ uint32_t hist[BS_MAX_BINS], boff[BS_MAX_BINS], bbase[BS_MAX_BINS];
+  __shared__ uint32_t hist[BS_MAX_BINS], boff[BS_MAX_BINS + 1];
   __shared__ uint32_t stage[BS_THREADS * NC * NW];
-  __shared__ uint8_t rbin[BS_THREADS * NC];
   __shared__ uint32_t total_s;
   const int lvl = blockIdx.y;
   const int lane = __lane_id();
@@ -101,7 +101,8 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
 #pragma unroll
   for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[keys[k] >> shift], 1u) : 0u;
   __syncthreads();
-  if (threadIdx.x < 64) {  // exclusive scan of <= 128 bins by one wave, global reservation per bin
+  const uint64_t wg_slot = (uint64_t)lvl * gridDim.x + blockIdx.x;
+  if (threadIdx.x < 64) {  // exclusive scan of <= 128 bins by one wave
     uint32_t c0 = lane < nbins ? hist[lane] : 0u, c1 = lane + 64 < nbins ? hist[lane + 64] : 0u;
     uint32_t inc0 = c0, inc1 = c1;
 #pragma unroll
@@ -110,15 +111,16 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
       if (lane >= d) { inc0 += a; inc1 += b; }
     }
     const uint32_t tot0 = __shfl(inc0, 63, 64);
-    if (lane < nbins) {
-      boff[lane] = inc0 - c0;
-      bbase[lane] = c0 ? atomicAdd(&cursor[lvl * BS_MAX_BINS + lane], c0) : 0u;
+    uint16_t* o = offs + wg_slot * (BS_MAX_BINS + 1);
+    boff[lane] = inc0 - c0;
+    boff[lane + 64] = tot0 + inc1 - c1;
+    o[lane] = (uint16_t)(inc0 - c0);
+    o[lane + 64] = (uint16_t)(tot0 + inc1 - c1);
+    if (lane == 63) {
+      total_s = tot0 + inc1;
+      boff[BS_MAX_BINS] = tot0 + inc1;
+      o[BS_MAX_BINS] = (uint16_t)(tot0 + inc1);
     }
-    if (lane + 64 < nbins) {
-      boff[lane + 64] = tot0 + inc1 - c1;
-      bbase[lane + 64] = c1 ? atomicAdd(&cursor[lvl * BS_MAX_BINS + lane + 64], c1) : 0u;
-    }
-    if (lane == 63) total_s = tot0 + inc1;
   }
   __syncthreads();
 #pragma unroll
@@ -126,7 +128,6 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
     if (emit[k]) {
       const uint32_t b = keys[k] >> shift;
       const uint32_t r = boff[b] + pos[k];
-      rbin[r] = (uint8_t)b;
       stage[r * NW] = keys[k];
       half_t hv[2 * (NW - 1)];
 #pragma unroll
@@ -136,26 +137,15 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
     }
   __syncthreads();
   const uint32_t total = total_s;
-  for (uint32_t dw = threadIdx.x; dw < total * NW; dw += blockDim.x) {
-    const uint32_t r = dw / NW, wq = dw - r * NW;
-    const uint32_t b = rbin[r];
-    const uint64_t slot = (uint64_t)bbase[b] + (r - boff[b]);
-    if (slot < (uint64_t)cap) {
-      bins[(((uint64_t)lvl * bpl + b) * cap + slot) * NW + wq] = stage[dw];
-    } else if (wq == 0) {  // bin overflow (never with hashed keys and the default slack): direct atomics
-      const uint32_t key = stage[r * NW];
-      const half_t* hv = reinterpret_cast<const half_t*>(&stage[r * NW + 1]);
-      float* o = out + ((size_t)desc.offset[lvl] + key) * NV;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) atomicAdd(o + j, h2f(hv[j]) * out_scale);
-    }
-  }
+  uint32_t* dst = bins + wg_slot * (uint64_t)(BS_THREADS * NC * NW);
+  for (uint32_t dw = threadIdx.x; dw < total * NW; dw += blockDim.x) dst[dw] = stage[dw];  // already sorted by bin
 }
 
-template <int NV>
-__global__ void __launch_bounds__(512) bin_pass2_kernel(GridDesc desc, int shift, int bpl, int64_t cap, int64_t P,
-                                                       const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ bins,
+template <int D, int NV>
+__global__ void __launch_bounds__(512) bin_pass2_kernel(GridDesc desc, int shift, int n_wg, int64_t P,
+                                                       const uint16_t* __restrict__ offs, const uint32_t* __restrict__ bins,
                                                        const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
+  constexpr int NC = 1 << D;
   constexpr int NW = RecWords<NV>::n;
   extern __shared__ long long acc[];
   const int lvl = blockIdx.y, b = blockIdx.x;
@@ -163,24 +153,30 @@ __global__ void __launch_bounds__(512) bin_pass2_kernel(GridDesc desc, int shift
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   const int nbins = (int)((size + (1u << shift) - 1) >> shift);
   if (!hashed || nbins > BS_MAX_BINS || nbins <= 1 || b >= nbins) return;
-  const uint32_t n = (uint32_t)min((int64_t)cursor[lvl * BS_MAX_BINS + b], cap);
-  if (n == 0) return;
+  const float gmax = lvl_max[lvl];
+  if (!(gmax > 0.0f)) return;
   const uint32_t lo = (uint32_t)b << shift;
   const int n_el = (int)min(1u << shift, size - lo) * NV;
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) acc[i] = 0;
   __syncthreads();
-  const float fxs = fx_scale((float)P * lvl_max[lvl] * 1.01f + 1e-30f, 61);
-  const uint32_t* rec = bins + ((uint64_t)lvl * bpl + b) * cap * NW;
-  for (uint32_t r = threadIdx.x; r < n; r += blockDim.x) {
-    const uint32_t key = rec[(uint64_t)r * NW] - lo;
-    uint32_t w[NW - 1];
+  const float fxs = fx_scale((float)P * gmax * 1.01f, 61);
+  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;  // 32 groups of 16 lanes, one pass-1 workgroup's run each
+  for (int w = grp; w < n_wg; w += 32) {
+    const uint64_t slot = (uint64_t)lvl * n_wg + w;
+    const uint16_t* o = offs + slot * (BS_MAX_BINS + 1);
+    const uint32_t s0 = o[b], s1 = o[b + 1];
+    const uint32_t* rec = bins + slot * (uint64_t)(BS_THREADS * NC * NW);
+    for (uint32_t r = s0 + l16; r < s1; r += 16) {
+      const uint32_t key = rec[r * NW] - lo;
+      uint32_t wd[NW - 1];
 #pragma unroll
-    for (int q = 0; q < NW - 1; ++q) w[q] = rec[(uint64_t)r * NW + 1 + q];
-    const half_t* hv = reinterpret_cast<const half_t*>(w);
+      for (int q = 0; q < NW - 1; ++q) wd[q] = rec[r * NW + 1 + q];
+      const half_t* hv = reinterpret_cast<const half_t*>(wd);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const float v = h2f(hv[j]);
-      if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[key * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
+      for (int j = 0; j < NV; ++j) {
+        const float v = h2f(hv[j]);
+        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[key * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
+      }
     }
   }
   __syncthreads();
@@ -199,16 +195,12 @@ BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
   BsPlan pl;
   pl.shift = bs_shift(NV);
   pl.rec_words = 1 + (NV + 1) / 2;
-  int64_t max_bins = 1;
-  for (int l = 0; l < d.n_levels; ++l) max_bins = std::max<int64_t>(max_bins, ((int64_t)d.size[l] + (1 << pl.shift) - 1) >> pl.shift);
-  max_bins = std::min<int64_t>(max_bins, BS_MAX_BINS);
-  const int64_t corners = 1 << n_dims;
-  pl.bins_per_level = (int)max_bins;
-  pl.cap = (P * corners + max_bins - 1) / max_bins * 3 / 2 + 4096;  // 50 % slack over the uniform share + headroom
-  pl.off_cursor = 0;
-  pl.off_max = (int64_t)d.n_levels * BS_MAX_BINS * 4;
-  pl.off_bins = (pl.off_max + 64 * 4 + 255) / 256 * 256;
-  pl.bytes = pl.off_bins + (int64_t)d.n_levels * max_bins * pl.cap * pl.rec_words * 4;
+  pl.n_wg = ceil_div64(P, BS_THREADS);
+  const int64_t rec_per_wg = (int64_t)BS_THREADS << n_dims;
+  pl.off_max = 0;
+  pl.off_offs = 256;
+  pl.off_bins = (pl.off_offs + (int64_t)d.n_levels * pl.n_wg * (BS_MAX_BINS + 1) * 2 + 255) / 256 * 256;
+  pl.bytes = pl.off_bins + (int64_t)d.n_levels * pl.n_wg * rec_per_wg * pl.rec_words * 4;
   return pl;
 }
 
@@ -217,22 +209,25 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   if (P == 0) return 0;
   const BsPlan pl = bs_plan(desc, n_dims, NV, P);
   char* ws = (char*)workspace;
-  uint32_t* cursor = (uint32_t*)(ws + pl.off_cursor);
   float* lvl_max = (float*)(ws + pl.off_max);
+  uint16_t* offs = (uint16_t*)(ws + pl.off_offs);
   uint32_t* bins = (uint32_t*)(ws + pl.off_bins);
-  hipError_t e = hipMemsetAsync(ws, 0, pl.off_bins, stream);
+  hipError_t e = hipMemsetAsync(ws, 0, 256, stream);
   if (e != hipSuccess) { l4d_set_error((int)e, "bs_scatter memset"); return (int)e; }
   BsCols c;
   for (int d = 0; d < 3; ++d) c.c[d] = d < n_dims ? cols[d] : 0;
-  dim3 grid1((unsigned)ceil_div64(P, BS_THREADS), desc.n_levels);
-  dim3 grid2(pl.bins_per_level, desc.n_levels);
+  int max_bins = 1;
+  for (int l = 0; l < desc.n_levels; ++l) max_bins = std::max<int>(max_bins, (int)(((int64_t)desc.size[l] + (1 << pl.shift) - 1) >> pl.shift));
+  max_bins = std::min(max_bins, BS_MAX_BINS);
+  dim3 grid1((unsigned)pl.n_wg, desc.n_levels);
+  dim3 grid2(max_bins, desc.n_levels);
   const int lds2 = (1 << pl.shift) * NV * 8;
 #define BS_LAUNCH(D, V)                                                                                                      \
   {                                                                                                                          \
     hipLaunchKernelGGL((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
-                       g_col, pre_scale, pl.shift, pl.bins_per_level, pl.cap, cursor, bins, lvl_max, out, out_scale);                          \
-    hipFuncSetAttribute((const void*)bin_pass2_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);                 \
-    hipLaunchKernelGGL((bin_pass2_kernel<V>), grid2, dim3(512), lds2, stream, desc, pl.shift, pl.bins_per_level, pl.cap, P, cursor, bins,       \
+                       g_col, pre_scale, pl.shift, offs, bins, lvl_max, out, out_scale);                                     \
+    hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);              \
+    hipLaunchKernelGGL((bin_pass2_kernel<D, V>), grid2, dim3(512), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
                        lvl_max, out, out_scale);                                                                            \
   }
   if (n_dims == 3 && NV == 4) BS_LAUNCH(3, 4)

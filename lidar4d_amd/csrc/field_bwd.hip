@@ -26,20 +26,24 @@
 #define ST_DYN_MAX 16    // [16 .. 16 + 3L) max |gdynT| per column
 #define ST_SIZE 80
 
+// planes of a group in comb order: static (0,1)(0,2)(1,2) = ci 0,1,3; time (0,3)(1,3)(2,3) = ci 2,4,5
+__device__ __forceinline__ constexpr int group_ci(bool time_group, int j) {
+  return time_group ? (j == 0 ? 2 : j == 1 ? 4 : 5) : (j == 0 ? 0 : j == 1 ? 1 : 3);
+}
+
 template <int C>
 __device__ __forceinline__ void group_taps(const FieldDesc& fd, int s, const float coord[4], bool time_group, Tap taps[3],
                                            float v[3][C], int cis[3]) {
-  int n = 0;
 #pragma unroll
-  for (int ci = 0; ci < NPLANES; ++ci) {
-    const int a = COMB_A[ci], b = COMB_B[ci];
-    if ((b == 3) != time_group) continue;
+  for (int j = 0; j < 3; ++j) {  // j is a compile-time constant after unrolling: taps/v stay in registers
+    const int ci = time_group ? (j == 0 ? 2 : j == 1 ? 4 : 5) : (j == 0 ? 0 : j == 1 ? 1 : 3);
+    const int a = time_group ? j : (j == 2 ? 1 : 0);
+    const int b = time_group ? 3 : (j == 0 ? 1 : 2);
     const int W = fd.planes.res[s][a], H = fd.planes.res[s][b];
-    axis_tap(coord[a], W, taps[n].x0, taps[n].x1, taps[n].wx0, taps[n].wx1, taps[n].mx);
-    axis_tap(coord[b], H, taps[n].y0, taps[n].y1, taps[n].wy0, taps[n].wy1, taps[n].my);
-    sample_plane<C>(fd.planes_cl + fd.planes.off[s][ci], W, taps[n], v[n]);
-    cis[n] = ci;
-    ++n;
+    axis_tap(coord[a], W, taps[j].x0, taps[j].x1, taps[j].wx0, taps[j].wx1, taps[j].mx);
+    axis_tap(coord[b], H, taps[j].y0, taps[j].y1, taps[j].wy0, taps[j].wy1, taps[j].my);
+    sample_plane<C>(fd.planes_cl + fd.planes.off[s][ci], W, taps[j], v[j]);
+    cis[j] = ci;
   }
 }
 
@@ -114,21 +118,7 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
       if (!(e == 1 ? has_fwd : has_bwd)) continue;
       const float* xe = e == 1 ? x1 : x2;
       float* ge = e == 1 ? g1 : g2;
-      TapVals<C> tv[3];
-      {
-        int n = 0;
-#pragma unroll
-        for (int ci = 0; ci < NPLANES; ++ci) {
-          const int a = COMB_A[ci], b = COMB_B[ci];
-          if (b != 3) continue;
-          const int W = fd.planes.res[s][a], H = fd.planes.res[s][b];
-          axis_tap(xe[a], W, taps[n].x0, taps[n].x1, taps[n].wx0, taps[n].wx1, taps[n].mx);
-          axis_tap(xe[b], H, taps[n].y0, taps[n].y1, taps[n].wy0, taps[n].wy1, taps[n].my);
-          load_taps<C>(fd.planes_cl + fd.planes.off[s][ci], W, taps[n], tv[n], v[n]);
-          cis[n] = ci;
-          ++n;
-        }
-      }
+      group_taps<C>(fd, s, xe, true, taps, v, cis);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float gv[C];
@@ -136,7 +126,11 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
         for (int k = 0; k < C; ++k) gv[k] = 0.25f * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
         float gix = 0.0f, giy = 0.0f;
         const int ci = cis[j];
-        coord_grad_from_taps<C>(tv[j], taps[j], gv, gix, giy);
+        // the four taps are re-read (L1 hits) as 8 vector loads rather than kept live across the product rule
+        TapVals<C> tv;
+        float dummy[C];
+        load_taps<C>(fd.planes_cl + fd.planes.off[s][ci], fd.planes.res[s][COMB_A[ci]], taps[j], tv, dummy);
+        coord_grad_from_taps<C>(tv, taps[j], gv, gix, giy);
         ge[COMB_A[ci]] += gix * taps[j].mx;
         ge[COMB_B[ci]] += giy * taps[j].my;
       }

@@ -23,11 +23,11 @@ __global__ void time_setup_kernel(const float* __restrict__ t, int num_frames, f
 
 template <int C>
 __device__ __forceinline__ void planes_group(const FieldDesc& fd, int s, const float coord[4], bool time_group, float out[C]) {
-  bool first = true;
 #pragma unroll
-  for (int ci = 0; ci < NPLANES; ++ci) {
-    const int a = COMB_A[ci], b = COMB_B[ci];
-    if ((b == 3) != time_group) continue;
+  for (int j = 0; j < 3; ++j) {
+    const int ci = time_group ? (j == 0 ? 2 : j == 1 ? 4 : 5) : (j == 0 ? 0 : j == 1 ? 1 : 3);
+    const int a = time_group ? j : (j == 2 ? 1 : 0);
+    const int b = time_group ? 3 : (j == 0 ? 1 : 2);
     Tap t;
     const int W = fd.planes.res[s][a], H = fd.planes.res[s][b];
     axis_tap(coord[a], W, t.x0, t.x1, t.wx0, t.wx1, t.mx);
@@ -35,8 +35,7 @@ __device__ __forceinline__ void planes_group(const FieldDesc& fd, int s, const f
     float v[C];
     sample_plane<C>(fd.planes_cl + fd.planes.off[s][ci], W, t, v);
 #pragma unroll
-    for (int k = 0; k < C; ++k) out[k] = first ? v[k] : out[k] * v[k];
-    first = false;
+    for (int k = 0; k < C; ++k) out[k] = j == 0 ? v[k] : out[k] * v[k];
   }
 }
 

@@ -47,4 +47,9 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // non-negative floats order like their bit patterns
-__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) { atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v)); }
+// The maxima are touched by every wave of a launch: read first (L2-scope load, cheap) and only issue the atomic when it
+// can raise the value -- after the first few workgroups almost nobody does.
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
+  const unsigned int cur = __hip_atomic_load(reinterpret_cast<unsigned int*>(addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__float_as_uint(v) > cur) atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
