@@ -11,14 +11,17 @@
 // Run-length pre-reduction: consecutive lanes (consecutive samples of a ray) that target the same key are summed
 // into the first lane of the run.  Returns true for lanes that must issue the atomic (run heads; every active lane
 // when the wave's keys are mostly distinct and the shuffle work would be wasted).  All 64 lanes must call this.
+// max_heads: merge only when the wave holds at most this many runs.  For global atomics (20 G/s) merging nearly always
+// pays (default 40); in front of LDS integer atomics a same-address pile-up only costs ~1 cycle per lane, so the
+// 6*K shuffles are worth it for very long runs only (pass 4).
 template <int K>
-__device__ __forceinline__ bool wave_run_reduce(uint32_t key, bool active, float v[K]) {
+__device__ __forceinline__ bool wave_run_reduce(uint32_t key, bool active, float v[K], int max_heads = 40) {
   const int lane = __lane_id();
   if (!active) key = 0xFFFFFF00u | (uint32_t)lane;  // unique, never merged
   const uint32_t prev = __shfl_up(key, 1, 64);
   const bool head = (lane == 0) || (key != prev);
   const unsigned long long H = __ballot(head);
-  if (__popcll(H) > 40) return active;  // wave-uniform: little to merge
+  if (__popcll(H) > max_heads) return active;  // wave-uniform: little to merge
   const unsigned long long above = (lane == 63) ? 0ull : (H & ~((2ull << lane) - 1ull));
   const int end = above ? (__ffsll((long long)above) - 2) : 63;  // last lane of this lane's run
 #pragma unroll
