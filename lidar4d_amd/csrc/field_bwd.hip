@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
             float vals[C];
 #pragma unroll
             for (int k = 0; k < C; ++k) vals[k] = gv[k] * wts[q];
-            if (!wave_run_reduce<C>(key, active && wts[q] != 0.0f, vals, 4)) continue;
+            if (!row_merge<C>(key, active, vals)) continue;
             if (in_win) {
               int* dst = &lds_i[lds_off(s, j) + (rr * W + xs_[q]) * C];
 #pragma unroll
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, Ba
       float vals[C];
 #pragma unroll
       for (int k = 0; k < C; ++k) vals[k] = gv[k] * wts[q];
-      if (!wave_run_reduce<C>((uint32_t)(ys[q] * W + xs_[q]), in && wts[q] != 0.0f, vals, 4)) continue;
+      if (!row_merge<C>((uint32_t)(ys[q] * W + xs_[q]), in, vals)) continue;
       int* dst = &lds_i[((ys[q] - row0) * W + xs_[q]) * C];
 #pragma unroll
       for (int k = 0; k < C; ++k)

@@ -35,6 +35,28 @@ __device__ __forceinline__ bool wave_run_reduce(uint32_t key, bool active, float
   return head && active;
 }
 
+// Row merge: when all 16 lanes of a DPP row (16 consecutive samples of a ray) target the same address -- the normal
+// case on coarse planes / levels -- sum them with 4 v_add_f32_dpp (pure VALU, no LDS traffic; __shfl goes through the
+// LDS crossbar like the atomics it is meant to spare) and let lane 15 of the row issue the add.  Rows that are not
+// uniform keep one add per lane.  Returns true for lanes that must issue.
+template <int K>
+__device__ __forceinline__ bool row_merge(uint32_t key, bool active, float v[K]) {
+  const int lane = __lane_id();
+  const uint32_t k0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x150 /*row_newbcast:0*/, 0xf, 0xf, false);
+  const unsigned long long same = __ballot(active && key == k0);
+  if (((same >> (lane & 48)) & 0xFFFFull) != 0xFFFFull) return active;  // uniform per row: all 16 lanes agree
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float x = v[k];
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
+    v[k] = x;
+  }
+  return (lane & 15) == 15;
+}
+
 // fixed-point scale: largest power of two s with bound * s < 2^bits (bound > 0)
 __device__ __forceinline__ float fx_scale(float bound, int bits) {
   if (!(bound > 0.0f)) return 1.0f;
