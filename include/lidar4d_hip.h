@@ -203,13 +203,14 @@ int l4d_density_encode_fwd(const l4d_field_desc* f /*host*/, const float* xt, co
                            const float* tinfo, int64_t P, void* X, int32_t in_pad, void* stream);
 /* Adjoint.  dX [P,in_pad] fp16 (loss-scaled); parameter gradients are accumulated multiplied by param_scale
  * (= 1/loss_scale); dflow16 [P,16] fp16 stays in dX's scaled domain.  plane_abs_max: device fp32 = max |plane
- * parameter| (bounds the fixed-point LDS accumulators); workspace: l4d_density_encode_bwd_workspace() bytes of
+ * parameter| (bounds the fixed-point LDS accumulators); samples_per_ray: T when the P rows are rays x T samples in
+ * ray-major order (enables skipping whole wavefronts per plane band), 0 if unknown; workspace: l4d_density_encode_bwd_workspace() bytes of
  * device scratch.  Several launches: see lidar4d_amd/csrc/field_bwd.hip. */
 int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f /*host*/, int64_t P);
 int l4d_density_encode_bwd(const l4d_field_desc* f /*host*/, const l4d_field_grads* g /*host*/, const float* xt,
                            const void* flow16, const float* tinfo, int64_t P, const void* dX, int32_t in_pad,
-                           float param_scale, const float* plane_abs_max, void* workspace, void* dflow16,
-                           void* stream);
+                           float param_scale, const float* plane_abs_max, int32_t samples_per_ray, void* workspace,
+                           void* dflow16, void* stream);
 
 /* ---- optimiser + casts (runner.py:506-508 Adam step; tcnn's per-forward fp32->fp16 param cast) ---- */
 int l4d_cast_f32_to_f16(const float* src, void* dst, int64_t n, void* stream);

@@ -330,7 +330,7 @@ struct BandTasks {
 
 __global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, BandTasks tasks, float* __restrict__ garena,
                                                                const float* __restrict__ xt, int64_t P, int64_t chunk,
-                                                               int64_t stride, const half_t* __restrict__ gvs, float pscale,
+                                                               int wave_skip, const half_t* __restrict__ gvs, float pscale,
                                                                const float* __restrict__ stats) {
   constexpr int C = 8;
   extern __shared__ int lds_i[];
@@ -351,6 +351,18 @@ __global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, Ba
     const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
     const bool active = pr < hi_p;
     const int64_t p = active ? pr : hi_p - 1;
+    if (wave_skip) {
+      // the 64 lanes of a wave are consecutive samples of ONE ray (samples-per-ray % 64 == 0): the band coordinate is
+      // monotone along them, so two scalar loads decide whether the whole wave misses this row band
+      const int64_t pw = lo_p + it * blockDim.x + (threadIdx.x & ~63);
+      if (pw >= hi_p) continue;
+      const int64_t pl = min(pw + 63, hi_p - 1);
+      int r0a, r1a, r0b, r1b;
+      float w0, w1, m;
+      axis_tap(xt[pw * 4 + b], H, r0a, r1a, w0, w1, m);
+      axis_tap(xt[pl * 4 + b], H, r0b, r1b, w0, w1, m);
+      if (max(r1a, r1b) < row0 || min(r0a, r0b) >= row0 + nrows) continue;
+    }
     const float ca = xt[p * 4 + a], cb = xt[p * 4 + b];
     Tap t;
     axis_tap(cb, H, t.y0, t.y1, t.wy0, t.wy1, t.my);
@@ -494,7 +506,8 @@ extern "C" int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f, int
 
 extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_grads* g, const float* xt, const void* flow16,
                                       const float* tinfo, int64_t P, const void* dX, int32_t in_pad, float param_scale,
-                                      const float* plane_abs_max, void* workspace, void* dflow16, void* stream_) {
+                                      const float* plane_abs_max, int32_t samples_per_ray, void* workspace, void* dflow16,
+                                      void* stream_) {
   if (P == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   FieldDesc d;
@@ -532,6 +545,9 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   const int64_t chunk = ceil_div64(P, n_chunks);
   n_chunks = (int)ceil_div64(P, chunk);
   const int64_t stride = pick_stride(chunk);
+  (void)stride;
+  // consecutive-lane = consecutive-sample-of-one-ray property, needed for the wave-level band skip
+  const int wave_skip = samples_per_ray > 0 && samples_per_ray % 64 == 0 && chunk % 64 == 0;
 
   // time planes
   {
@@ -563,7 +579,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       }
     hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     hipLaunchKernelGGL(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(512), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
-                       stride, gvs, param_scale, stats);
+                       wave_skip, gvs, param_scale, stats);
   }
   // dynamic hash
   {

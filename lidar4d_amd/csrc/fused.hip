@@ -46,13 +46,22 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
   *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(h);
 }
 
-__global__ void __launch_bounds__(256) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
-                                                                const half_t* __restrict__ flow16,
-                                                                const float* __restrict__ tinfo, int64_t P,
-                                                                half_t* __restrict__ X, int in_pad) {
+// Each thread assembles its sample's whole input row, but in pieces (16-B plane groups, 8-B hash levels, 2-B dynamic
+// levels).  Written straight to HBM those partial-line stores cost 17.7 GB of write traffic for a 3.2 GB matrix
+// (profiles/r01_pmc_WRITE_SIZE_c3.txt), so the row is staged in LDS (272-byte row pitch: 16-B aligned, spreads the
+// lanes' rows over the banks) and each wave then writes its 64 rows as full 16-B-per-lane coalesced stores.
+#define ENC_THREADS 128
+#define ENC_PITCH 136  // halfs per staged row (128 + 8 pad)
+__global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
+                                                                        const half_t* __restrict__ flow16,
+                                                                        const float* __restrict__ tinfo, int64_t P,
+                                                                        half_t* __restrict__ X, int in_pad) {
   constexpr int C = 8;
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
+  __shared__ __attribute__((aligned(16))) half_t stage[ENC_THREADS * ENC_PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wave_p0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+  const int64_t pr = wave_p0 + lane;
+  const int64_t p = pr < P ? pr : P - 1;
   const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
   const float t0 = tinfo[0], t1 = tinfo[1], t2 = tinfo[2];
   const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
@@ -66,7 +75,7 @@ __global__ void __launch_bounds__(256) density_encode_fwd_kernel(FieldDesc fd, c
   const float x0[4] = {c4[0], c4[1], c4[2], t0};
   const float x1[4] = {c4[0] + fl[0], c4[1] + fl[1], c4[2] + fl[2], t1};
   const float x2[4] = {c4[0] + fl[3], c4[1] + fl[4], c4[2] + fl[5], t2};
-  half_t* row = X + p * in_pad;
+  half_t* row = stage + (wave * 64 + lane) * ENC_PITCH;
   const int nS = fd.planes.n_scales;
 
   // ---- hex-planes (planes_field.py:87-141; blend lidar4d.py:175) ----
@@ -115,6 +124,15 @@ __global__ void __launch_bounds__(256) density_encode_fwd_kernel(FieldDesc fd, c
     col += L;
   }
   for (; col < in_pad; ++col) row[col] = (half_t)1.0f;  // tcnn pads the network input with ones
+
+  __syncthreads();  // rows of this wave complete (and visible) before the cooperative copy-out
+  const int chunks = in_pad / 8;  // 16-byte chunks per row
+  const half_t* wstage = stage + wave * 64 * ENC_PITCH;
+  for (int idx = lane; idx < 64 * chunks; idx += 64) {
+    const int r = idx / chunks, c = idx - r * chunks;
+    const int64_t grow = wave_p0 + r;
+    if (grow < P) *reinterpret_cast<uint4*>(X + grow * in_pad + c * 8) = *reinterpret_cast<const uint4*>(wstage + r * ENC_PITCH + c * 8);
+  }
 }
 
 // ---- sampling that also emits the normalised (x, t) rows the field kernels read --------------------
@@ -173,11 +191,11 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
   if (P == 0) return 0;
   FieldDesc d;
   if (make_field(f, d)) return 1;
-  if (l4d_field_width(f) > in_pad || in_pad % 8) {
+  if (l4d_field_width(f) > in_pad || in_pad % 8 || in_pad > 128) {
     l4d_set_error(1, "l4d_density_encode_fwd: in_pad too small for the field width (or not a multiple of 8)");
     return 1;
   }
-  hipLaunchKernelGGL(density_encode_fwd_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, d, xt,
+  hipLaunchKernelGGL(density_encode_fwd_kernel, dim3((unsigned)ceil_div64(P, ENC_THREADS)), dim3(ENC_THREADS), 0, (hipStream_t)stream, d, xt,
                      (const half_t*)flow16, tinfo, P, (half_t*)X, in_pad);
   L4D_LAUNCH_CHECK("l4d_density_encode_fwd");
   return 0;

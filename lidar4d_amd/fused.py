@@ -155,7 +155,7 @@ class RenderFn(torch.autograd.Function):
         gcl = torch.zeros(pe.layout.numel, dtype=torch.float32, device=dev)
         fd = _field_desc(model)
         vmax = pe._arena().abs().max().reshape(1)
-        dflow16 = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv, vmax)
+        dflow16 = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv, vmax, samples_per_ray=T)
         tmp = torch.empty(pe.layout.numel, dtype=torch.float32, device=dev)
         planes = pe._flat_planes()
         views, o = [], 0

@@ -305,7 +305,8 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
     return X
 
 
-def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_scale, plane_abs_max, dflow16=None):
+def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_scale, plane_abs_max, samples_per_ray=0,
+                       dflow16=None):
     """Adjoint of density_encode_fwd (several launches, lidar4d_amd/csrc/field_bwd.hip).  plane_abs_max: 1-element fp32
     device tensor, max |plane parameter| (bound for the fixed-point LDS accumulators)."""
     _chk(dX, torch.float16, "dX"), _chk(plane_abs_max, torch.float32, "plane_abs_max")
@@ -315,7 +316,7 @@ def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_sca
     nbytes = _lib.lib().l4d_density_encode_bwd_workspace(C.byref(field_desc), P)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dX.device)
     call("l4d_density_encode_bwd", C.byref(field_desc), C.byref(field_grads), _p(xt), _p(flow16), _p(tinfo), P, _p(dX),
-         in_pad, float(param_scale), _p(plane_abs_max), _p(ws), _p(dflow16), _stream())
+         in_pad, float(param_scale), _p(plane_abs_max), int(samples_per_ray), _p(ws), _p(dflow16), _stream())
     return dflow16
 
 
