@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
 }
 
 template <int D, int NV>
-__global__ void __launch_bounds__(512) bin_pass2_kernel(GridDesc desc, int shift, int n_wg, int64_t P,
+__global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shift, int n_wg, int64_t P,
                                                        const uint16_t* __restrict__ offs, const uint32_t* __restrict__ bins,
                                                        const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
@@ -160,8 +160,8 @@ __global__ void __launch_bounds__(512) bin_pass2_kernel(GridDesc desc, int shift
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) acc[i] = 0;
   __syncthreads();
   const float fxs = fx_scale((float)P * gmax * 1.01f, 61);
-  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;  // 32 groups of 16 lanes, one pass-1 workgroup's run each
-  for (int w = grp; w < n_wg; w += 32) {
+  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;  // 64 groups of 16 lanes, one pass-1 workgroup's run each
+  for (int w = grp; w < n_wg; w += 64) {
     const uint64_t slot = (uint64_t)lvl * n_wg + w;
     const uint16_t* o = offs + slot * (BS_MAX_BINS + 1);
     const uint32_t s0 = o[b], s1 = o[b + 1];
@@ -227,7 +227,7 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
     hipLaunchKernelGGL((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
                        g_col, pre_scale, pl.shift, offs, bins, lvl_max, out, out_scale);                                     \
     hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);              \
-    hipLaunchKernelGGL((bin_pass2_kernel<D, V>), grid2, dim3(512), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
+    hipLaunchKernelGGL((bin_pass2_kernel<D, V>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
                        lvl_max, out, out_scale);                                                                            \
   }
   if (n_dims == 3 && NV == 4) BS_LAUNCH(3, 4)

@@ -192,7 +192,7 @@ static int64_t pick_stride(int64_t n) {
 // 2. time planes: all scales, all three frames, one pass; LDS window = 3 rows around t per plane
 // ------------------------------------------------------------------------------------------------
 #define TROWS 3
-__global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
+__global__ void __launch_bounds__(1024) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
                                                             int64_t P, int64_t chunk, int64_t stride, const half_t* __restrict__ dX,
                                                             int in_pad, float pscale, const float* __restrict__ stats) {
@@ -328,7 +328,7 @@ struct BandTasks {
   short s[MAX_TASKS], j[MAX_TASKS], row0[MAX_TASKS], nrows[MAX_TASKS];
 };
 
-__global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, BandTasks tasks, float* __restrict__ garena,
+__global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, BandTasks tasks, float* __restrict__ garena,
                                                                const float* __restrict__ xt, int64_t P, int64_t chunk,
                                                                int wave_skip, const half_t* __restrict__ gvs, float pscale,
                                                                const float* __restrict__ stats) {
@@ -347,28 +347,40 @@ __global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, Ba
   const float fxs = fx_scale((float)chunk * stats[ST_GVS_MAX + s] * 1.01f + 1e-30f, 30);
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
   const int64_t n_iter = (chunk + blockDim.x - 1) / blockDim.x;
-  for (int64_t it = 0; it < n_iter; ++it) {
+  const int lane_ = threadIdx.x & 63;
+  for (int64_t it0 = 0; it0 < n_iter; it0 += 64) {
+    // Band test for 64 iterations at once.  The 64 lanes of a wave are consecutive samples of ONE ray (samples-per-ray
+    // % 64 == 0) and the band coordinate is monotone along them, so the first and last sample decide whether the wave
+    // misses this row band; lane i tests iteration it0 + i (two loads, all in flight together instead of a dependent
+    // load per iteration).
+    unsigned long long todo = ~0ull;
+    if (wave_skip) {
+      const int64_t pw = lo_p + (it0 + lane_) * blockDim.x + (threadIdx.x & ~63);
+      bool hit = false;
+      if (it0 + lane_ < n_iter && pw < hi_p) {
+        const int64_t pl = min(pw + 63, hi_p - 1);
+        int r0a, r1a, r0b, r1b;
+        float w0, w1, m;
+        axis_tap(xt[pw * 4 + b], H, r0a, r1a, w0, w1, m);
+        axis_tap(xt[pl * 4 + b], H, r0b, r1b, w0, w1, m);
+        hit = !(max(r1a, r1b) < row0 || min(r0a, r0b) >= row0 + nrows);
+      }
+      todo = __ballot(hit);
+    }
+    while (todo) {
+    const int bit = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int64_t it = it0 + bit;
+    if (it >= n_iter) break;
     const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
     const bool active = pr < hi_p;
     const int64_t p = active ? pr : hi_p - 1;
-    if (wave_skip) {
-      // the 64 lanes of a wave are consecutive samples of ONE ray (samples-per-ray % 64 == 0): the band coordinate is
-      // monotone along them, so two scalar loads decide whether the whole wave misses this row band
-      const int64_t pw = lo_p + it * blockDim.x + (threadIdx.x & ~63);
-      if (pw >= hi_p) continue;
-      const int64_t pl = min(pw + 63, hi_p - 1);
-      int r0a, r1a, r0b, r1b;
-      float w0, w1, m;
-      axis_tap(xt[pw * 4 + b], H, r0a, r1a, w0, w1, m);
-      axis_tap(xt[pl * 4 + b], H, r0b, r1b, w0, w1, m);
-      if (max(r1a, r1b) < row0 || min(r0a, r0b) >= row0 + nrows) continue;
-    }
     const float ca = xt[p * 4 + a], cb = xt[p * 4 + b];
     Tap t;
     axis_tap(cb, H, t.y0, t.y1, t.wy0, t.wy1, t.my);
     const bool in0 = active && t.y0 >= row0 && t.y0 < row0 + nrows;
     const bool in1 = active && t.y1 >= row0 && t.y1 < row0 + nrows && t.y1 != t.y0;
-    if (!__any(in0 || in1)) continue;  // wave-uniform
+    if (!__any(in0 || in1)) continue;  // wave-uniform (continues the while loop)
     axis_tap(ca, W, t.x0, t.x1, t.wx0, t.wx1, t.mx);
     float gv[C];
     {
@@ -391,6 +403,7 @@ __global__ void __launch_bounds__(512) planes_static_lds_kernel(FieldDesc fd, Ba
       for (int k = 0; k < C; ++k)
         if (vals[k] != 0.0f) atomicAdd(dst + k, __float2int_rn(vals[k] * fxs));
     }
+    }  // while (todo)
   }
   __syncthreads();
   const float inv = pscale / fxs;
@@ -411,7 +424,7 @@ struct HashTasks {
   int hoff[MAX_TASKS];  // offset of (plane, level) in Hbuf
 };
 
-__global__ void __launch_bounds__(512) dynhash_lds_kernel(FieldDesc fd, HashTasks tasks, const float* __restrict__ xt, int64_t P,
+__global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTasks tasks, const float* __restrict__ xt, int64_t P,
                                                          int64_t chunk, int64_t stride, const half_t* __restrict__ gdynT,
                                                          const float* __restrict__ stats, float* __restrict__ Hbuf) {
   extern __shared__ long long lds_l[];
@@ -556,7 +569,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       for (int j = 0; j < 3; ++j) lds += TROWS * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
     hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
+    hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(1024), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
                        tinfo, P, chunk, stride, (const half_t*)dX, in_pad, param_scale, stats);
   }
   // static planes
@@ -578,7 +591,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
         }
       }
     hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    hipLaunchKernelGGL(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(512), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
+    hipLaunchKernelGGL(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
                        wave_skip, gvs, param_scale, stats);
   }
   // dynamic hash
@@ -601,7 +614,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
     hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(512), 128 * 1024, stream, d, t, xt, P, chunk, (int64_t)1, gdynT, stats, Hbuf);
+    hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xt, P, chunk, (int64_t)1, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);
