@@ -67,8 +67,8 @@ torch.set_num_threads(cores)
 scale, num_frames, budget = {scale!r}, {num_frames!r}, {budget!r}
 m = fields_ref.LiDAR4D(near_lidar=1.0 * scale, far_lidar=81.0 * scale, num_frames=num_frames)
 g = torch.Generator().manual_seed(0)
-rd = torch.nn.functional.normalize(torch.randn(1, 256, 3, generator=g), dim=-1)
-ro = torch.zeros(1, 256, 3)
+rd = torch.nn.functional.normalize(torch.randn(1, 1024, 3, generator=g), dim=-1)
+ro = torch.zeros(1, 1024, 3)
 t = torch.tensor([[0.5]])
 def step(n):
     t0 = time.time()
@@ -77,7 +77,7 @@ def step(n):
     return time.time() - t0
 step(4)                                        # warm-up (allocator, thread pool)
 probe = step(8)
-n = int(max(8, min(256, budget / max(probe / 8, 1e-6))))
+n = int(max(8, min(1024, budget / max(probe / 8, 1e-6))))
 dt = step(n)
 print(json.dumps(dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
       sample="oracle (torch CPU restatement of the reference path, tiny-cuda-nn rounding points) forward+backward of "
@@ -85,7 +85,7 @@ print(json.dumps(dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
 """
 
 
-def cpu_baseline(num_frames, scale, budget_s=15.0, timeout_s=240):
+def cpu_baseline(num_frames, scale, budget_s=20.0, timeout_s=240):
     """Oracle (CPU restatement = a port of the reference path) fwd+bwd on the host cores, in a subprocess with a hard
     timeout so the bench line is always produced."""
     import subprocess
@@ -164,7 +164,10 @@ def main():
             k[1] += s.elapsed_time(e)
         _lib.PROFILE = None
         per_step = {k: v[1] / args.profile_steps for k, v in kernels.items()}
-        dominant = max(per_step, key=per_step.get)
+        # entry points that launch several kernels (the adjoints) are aggregates; the roofline is quoted for the
+        # dominant SINGLE kernel, whose name rocprofv3 reports the same way (profiles/)
+        aggregates = {"l4d_density_encode_bwd", "l4d_hashgrid_t_bwd", "l4d_planes_relayout"}
+        dominant = max((k for k in per_step if k not in aggregates), key=per_step.get)
         launches = kernels[dominant][0] / args.profile_steps
         avg_ms = kernels[dominant][1] / kernels[dominant][0]
         P = n_rays * 768
@@ -179,7 +182,7 @@ def main():
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": alg * P, "avg_launch_ms": round(avg_ms, 4),
-                        "launches_per_step": launches,
+                        "launches_per_step": launches, "rocprof_kernel": "density_encode_fwd_kernel" if dominant == "l4d_density_encode_fwd" else dominant,
                         "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
         else:
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

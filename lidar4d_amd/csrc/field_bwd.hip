@@ -7,11 +7,12 @@
 // LDS as fixed-point integers (ds_add_u32 / ds_add_u64 run 24x faster than ds_add_f32 and are order-independent,
 // i.e. deterministic) and flushed once per workgroup with coalesced atomics.
 //
+//   0. static 3-D hash grid: sorted scatter (binscatter.hip).
 //   1. prep (one thread per sample): reads dX; writes the static planes' per-plane gradient factors
 //      gvs[p][scale][plane][8] (product rule already applied), the dynamic-hash upstream gradient transposed
-//      gdynT[col][p], column maxima for the fixed-point scales; scatters the static 3-D hash gradient (run-length
-//      pre-reduced along the ray, then global atomics); computes d(flow) from the time planes' coordinate adjoint.
-//   2. planes_dyn (one pass): all time planes of all scales fit in LDS as the 3 rows around t -> int32 accumulation.
+//      gdynT[col][p], and running maxima for the fixed-point scales.
+//   2. planes_dyn (one pass): all time planes of all scales fit in LDS as the 3 rows around t -> int32 accumulation;
+//      also the coordinate adjoint of the two warped lookups = d(flow).
 //   3. planes_static (passes over <=128 KB row bands of each plane): int32 accumulation from gvs.
 //   4. dynhash (passes over (plane, level, entry range)): the 2 slices x 4 features of an entry all receive
 //      basis[f] * w_slice * H[entry], so only the scalar H is accumulated (int64), then expanded.
@@ -51,35 +52,25 @@ __device__ __forceinline__ void group_taps(const FieldDesc& fd, int s, const flo
 // 1. prep
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const float* __restrict__ xt,
-                                                            const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
+                                                            const float* __restrict__ tinfo,
                                                             int64_t P, const half_t* __restrict__ dX, int in_pad, float pscale,
                                                             half_t* __restrict__ gvs, half_t* __restrict__ gdynT,
-                                                            float* __restrict__ stats, half_t* __restrict__ dflow16) {
+                                                            float* __restrict__ stats) {
   constexpr int C = 8;
   const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = pr < P;
   const int64_t p = valid ? pr : P - 1;  // every lane runs the whole body: the wave helpers need all 64 lanes
   const int lane = __lane_id();
   const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
-  const float t0 = tinfo[0], t1 = tinfo[1], t2 = tinfo[2];
+  const float t0 = tinfo[0];
   const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
-  float fl[8];
-  {
-    uint4 u = *reinterpret_cast<const uint4*>(flow16 + p * 16);
-    const half_t* h = reinterpret_cast<const half_t*>(&u);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
-  }
   const float x0[4] = {c4[0], c4[1], c4[2], t0};
-  const float x1[4] = {c4[0] + fl[0], c4[1] + fl[1], c4[2] + fl[2], t1};
-  const float x2[4] = {c4[0] + fl[3], c4[1] + fl[4], c4[2] + fl[5], t2};
   const half_t* row = dX + p * in_pad;
   const int nS = fd.planes.n_scales;
   const float c0 = 0.5f + (has_fwd ? 0.0f : 0.25f) + (has_bwd ? 0.0f : 0.25f);
-  float g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f};
   float gd_max = 0.0f;
 
-  // ---- hex-planes: static factors + coordinate adjoint of the warped time-plane lookups ----
+  // ---- hex-planes: static planes' product-rule factors, and the range of the time-plane upstream gradient ----
   for (int s = 0; s < nS; ++s) {
     float gs[C], gd[C];
     {
@@ -113,28 +104,6 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
     }
     smax = wave_max(smax);
     if (lane == 0 && smax > 0.0f) atomic_max_nonneg(stats + ST_GVS_MAX + s, smax);
-#pragma unroll
-    for (int e = 1; e <= 2; ++e) {
-      if (!(e == 1 ? has_fwd : has_bwd)) continue;
-      const float* xe = e == 1 ? x1 : x2;
-      float* ge = e == 1 ? g1 : g2;
-      group_taps<C>(fd, s, xe, true, taps, v, cis);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        float gv[C];
-#pragma unroll
-        for (int k = 0; k < C; ++k) gv[k] = 0.25f * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
-        float gix = 0.0f, giy = 0.0f;
-        const int ci = cis[j];
-        // the four taps are re-read (L1 hits) as 8 vector loads rather than kept live across the product rule
-        TapVals<C> tv;
-        float dummy[C];
-        load_taps<C>(fd.planes_cl + fd.planes.off[s][ci], fd.planes.res[s][COMB_A[ci]], taps[j], tv, dummy);
-        coord_grad_from_taps<C>(tv, taps[j], gv, gix, giy);
-        ge[COMB_A[ci]] += gix * taps[j].mx;
-        ge[COMB_B[ci]] += giy * taps[j].my;
-      }
-    }
   }
   gd_max = wave_max(gd_max);
   if (lane == 0 && gd_max > 0.0f) atomic_max_nonneg(stats + ST_GD_MAX, gd_max);
@@ -159,19 +128,6 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
     }
   }
 
-  if (valid) {
-    half_t out[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) out[k] = (half_t)0.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      out[k] = f2h(fminf(fmaxf(g1[k], -65504.f), 65504.f));
-      out[3 + k] = f2h(fminf(fmaxf(g2[k], -65504.f), 65504.f));
-    }
-    uint4* dst = reinterpret_cast<uint4*>(dflow16 + p * 16);
-    dst[0] = reinterpret_cast<uint4*>(out)[0];
-    dst[1] = reinterpret_cast<uint4*>(out)[1];
-  }
 }
 
 // Lanes of a wave should not work on consecutive samples of one ray here: those hit the SAME texel, and same-address
@@ -192,10 +148,11 @@ static int64_t pick_stride(int64_t n) {
 // 2. time planes: all scales, all three frames, one pass; LDS window = 3 rows around t per plane
 // ------------------------------------------------------------------------------------------------
 #define TROWS 3
-__global__ void __launch_bounds__(1024) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
+__global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
                                                             int64_t P, int64_t chunk, int64_t stride, const half_t* __restrict__ dX,
-                                                            int in_pad, float pscale, const float* __restrict__ stats) {
+                                                            int in_pad, float pscale, const float* __restrict__ stats,
+                                                            half_t* __restrict__ dflow16) {
   constexpr int C = 8;
   extern __shared__ int lds_i[];
   const int nS = fd.planes.n_scales;
@@ -248,6 +205,7 @@ __global__ void __launch_bounds__(1024) planes_dyn_lds_kernel(FieldDesc fd, floa
       for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
     }
     const half_t* row = dX + p * in_pad;
+    float gflow[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // d/d(x1), d/d(x2): x1 = x + flow[:3], x2 = x + flow[3:]
     for (int s = 0; s < nS; ++s) {
       float gd[C];
       {
@@ -275,6 +233,14 @@ __global__ void __launch_bounds__(1024) planes_dyn_lds_kernel(FieldDesc fd, floa
           float gv[C];
 #pragma unroll
           for (int k = 0; k < C; ++k) gv[k] = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
+          if (e > 0) {  // coordinate adjoint of the warped lookups (time plane j pairs spatial axis j with t)
+            TapVals<C> tv;
+            float dummy[C];
+            load_taps<C>(fd.planes_cl + fd.planes.off[s][cis[j]], W, t, tv, dummy);  // L1 hits
+            float gix = 0.0f, giy = 0.0f;
+            coord_grad_from_taps<C>(tv, t, gv, gix, giy);
+            gflow[(e - 1) * 3 + j] += gix * t.mx;
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int rr = ys[q] - r_lo(s);
@@ -298,6 +264,14 @@ __global__ void __launch_bounds__(1024) planes_dyn_lds_kernel(FieldDesc fd, floa
           }
         }
       }
+    }
+    if (active) {  // d(flow), in dX's (loss-scaled) domain
+      half_t out[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) out[k] = k < 6 ? f2h(fminf(fmaxf(gflow[k], -65504.f), 65504.f)) : (half_t)0.0f;
+      uint4* dst = reinterpret_cast<uint4*>(dflow16 + p * 16);
+      dst[0] = reinterpret_cast<uint4*>(out)[0];
+      dst[1] = reinterpret_cast<uint4*>(out)[1];
     }
   }
   __syncthreads();
@@ -543,7 +517,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
 
   hipLaunchKernelGGL(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, stream, d, xt,
-                     (const half_t*)flow16, tinfo, P, (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, (half_t*)dflow16);
+                     tinfo, P, (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats);
 
   // static 3-D hash grid: sorted scatter of dX[:, 2*nS*8 + lvl*4 ..] (binscatter.hip)
   {
@@ -569,8 +543,8 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       for (int j = 0; j < 3; ++j) lds += TROWS * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
     hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(1024), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
-                       tinfo, P, chunk, stride, (const half_t*)dX, in_pad, param_scale, stats);
+    hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
+                       tinfo, P, chunk, stride, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16);
   }
   // static planes
   {
