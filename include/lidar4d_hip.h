@@ -198,9 +198,11 @@ int l4d_time_setup(const float* t, int32_t num_frames, float* tinfo, void* strea
 int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, const float* lin, const float* noise,
                        const float* t, int64_t N, int32_t T, float near, float far, float bound, float* z_vals,
                        float* xt, void* stream);
-/* flow16 [P,16] fp16: flow network output (cols 0-2 forward, 3-5 backward); X [P,in_pad] fp16 */
+/* flow16 [P,16] fp16: flow network output (cols 0-2 forward, 3-5 backward); X [P,in_pad] fp16.
+ * hd_scratch: null, or (levels of the 3 dynamic grids) * P fp16 of device scratch -> the 2-D x time hash stacks are
+ * evaluated by a separate kernel from LDS-resident slice tables (faster from ~1e5 samples). */
 int l4d_density_encode_fwd(const l4d_field_desc* f /*host*/, const float* xt, const void* flow16,
-                           const float* tinfo, int64_t P, void* X, int32_t in_pad, void* stream);
+                           const float* tinfo, int64_t P, void* X, int32_t in_pad, void* hd_scratch, void* stream);
 /* Adjoint.  dX [P,in_pad] fp16 (loss-scaled); parameter gradients are accumulated multiplied by param_scale
  * (= 1/loss_scale); dflow16 [P,16] fp16 stays in dX's scaled domain.  plane_abs_max: device fp32 = max |plane
  * parameter| (bounds the fixed-point LDS accumulators); samples_per_ray: T when the P rows are rays x T samples in

@@ -82,7 +82,7 @@ SIGNATURES = {
     "l4d_sigma_from_h": [P, I64, P, P],
     "l4d_sigma_bwd": [P, P, I64, F32, P, P],
     "l4d_time_setup": [P, I32, P, P],
-    "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P],
+    "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P, P],
     "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P],
     "l4d_density_encode_bwd_workspace": [FD, I64],
     "l4d_field_width": [FD],

@@ -7,6 +7,7 @@
 //
 // This is the direct-gather formulation (every table entry is fetched through L1/L2).
 #include "field_dev.h"
+#include <algorithm>
 
 // tinfo: [0]=t, [1]=t1, [2]=t2, [3]=has_fwd, [4]=has_bwd, [5]=frame_idx  (model/lidar4d.py:143,157-173)
 __global__ void time_setup_kernel(const float* __restrict__ t, int num_frames, float* __restrict__ tinfo) {
@@ -52,9 +53,11 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 // lanes' rows over the banks) and each wave then writes its 64 rows as full 16-B-per-lane coalesced stores.
 #define ENC_THREADS 128
 #define ENC_PITCH 136  // halfs per staged row (128 + 8 pad)
+template <bool USE_HDT>
 __global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
                                                                         const float* __restrict__ tinfo, int64_t P,
+                                                                        const half_t* __restrict__ hdT,
                                                                         half_t* __restrict__ X, int in_pad) {
   constexpr int C = 8;
   __shared__ __attribute__((aligned(16))) half_t stage[ENC_THREADS * ENC_PITCH];
@@ -109,19 +112,27 @@ __global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDe
   }
 
   // ---- dynamic HashGridT stacks at the current and the two warped neighbour frames (lidar4d.py:145,157-176) ----
-  const TimeCoef tc0 = time_coef(t0, fd.n_slices), tc1 = time_coef(t1, fd.n_slices), tc2 = time_coef(t2, fd.n_slices);
+  const int col_dyn0 = col;
+  {
+    const TimeCoef tc0 = time_coef(t0, fd.n_slices), tc1 = time_coef(t1, fd.n_slices), tc2 = time_coef(t2, fd.n_slices);
 #pragma unroll
-  for (int plane = 0; plane < 3; ++plane) {
-    const int ca = plane == 2 ? 1 : 0, cb = plane == 0 ? 1 : 2;  // xy, xz, yz
-    const float q0[2] = {x0[ca], x0[cb]}, q1[2] = {x1[ca], x1[cb]}, q2[2] = {x2[ca], x2[cb]};
-    const int L = fd.hd[plane].n_levels;
-    for (int lvl = 0; lvl < L; ++lvl) {
-      const float r0 = hash_t_level(fd, plane, lvl, tc0, q0);
-      const float r1 = has_fwd ? hash_t_level(fd, plane, lvl, tc1, q1) : r0;
-      const float r2 = has_bwd ? hash_t_level(fd, plane, lvl, tc2, q2) : r0;
-      row[col + lvl] = f2h(0.5f * r0 + 0.25f * (r1 + r2));
+    for (int plane = 0; plane < 3; ++plane) {
+      const int L = fd.hd[plane].n_levels;
+      if (USE_HDT && plane > 0) {  // xz / yz: evaluated by dynhash_fwd_lds_kernel from LDS-resident slice tables
+        for (int lvl = 0; lvl < L; ++lvl) row[col + lvl] = hdT[(int64_t)(col - col_dyn0 + lvl) * P + p];
+        col += L;
+        continue;
+      }
+      const int ca = plane == 2 ? 1 : 0, cb = plane == 0 ? 1 : 2;  // xy, xz, yz
+      const float q0[2] = {x0[ca], x0[cb]}, q1[2] = {x1[ca], x1[cb]}, q2[2] = {x2[ca], x2[cb]};
+      for (int lvl = 0; lvl < L; ++lvl) {
+        const float r0 = hash_t_level(fd, plane, lvl, tc0, q0);
+        const float r1 = has_fwd ? hash_t_level(fd, plane, lvl, tc1, q1) : r0;
+        const float r2 = has_bwd ? hash_t_level(fd, plane, lvl, tc2, q2) : r0;
+        row[col + lvl] = f2h(0.5f * r0 + 0.25f * (r1 + r2));
+      }
+      col += L;
     }
-    col += L;
   }
   for (; col < in_pad; ++col) row[col] = (half_t)1.0f;  // tcnn pads the network input with ones
 
@@ -132,6 +143,97 @@ __global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDe
     const int r = idx / chunks, c = idx - r * chunks;
     const int64_t grow = wave_p0 + r;
     if (grow < P) *reinterpret_cast<uint4*>(X + grow * in_pad + c * 8) = *reinterpret_cast<const uint4*>(wstage + r * ENC_PITCH + c * 8);
+  }
+}
+
+// ---- dynamic hash, forward, with LDS-resident slice tables ---------------------------------------------------
+// 576 of the 832 table gathers per sample are the 2-D x time stacks (3 frames x 3 planes x 2 slices x 8 levels x 4
+// corners), and through L1/L2 every one of them is its own cache line (one line per clock per CU).  For the xz and yz
+// stacks a slice-level is 64 KB, so one workgroup stages BOTH time slices of a (plane, level) in LDS (128 KB) and
+// serves the corner reads of its whole chunk of samples x 3 frames from there: 384 of the 576 gathers leave the
+// L1/L2 path.  (An xy slice-level is 256 KB: it would need the per-slice interpolated feature -- which tiny-cuda-nn
+// rounds to fp16, rounding point R2 -- carried across table parts; xy stays on the direct path in the encode kernel.)
+// Frames whose slice pair differs from the current frame's (only when a slice boundary lies between the neighbour
+// times) take the direct global path.  Output: column-major hdT[col][P] fp16, merged into X by the encode kernel.
+#define DH_THREADS 1024
+#define DH_MAX_ENTRIES 8192  // per slice: 2 slices x 8192 x 8 B = 128 KB
+__global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc fd, const float* __restrict__ xt,
+                                                                    const half_t* __restrict__ flow16,
+                                                                    const float* __restrict__ tinfo, int64_t P, int64_t chunk,
+                                                                    half_t* __restrict__ hdT) {
+  extern __shared__ uint2 lds_tab[];
+  // task = (plane in {xz, yz}, level); hdT column = levels(xy) + ...
+  int task = blockIdx.y, plane = 1;
+  if (task >= fd.hd[1].n_levels) { task -= fd.hd[1].n_levels; plane = 2; }
+  const int lvl = task;
+  const int col = fd.hd[0].n_levels + (plane == 2 ? fd.hd[1].n_levels : 0) + lvl;
+  const int ca = plane == 2 ? 1 : 0, cb = 2;
+  const GridDesc& g = fd.hd[plane];
+  const float scale = g.scale[lvl];
+  const uint32_t res = g.res[lvl], size = g.size[lvl];
+  const bool hashed = (g.hashed_mask >> lvl) & 1u;
+  TimeCoef tc[3] = {time_coef(tinfo[0], fd.n_slices), time_coef(tinfo[1], fd.n_slices), time_coef(tinfo[2], fd.n_slices)};
+  const bool has_e[3] = {true, tinfo[3] != 0.0f, tinfo[4] != 0.0f};
+  bool in_lds[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) in_lds[e] = has_e[e] && tc[e].sp.i1 == tc[0].sp.i1 && tc[e].sp.i2 == tc[0].sp.i2;
+  const bool two = tc[0].sp.i1 != tc[0].sp.i2;
+  // stage the current frame's slice pair of this (plane, level): slice i1 at [0, size), slice i2 at [size, 2 size)
+  {
+    const uint2* t1p = reinterpret_cast<const uint2*>(fd.hd_tables[plane][tc[0].sp.i1] + (size_t)g.offset[lvl] * 4);
+    const uint2* t2p = reinterpret_cast<const uint2*>(fd.hd_tables[plane][tc[0].sp.i2] + (size_t)g.offset[lvl] * 4);
+    for (uint32_t i = threadIdx.x * 2; i < size; i += DH_THREADS * 2) {  // sizes are multiples of 8 entries
+      *reinterpret_cast<uint4*>(&lds_tab[i]) = *reinterpret_cast<const uint4*>(&t1p[i]);
+      if (two) *reinterpret_cast<uint4*>(&lds_tab[size + i]) = *reinterpret_cast<const uint4*>(&t2p[i]);
+    }
+  }
+  __syncthreads();
+  half_t* out = hdT + (int64_t)col * P;
+  const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
+  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += DH_THREADS) {
+    const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
+    const uint4 u = *reinterpret_cast<const uint4*>(flow16 + p * 16);
+    const half_t* fh = reinterpret_cast<const half_t*>(&u);
+    const float xa[3] = {c4[ca], c4[ca] + h2f(fh[ca]), c4[ca] + h2f(fh[3 + ca])};
+    const float xb[3] = {c4[cb], c4[cb] + h2f(fh[cb]), c4[cb] + h2f(fh[3 + cb])};
+    float r[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      r[e] = 0.0f;
+      if (!has_e[e]) continue;
+      const float q[2] = {xa[e], xb[e]};
+      if (!in_lds[e]) {  // neighbour frame on another slice pair (rare): direct gathers
+        r[e] = hash_t_level(fd, plane, lvl, tc[e], q);
+        continue;
+      }
+      Cell<2> c = locate<2>(q, scale);
+      float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cn = 0; cn < 4; ++cn) {
+        uint32_t gv[2];
+        const float w = corner<2>(c, cn, gv);
+        const uint32_t idx = grid_index<2>(gv, res, size, hashed);
+        const uint2 ra = lds_tab[idx];
+        const half_t* ha = reinterpret_cast<const half_t*>(&ra);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) a[f] += w * h2f(ha[f]);
+        if (two) {
+          const uint2 rb = lds_tab[size + idx];
+          const half_t* hb = reinterpret_cast<const half_t*>(&rb);
+#pragma unroll
+          for (int f = 0; f < 4; ++f) b[f] += w * h2f(hb[f]);
+        }
+      }
+      if (two) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) r[e] += tc[e].basis[f] * (tc[e].sp.w1 * h2f(f2h(a[f])) + tc[e].sp.w2 * h2f(f2h(b[f])));
+      } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) r[e] += tc[e].basis[f] * h2f(f2h(a[f]));
+      }
+    }
+    const float r1 = has_e[1] ? r[1] : r[0], r2 = has_e[2] ? r[2] : r[0];
+    out[p] = f2h(0.5f * r[0] + 0.25f * (r1 + r2));
   }
 }
 
@@ -187,7 +289,7 @@ extern "C" int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, cons
 }
 
 extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, const void* flow16, const float* tinfo,
-                                      int64_t P, void* X, int32_t in_pad, void* stream) {
+                                      int64_t P, void* X, int32_t in_pad, void* hd_scratch, void* stream) {
   if (P == 0) return 0;
   FieldDesc d;
   if (make_field(f, d)) return 1;
@@ -195,9 +297,25 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     l4d_set_error(1, "l4d_density_encode_fwd: in_pad too small for the field width (or not a multiple of 8)");
     return 1;
   }
-  hipLaunchKernelGGL(density_encode_fwd_kernel, dim3((unsigned)ceil_div64(P, ENC_THREADS)), dim3(ENC_THREADS), 0, (hipStream_t)stream, d, xt,
-                     (const half_t*)flow16, tinfo, P, (half_t*)X, in_pad);
+  if (hd_scratch) {
+    if (d.hd[1].size[d.hd[1].n_levels - 1] > DH_MAX_ENTRIES || d.hd[2].size[d.hd[2].n_levels - 1] > DH_MAX_ENTRIES) {
+      l4d_set_error(1, "l4d_density_encode_fwd: xz/yz slice tables exceed the LDS staging size; pass hd_scratch = null");
+      return 1;
+    }
+    int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, 8192)));
+    const int64_t chunk = ceil_div64(P, n_chunks);
+    n_chunks = (int)ceil_div64(P, chunk);
+    hipFuncSetAttribute((const void*)dynhash_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DH_MAX_ENTRIES * 8);
+    hipLaunchKernelGGL(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
+                       2 * DH_MAX_ENTRIES * 8, (hipStream_t)stream, d, xt, (const half_t*)flow16, tinfo, P, chunk, (half_t*)hd_scratch);
+  }
+  const dim3 egrid((unsigned)ceil_div64(P, ENC_THREADS));
+  if (hd_scratch)
+    hipLaunchKernelGGL((density_encode_fwd_kernel<true>), egrid, dim3(ENC_THREADS), 0, (hipStream_t)stream, d, xt,
+                       (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);
+  else
+    hipLaunchKernelGGL((density_encode_fwd_kernel<false>), egrid, dim3(ENC_THREADS), 0, (hipStream_t)stream, d, xt,
+                       (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);
   L4D_LAUNCH_CHECK("l4d_density_encode_fwd");
   return 0;
 }
-

@@ -14,6 +14,7 @@ def call(name, *args):
     _lib.call(name, *args)
 
 
+LDS_DYNHASH_MIN_POINTS = 1 << 15          # below this the per-sample direct-gather path wins (table fills dominate)
 BINNED_SCATTER_MIN_RECORDS = 1 << 16  # below this the global-atomic path is cheaper than two extra launches
 
 
@@ -301,7 +302,12 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
     P = xt.shape[0]
     if X is None:
         X = torch.empty(P, in_pad, dtype=torch.float16, device=xt.device)
-    call("l4d_density_encode_fwd", C.byref(field_desc), _p(xt), _p(flow16), _p(tinfo), P, _p(X), in_pad, _stream())
+    scratch = None
+    if P >= LDS_DYNHASH_MIN_POINTS and max(field_desc.hash_dynamic[1].size[field_desc.hash_dynamic[1].n_levels - 1],
+                                           field_desc.hash_dynamic[2].size[field_desc.hash_dynamic[2].n_levels - 1]) <= 8192:
+        n_dyn = sum(field_desc.hash_dynamic[i].n_levels for i in range(3))
+        scratch = torch.empty(n_dyn * P, dtype=torch.float16, device=xt.device)
+    call("l4d_density_encode_fwd", C.byref(field_desc), _p(xt), _p(flow16), _p(tinfo), P, _p(X), in_pad, _p(scratch), _stream())
     return X
 
 
