@@ -182,7 +182,8 @@ def main():
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": alg * P, "avg_launch_ms": round(avg_ms, 4),
-                        "launches_per_step": launches, "rocprof_kernel": "density_encode_fwd_kernel" if dominant == "l4d_density_encode_fwd" else dominant,
+                        "launches_per_step": launches,
+                        "rocprof_kernels": "dynhash_fwd_lds_kernel + density_encode_fwd_kernel<true>" if dominant == "l4d_density_encode_fwd" else dominant,
                         "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
         else:
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
