@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblidar4d_hip.so")
+LIB_PATH = os.environ.get("L4D_LIB", os.path.join(_HERE, "liblidar4d_hip.so"))  # L4D_LIB: ablation builds (tools/)
 
 L4D_MAX_LEVELS = 16
 L4D_MAX_TIME_SLICES = 8

@@ -252,9 +252,13 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
             if (!row_merge<C>(key, active, vals)) continue;
             if (in_win) {
               int* dst = &lds_i[lds_off(s, j) + (rr * W + xs_[q]) * C];
+#ifndef ABL_NO_LDS_ATOMICS
 #pragma unroll
               for (int k = 0; k < C; ++k)
                 if (vals[k] != 0.0f) atomicAdd(dst + k, __float2int_rn(vals[k] * fxs));
+#else
+              asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
+#endif
             } else {  // outside the LDS window (only for exotic num_frames / time_resolution): direct
               float* dst = garena + fd.planes.off[s][cis[j]] + ((size_t)ys[q] * W + xs_[q]) * C;
 #pragma unroll
