@@ -214,6 +214,17 @@ int l4d_density_encode_bwd(const l4d_field_desc* f /*host*/, const l4d_field_gra
                            float param_scale, const float* plane_abs_max, int32_t samples_per_ray, void* workspace,
                            void* dflow16, void* stream);
 
+/* ---- chamfer_3DDist : utils/chamfer3D/chamfer3D.cu:11-194, dist_chamfer_3D.py:31-83 (SURVEY 8f "next" row 1) ----
+ * xyz1 [b,n,3], xyz2 [b,m,3] fp32 -> dist1 [b,n], dist2 [b,m] (squared distance to the nearest point of the other
+ * cloud), idx1 [b,n], idx2 [b,m] (int32, first minimum wins).  workspace: l4d_chamfer_workspace() bytes. */
+int64_t l4d_chamfer_workspace(int32_t b, int32_t n, int32_t m);
+int l4d_chamfer_fwd(const float* xyz1, const float* xyz2, int32_t b, int32_t n, int32_t m, float* dist1, float* dist2,
+                    int32_t* idx1, int32_t* idx2, void* workspace, void* stream);
+/* grad_xyz1 [b,n,3], grad_xyz2 [b,m,3] must be zero-filled by the caller (accumulated with atomics) */
+int l4d_chamfer_bwd(const float* xyz1, const float* xyz2, int32_t b, int32_t n, int32_t m, const float* grad_dist1,
+                    const float* grad_dist2, const int32_t* idx1, const int32_t* idx2, float* grad_xyz1,
+                    float* grad_xyz2, void* stream);
+
 /* ---- optimiser + casts (runner.py:506-508 Adam step; tcnn's per-forward fp32->fp16 param cast) ---- */
 int l4d_cast_f32_to_f16(const float* src, void* dst, int64_t n, void* stream);
 int l4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16 /*or null*/,

@@ -86,6 +86,9 @@ SIGNATURES = {
     "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P],
     "l4d_density_encode_bwd_workspace": [FD, I64],
     "l4d_field_width": [FD],
+    "l4d_chamfer_workspace": [I32, I32, I32],
+    "l4d_chamfer_fwd": [P, P, I32, I32, I32, P, P, P, P, P, P],
+    "l4d_chamfer_bwd": [P, P, I32, I32, I32, P, P, P, P, P, P, P],
     "l4d_cast_f32_to_f16": [P, P, I64, P],
     "l4d_adam_step": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, F32, F32, P],
 }

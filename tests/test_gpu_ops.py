@@ -239,3 +239,32 @@ def test_adam_matches_torch():
         ops.adam_step(p, g, m, v, p16, 1e-2, 0.9, 0.99, 1e-15, step)
         rel_close(p, p_ref, 1e-5, 1e-6, f"adam step {step}")
     assert torch.equal(p16, p.half())
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1000, 1700), (2, 513, 257), (1, 16384, 16384)])
+def test_chamfer_fwd_bwd(b, n, m):
+    """l4d_chamfer_fwd/bwd (replacement of utils/chamfer3D/chamfer3D.cu) against the brute-force oracle."""
+    from lidar4d_amd.chamfer import chamfer_3DDist
+    from oracle.chamfer_ref import chamfer as chamfer_ref
+    g = torch.Generator().manual_seed(b * 1000 + n)
+    a = (torch.rand(b, n, 3, generator=g) * 2 - 1).requires_grad_(True)
+    c = (torch.rand(b, m, 3, generator=g) * 2 - 1).requires_grad_(True)
+    ag, cg = a.detach().to(DEV).requires_grad_(True), c.detach().to(DEV).requires_grad_(True)
+    d1, d2, i1, i2 = chamfer_3DDist()(ag, cg)
+    assert d1.shape == (b, n) and d2.shape == (b, m) and i1.dtype == torch.int32
+    if n * m <= 4_000_000:
+        r1, r2, j1, j2 = chamfer_ref(a, c)
+        assert torch.equal(d1.cpu(), r1.detach()) and torch.equal(d2.cpu(), r2.detach()), "same fp32 arithmetic: bit-exact"
+        assert torch.equal(i1.cpu().long(), j1) and torch.equal(i2.cpu().long(), j2)
+        w1, w2 = torch.rand(b, n, generator=g), torch.rand(b, m, generator=g)
+        ((r1 * w1).sum() + (r2 * w2).sum()).backward()
+        ((d1 * w1.to(DEV)).sum() + (d2 * w2.to(DEV)).sum()).backward()
+        rel_close(ag.grad, a.grad, 1e-5, 1e-6, "chamfer grad xyz1")
+        rel_close(cg.grad, c.grad, 1e-5, 1e-6, "chamfer grad xyz2")
+    else:  # full ray-batch size: properties instead of the O(n m) oracle
+        sel = torch.arange(0, n, 97)
+        dd = ((ag.detach()[0, sel, None, :] - cg.detach()[0, None, :, :]) ** 2)
+        ref = (dd[..., 0] + dd[..., 1] + dd[..., 2]).min(1)
+        assert torch.equal(d1[0, sel], ref.values) and torch.equal(i1[0, sel].long(), ref.indices)
+        s1, s2, k1, _ = chamfer_3DDist()(ag, ag)
+        assert float(s1.abs().max()) == 0.0 and torch.equal(k1[0].long().cpu(), torch.arange(n))
