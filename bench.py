@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chamfer", action="store_true", help="add the reference's ray chamfer loss term (runner.py:215-220) to the step")
     ap.add_argument("--profile-steps", type=int, default=2)
     args = ap.parse_args()
 
@@ -130,7 +131,7 @@ def main():
     torch.manual_seed(0)  # identical initial replicas on every rank
     model = LiDAR4D(near_lidar=1.0 * KITTI360_SCALE, far_lidar=81.0 * KITTI360_SCALE, num_frames=51, **model_kw).to(dev)
     data = SyntheticKitti360(dev, num_rays=n_rays, seed=1000 + rank)
-    trainer = Trainer(model, data)
+    trainer = Trainer(model, data, chamfer=args.chamfer)
 
     def barrier():
         if world > 1:
@@ -207,7 +208,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "rays_per_gpu_per_step": n_rays, "samples_per_ray": 768,
                        "global_rays_per_step": n_rays * world, "parallelism": f"ray-sharded dp{world}, 1 RCCL all-reduce/step",
-                       "step": "forward + backward + Adam, losses L1 depth + MSE raydrop + MSE intensity (no chamfer/flow loss)"},
+                       "step": "forward + backward + Adam, losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else " (no chamfer/flow loss)")},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

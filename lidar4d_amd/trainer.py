@@ -26,6 +26,20 @@ def lidar_loss(outputs, images_lidar, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, sm
     return loss.sum()
 
 
+def ray_chamfer_loss(outputs, data, scale):
+    """runner.py:215-220: chamfer distance between predicted and ground-truth points along the same rays (in metres),
+    (dist1 + dist2).mean() * 0.5, on the HIP chamfer kernel (lidar4d_amd/chamfer.py)."""
+    from .chamfer import chamfer_3DDist
+    gt_raydrop = data["images_lidar"][:, :, 0]
+    gt_depth = data["images_lidar"][:, :, 2] * gt_raydrop
+    pred_depth = outputs["depth_lidar"] * gt_raydrop
+    rays_d = data["rays_d_lidar"]
+    pred_lidar = rays_d * pred_depth.unsqueeze(-1) / scale
+    gt_lidar = rays_d * gt_depth.unsqueeze(-1) / scale
+    dist1, dist2, _, _ = chamfer_3DDist()(pred_lidar, gt_lidar)
+    return (dist1 + dist2).mean() * 0.5
+
+
 class FlatAdam:
     """torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) over the model's flat arenas: one l4d_adam_step launch per lr
     group (encoders at lr, networks at 0.1 lr: lidar4d.py:226-237), which also refreshes the fp16 compute copies.
@@ -63,8 +77,10 @@ class Trainer:
     indices -- parameters are replicated and the flat gradient buffer is SUM-all-reduced once per step (the primary
     loss is a sum over rays, so the result equals one big batch)."""
 
-    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768):
-        self.model, self.dataset, self.num_steps = model, dataset, num_steps
+    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=False):
+        """chamfer=True adds the reference's ray chamfer term (runner.py:215-220); it is a mean over the rank's own
+        rays, so under data parallelism it is scaled by 1/world before the SUM all-reduce."""
+        self.model, self.dataset, self.num_steps, self.chamfer = model, dataset, num_steps, chamfer
         self.opt = FlatAdam(model, lr=lr, iters=iters)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -74,6 +90,8 @@ class Trainer:
         out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
                                 num_steps=self.num_steps)
         loss = lidar_loss(out, data["images_lidar"])
+        if self.chamfer:
+            loss = loss + ray_chamfer_loss(out, data, self.dataset.scale) / self.world
         loss.backward()
         if self.world > 1:
             dist.all_reduce(self.model._store.flat_grad, op=dist.ReduceOp.SUM)
