@@ -34,7 +34,10 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
                                                               float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
   constexpr int NW = RecWords<NV>::n;
-  __shared__ uint32_t hist[BS_MAX_BINS], boff[BS_MAX_BINS + 1];
+  // per-wave histograms: 1024 threads x 2^D records into <= 128 bins would otherwise pile ~64 same-address returning
+  // LDS atomics onto every counter
+  constexpr int NWAVES = BS_THREADS / 64;
+  __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
   __shared__ uint32_t stage[BS_THREADS * NC * NW];
   __shared__ uint32_t total_s;
   const int lvl = blockIdx.y;
@@ -56,7 +59,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
     any |= gv[j] != 0.0f;
     amax = fmaxf(amax, fabsf(gv[j]));
   }
-  if (threadIdx.x < BS_MAX_BINS) hist[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < NWAVES * BS_MAX_BINS; i += BS_THREADS) (&hist[0][0])[i] = 0;
   __syncthreads();
 
   float xin[D];
@@ -98,12 +101,23 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   if (lane == 0 && amax > 0.0f) atomic_max_nonneg(lvl_max + lvl, amax);
 
   // rank inside the workgroup
+  const int wave_id = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[keys[k] >> shift], 1u) : 0u;
+  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[wave_id][keys[k] >> shift], 1u) : 0u;
+  __syncthreads();
+  if (threadIdx.x < BS_MAX_BINS) {  // exclusive prefix over the waves of each bin; hist[0][b] <- bin total
+    uint32_t run = 0;
+    for (int w = 0; w < NWAVES; ++w) {
+      const uint32_t c = hist[w][threadIdx.x];
+      hist[w][threadIdx.x] = run;
+      run += c;
+    }
+    boff[threadIdx.x] = run;  // temporarily the bin total
+  }
   __syncthreads();
   const uint64_t wg_slot = (uint64_t)lvl * gridDim.x + blockIdx.x;
   if (threadIdx.x < 64) {  // exclusive scan of <= 128 bins by one wave
-    uint32_t c0 = lane < nbins ? hist[lane] : 0u, c1 = lane + 64 < nbins ? hist[lane + 64] : 0u;
+    uint32_t c0 = lane < nbins ? boff[lane] : 0u, c1 = lane + 64 < nbins ? boff[lane + 64] : 0u;
     uint32_t inc0 = c0, inc1 = c1;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -127,7 +141,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   for (int k = 0; k < NC; ++k)
     if (emit[k]) {
       const uint32_t b = keys[k] >> shift;
-      const uint32_t r = boff[b] + pos[k];
+      const uint32_t r = boff[b] + hist[wave_id][b] + pos[k];
       stage[r * NW] = keys[k];
       half_t hv[2 * (NW - 1)];
 #pragma unroll
