@@ -20,7 +20,7 @@
 #include "wave_dev.h"
 #include "binscatter.h"
 
-#define BS_THREADS 1024
+#define BS_THREADS 512
 #define BS_MAX_BINS 128
 
 template <int NV>
