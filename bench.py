@@ -33,6 +33,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 WORKLOADS = {
     # name: (model kwargs, rays per GPU per step, description)
     "c3": (dict(), 16384, "C3: KITTI-360 seq-4950-shaped full 4D (L=8 hash + hex-planes + flow_field), 16384 rays/batch/GPU training"),
+    "c2": (dict(n_levels_hash=16, num_layers_sigma=3), 4096,
+           "C2-shaped: L=16 hash + 3-layer-64 sigma MLP, 4096 rays/batch (the reference has no static-only switch: the full 4D field runs)"),
     "c3-4k": (dict(), 4096, "full 4D, 4096 rays/batch/GPU training (staged-chunk size)"),
     "c3-1k": (dict(), 1024, "full 4D, 1024 rays/batch/GPU training (the reference's own num_rays_lidar)"),
 }

@@ -49,10 +49,10 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 
 // Each thread assembles its sample's whole input row, but in pieces (16-B plane groups, 8-B hash levels, 2-B dynamic
 // levels).  Written straight to HBM those partial-line stores cost 17.7 GB of write traffic for a 3.2 GB matrix
-// (profiles/r01_pmc_WRITE_SIZE_c3.txt), so the row is staged in LDS (272-byte row pitch: 16-B aligned, spreads the
-// lanes' rows over the banks) and each wave then writes its 64 rows as full 16-B-per-lane coalesced stores.
+// (profiles/r01_pmc_WRITE_SIZE_c3.txt), so the row is staged in LDS (row pitch in_pad + 8 halfs: 16-B aligned, spreads
+// the lanes' rows over the banks) and each wave then writes its 64 rows as full 16-B-per-lane coalesced stores.
 #define ENC_THREADS 128
-#define ENC_PITCH 136  // halfs per staged row (128 + 8 pad)
+#define ENC_MAX_IN_PAD 192  // widest network input row (BASELINE config C2: L = 16 hash levels -> 176 columns)
 template <bool USE_HDT>
 __global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDe
                                                                         const half_t* __restrict__ hdT,
                                                                         half_t* __restrict__ X, int in_pad) {
   constexpr int C = 8;
-  __shared__ __attribute__((aligned(16))) half_t stage[ENC_THREADS * ENC_PITCH];
+  extern __shared__ __attribute__((aligned(16))) half_t stage[];  // [ENC_THREADS][in_pad + 8]
+  const int ENC_PITCH = in_pad + 8;  // halfs per staged row: 16-byte aligned, spreads the lanes' rows over the banks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wave_p0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
   const int64_t pr = wave_p0 + lane;
@@ -293,7 +294,7 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
   if (P == 0) return 0;
   FieldDesc d;
   if (make_field(f, d)) return 1;
-  if (l4d_field_width(f) > in_pad || in_pad % 8 || in_pad > 128) {
+  if (l4d_field_width(f) > in_pad || in_pad % 8 || in_pad > ENC_MAX_IN_PAD) {
     l4d_set_error(1, "l4d_density_encode_fwd: in_pad too small for the field width (or not a multiple of 8)");
     return 1;
   }
@@ -310,11 +311,12 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
                        2 * DH_MAX_ENTRIES * 8, (hipStream_t)stream, d, xt, (const half_t*)flow16, tinfo, P, chunk, (half_t*)hd_scratch);
   }
   const dim3 egrid((unsigned)ceil_div64(P, ENC_THREADS));
+  const int enc_lds = ENC_THREADS * (in_pad + 8) * 2;
   if (hd_scratch)
-    hipLaunchKernelGGL((density_encode_fwd_kernel<true>), egrid, dim3(ENC_THREADS), 0, (hipStream_t)stream, d, xt,
+    hipLaunchKernelGGL((density_encode_fwd_kernel<true>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
                        (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);
   else
-    hipLaunchKernelGGL((density_encode_fwd_kernel<false>), egrid, dim3(ENC_THREADS), 0, (hipStream_t)stream, d, xt,
+    hipLaunchKernelGGL((density_encode_fwd_kernel<false>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
                        (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);
   L4D_LAUNCH_CHECK("l4d_density_encode_fwd");
   return 0;

@@ -187,7 +187,10 @@ struct BwdFrags {
   static constexpr int NF = W1T + IN_TILES * 2;
 };
 
-template <int IN_TILES, int NH>
+// COL_LO..COL_HI: range of 16-wide input-column tiles whose dW1 / dX this launch produces; REST: also accumulate the
+// hidden/output layers' dW.  Inputs wider than 128 columns are handled by two launches (the dW1 accumulators of all
+// columns do not fit the register file next to the other layers'); the chain is recomputed, which is cheap.
+template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST>
 __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
                                                      const half_t* __restrict__ dy, int64_t cap,
                                                      const int32_t* __restrict__ n_rows,
@@ -230,7 +233,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
   // dW accumulators, C layout: [m = 16*mt + 4g + r][k = 16*nt + i]
   f4 dWo[4];
   f4 dWh[(NH > 1 ? NH - 1 : 1)][4][4];
-  f4 dW1[4][IN_TILES];
+  constexpr int NCOL = COL_HI - COL_LO;
+  f4 dW1[4][NCOL];
 #pragma unroll
   for (int a = 0; a < 4; ++a) dWo[a] = f4{0, 0, 0, 0};
 #pragma unroll
@@ -242,7 +246,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < IN_TILES; ++b) dW1[a][b] = f4{0, 0, 0, 0};
+    for (int b = 0; b < NCOL; ++b) dW1[a][b] = f4{0, 0, 0, 0};
 
   const int64_t n_macro = (P + 31) / 32;
   for (int64_t mtile = (int64_t)blockIdx.x * 4 + wave; mtile < n_macro; mtile += (int64_t)gridDim.x * 4) {
@@ -296,7 +300,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
         hT[nt][r] = f2h(t0[r]);
         hT[nt][4 + r] = f2h(t1[r]);
       }
-      dWo[nt] = MFMA(dyT, hT[nt], dWo[nt]);
+      if (REST) dWo[nt] = MFMA(dyT, hT[nt], dWo[nt]);
     }
     // dH_NH (chain) and dH_NH' (orientation 2), masked by ReLU
     {
@@ -358,10 +362,12 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
           hT[nt][4 + r] = f2h(t1[r]);
         }
       }
+      if (REST) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) dWh[layer - 2][mt][nt] = MFMA(dzT[mt], hT[nt], dWh[layer - 2][mt][nt]);
+          for (int nt = 0; nt < 4; ++nt) dWh[layer - 2][mt][nt] = MFMA(dzT[mt], hT[nt], dWh[layer - 2][mt][nt]);
+      }
       const int fb = L::WH + li * 16;
       h8 nz[2][2], nzT[4];
 #pragma unroll
@@ -415,7 +421,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
           xf[a][ks] = *reinterpret_cast<h8*>(&u);
         }
 #pragma unroll
-      for (int nt = 0; nt < IN_TILES; ++nt) {
+      for (int nt = COL_LO; nt < COL_HI; ++nt) {
         const h8 sel = (nt & 1) ? I1 : I0;
         f4 t0 = MFMA(xf[0][nt >> 1], sel, (f4{0, 0, 0, 0}));
         f4 t1 = MFMA(xf[1][nt >> 1], sel, (f4{0, 0, 0, 0}));
@@ -426,13 +432,13 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
           xT[4 + r] = f2h(t1[r]);
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) dW1[mt][nt] = MFMA(dzT[mt], xT, dW1[mt][nt]);
+        for (int mt = 0; mt < 4; ++mt) dW1[mt][nt - COL_LO] = MFMA(dzT[mt], xT, dW1[mt][nt - COL_LO]);
       }
       if (dx) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int mt = 0; mt < IN_TILES; ++mt) {
+          for (int mt = COL_LO; mt < COL_HI; ++mt) {
             f4 c = MFMA(FR(L::W1T + mt * 2 + 0), dzf[a][0], (f4{0, 0, 0, 0}));
             c = MFMA(FR(L::W1T + mt * 2 + 1), dzf[a][1], c);
             if (ok[a]) {
@@ -452,12 +458,13 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < IN_TILES; ++nt)
+    for (int nt = COL_LO; nt < COL_HI; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = dW1[mt][nt][r] * inv_scale;
+        const float v = dW1[mt][nt - COL_LO][r] * inv_scale;
         if (v != 0.0f) atomicAdd(gW1 + (16 * mt + 4 * g + r) * IN_PAD + 16 * nt + i, v);
       }
+  if (!REST) return;
 #pragma unroll
   for (int l = 0; l < NH - 1; ++l) {
     float* gWl = grad_w + HID * IN_PAD + l * HID * HID;
@@ -491,6 +498,7 @@ static int grid_for(int64_t tiles) {
 }
 
 #define FOR_EACH_CFG(X) X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3) X(4, 1) X(4, 2) X(4, 3) X(6, 1) X(6, 2) X(6, 3) X(8, 1) X(8, 2) X(8, 3)
+#define FOR_EACH_WIDE_CFG(X) X(10, 1) X(10, 2) X(10, 3) X(11, 1) X(11, 2) X(11, 3) X(12, 1) X(12, 2) X(12, 3)
 
 extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad, int32_t n_hidden,
                            const void* weights, void* y, void* act, void* stream) {
@@ -505,9 +513,10 @@ extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int3
     done = true;                                                                                                     \
   }
   FOR_EACH_CFG(X)
+  FOR_EACH_WIDE_CFG(X)
 #undef X
   if (!done) {
-    l4d_set_error(1, "l4d_mlp_fwd: unsupported (in_pad, n_hidden); in_pad in {16,32,64,96,128}, n_hidden in 1..3");
+    l4d_set_error(1, "l4d_mlp_fwd: unsupported (in_pad, n_hidden); in_pad in {16,32,64,96,128,160,176,192}, n_hidden in 1..3");
     return 1;
   }
   L4D_LAUNCH_CHECK("l4d_mlp_fwd");
@@ -524,12 +533,24 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   bool done = false;
 #define X(IT, NHH)                                                                                                   \
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
-    hipLaunchKernelGGL((mlp_bwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,   \
-                       (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights, (half_t*)dx, grad_w, \
-                       inv_loss_scale);                                                                              \
+    hipLaunchKernelGGL((mlp_bwd_kernel<IT, NHH, 0, IT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,         \
+                       (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
+                       (half_t*)dx, grad_w, inv_loss_scale);                                                         \
     done = true;                                                                                                     \
   }
   FOR_EACH_CFG(X)
+#undef X
+#define X(IT, NHH)                                                                                                   \
+  if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
+    hipLaunchKernelGGL((mlp_bwd_kernel<IT, NHH, 0, 6, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
+                       (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
+                       (half_t*)dx, grad_w, inv_loss_scale);                                                         \
+    hipLaunchKernelGGL((mlp_bwd_kernel<IT, NHH, 6, IT, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
+                       (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
+                       (half_t*)dx, grad_w, inv_loss_scale);                                                         \
+    done = true;                                                                                                     \
+  }
+  FOR_EACH_WIDE_CFG(X)
 #undef X
   if (!done) {
     l4d_set_error(1, "l4d_mlp_bwd: unsupported (in_pad, n_hidden)");

@@ -135,8 +135,9 @@ class FullyFusedMLP(nn.Module, _HalfParams):
         self.n_hidden_layers = int(cfg["n_hidden_layers"])
         self.shapes = mlp_layer_shapes(n_input_dims, n_output_dims, 64, self.n_hidden_layers)
         self.in_pad = self.shapes[0][1]
-        if self.in_pad > 128 or not 1 <= self.n_hidden_layers <= 3:
-            raise ValueError("lidar4d_amd.tcnn.Network: padded input width <= 128 and 1..3 hidden layers supported")
+        if self.in_pad not in (16, 32, 64, 96, 128, 160, 176, 192) or not 1 <= self.n_hidden_layers <= 3:
+            raise ValueError("lidar4d_amd.tcnn.Network: padded input width in {16,32,64,96,128,160,176,192} and 1..3 "
+                             "hidden layers are supported")
         g = torch.Generator().manual_seed(seed)
         chunks = []
         for rows, cols in self.shapes:

@@ -129,7 +129,7 @@ def test_frequency():
     rel_close(out.float(), ref(x).float(), rtol=2 * HALF_ULP, atol=2e-6, what="frequency")
 
 
-@pytest.mark.parametrize("n_in,n_out,n_hidden", [(120, 16, 1), (87, 1, 2), (120, 16, 2), (16, 6, 2), (60, 3, 3)])
+@pytest.mark.parametrize("n_in,n_out,n_hidden", [(120, 16, 1), (87, 1, 2), (120, 16, 2), (16, 6, 2), (60, 3, 3), (176, 16, 2), (150, 16, 1)])
 def test_mlp_fwd_bwd(n_in, n_out, n_hidden):
     from lidar4d_amd import tcnn
     cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
