@@ -156,11 +156,14 @@ def main():
     # ---- per-kernel timing pass (HIP events on the launch stream), outside the timed region ----
     roofline = None
     kernels = {}
-    if rank == 0 and args.profile_steps > 0:
-        _lib.PROFILE = []
+    if args.profile_steps > 0:
+        # every rank runs the extra steps (they contain the gradient all-reduce); only rank 0 records events
+        if rank == 0:
+            _lib.PROFILE = []
         for _ in range(args.profile_steps):
             trainer.train_step()
-        torch.cuda.synchronize()
+        barrier()
+    if rank == 0 and args.profile_steps > 0:
         for name, s, e in _lib.PROFILE:
             k = kernels.setdefault(name, [0, 0.0])
             k[0] += 1
