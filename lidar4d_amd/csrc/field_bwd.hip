@@ -130,27 +130,13 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
 
 }
 
-// Lanes of a wave should not work on consecutive samples of one ray here: those hit the SAME texel, and same-address
-// LDS atomics serialise 64-way.  A stride permutation (i -> i * 769 mod n, 769 prime ~ samples per ray) makes the
-// lanes of a wave walk ~64 different rays instead; it is a bijection whenever gcd(769, n) = 1.
-__device__ __forceinline__ int64_t stride_perm(int64_t i, int64_t n, int64_t stride) { return (i * stride) % n; }
-static int64_t pick_stride(int64_t n) {
-  const int64_t cands[] = {769, 773, 761, 757, 751, 1};
-  for (int64_t c : cands) {
-    int64_t a = n, b = c;
-    while (b) { int64_t t = a % b; a = b; b = t; }
-    if (a == 1) return c;
-  }
-  return 1;
-}
-
 // ------------------------------------------------------------------------------------------------
 // 2. time planes: all scales, all three frames, one pass; LDS window = 3 rows around t per plane
 // ------------------------------------------------------------------------------------------------
 #define TROWS 3
 __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
-                                                            int64_t P, int64_t chunk, int64_t stride, const half_t* __restrict__ dX,
+                                                            int64_t P, int64_t chunk, const half_t* __restrict__ dX,
                                                             int in_pad, float pscale, const float* __restrict__ stats,
                                                             half_t* __restrict__ dflow16) {
   constexpr int C = 8;
@@ -403,7 +389,7 @@ struct HashTasks {
 };
 
 __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTasks tasks, const float* __restrict__ xt, int64_t P,
-                                                         int64_t chunk, int64_t stride, const half_t* __restrict__ gdynT,
+                                                         int64_t chunk, const half_t* __restrict__ gdynT,
                                                          const float* __restrict__ stats, float* __restrict__ Hbuf) {
   extern __shared__ long long lds_l[];
   const int task = blockIdx.y;
@@ -535,8 +521,6 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, 8192)));
   const int64_t chunk = ceil_div64(P, n_chunks);
   n_chunks = (int)ceil_div64(P, chunk);
-  const int64_t stride = pick_stride(chunk);
-  (void)stride;
   // consecutive-lane = consecutive-sample-of-one-ray property, needed for the wave-level band skip
   const int wave_skip = samples_per_ray > 0 && samples_per_ray % 64 == 0 && chunk % 64 == 0;
 
@@ -548,7 +532,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
     hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
-                       tinfo, P, chunk, stride, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16);
+                       tinfo, P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16);
   }
   // static planes
   {
@@ -592,7 +576,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
     hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xt, P, chunk, (int64_t)1, gdynT, stats, Hbuf);
+    hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xt, P, chunk, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);
