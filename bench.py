@@ -37,7 +37,12 @@ WORKLOADS = {
            "C2-shaped: L=16 hash + 3-layer-64 sigma MLP, 4096 rays/batch (the reference has no static-only switch: the full 4D field runs)"),
     "c3-4k": (dict(), 4096, "full 4D, 4096 rays/batch/GPU training (staged-chunk size)"),
     "c3-1k": (dict(), 1024, "full 4D, 1024 rays/batch/GPU training (the reference's own num_rays_lidar)"),
+    # inference (BASELINE configs[4]): one step = one 64 x 2048 novel-view frame per GPU under no_grad --
+    # render(staged=True, 32 chunks of 4096 rays) + U-Net ray-drop refinement + masking (runner.py:438-470) +
+    # range image -> points -> chamfer distance / F-score against the ground-truth frame (utils/metrics.py:249-270)
+    "c5": (dict(), 64 * 2048, "C5: full LiDAR4D inference, 2048x64 novel-view render (staged) + U-Net ray-drop refinement + chamfer3D eval, one frame/GPU/step"),
 }
+INFERENCE = {"c5"}
 
 
 def algorithmic_bytes_per_sample(model):
@@ -132,8 +137,25 @@ def main():
     model_kw, n_rays, desc = WORKLOADS[args.workload]
     torch.manual_seed(0)  # identical initial replicas on every rank
     model = LiDAR4D(near_lidar=1.0 * KITTI360_SCALE, far_lidar=81.0 * KITTI360_SCALE, num_frames=51, **model_kw).to(dev)
-    data = SyntheticKitti360(dev, num_rays=n_rays, seed=1000 + rank)
+    inference = args.workload in INFERENCE
+    data = SyntheticKitti360(dev, W=2048 if inference else 1024, num_rays=n_rays, seed=1000 + rank)
     trainer = Trainer(model, data, chamfer=args.chamfer)
+    if inference:
+        from lidar4d_amd.data import KITTI360_FOV
+        from lidar4d_amd.metrics import PointsMeter
+        model.eval()
+        meter = PointsMeter(scale=KITTI360_SCALE, intrinsics=KITTI360_FOV)
+        frames = [data.frame((rank + world * k) % data.num_frames) for k in range(4)]  # resident before the timed region
+        counter = [0]
+
+        def step():
+            fr = frames[counter[0] % len(frames)]
+            counter[0] += 1
+            _, _, pred_depth = trainer.test_step(fr, refine=True)
+            gt = fr["images_lidar"]
+            meter.update(pred_depth, gt[..., 2] * gt[..., 0])
+    else:
+        step = trainer.train_step
 
     def barrier():
         if world > 1:
@@ -141,11 +163,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.train_step()
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.train_step()
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -161,7 +183,7 @@ def main():
         if rank == 0:
             _lib.PROFILE = []
         for _ in range(args.profile_steps):
-            trainer.train_step()
+            step()
         barrier()
     if rank == 0 and args.profile_steps > 0:
         for name, s, e in _lib.PROFILE:
@@ -176,7 +198,7 @@ def main():
         dominant = max((k for k in per_step if k not in aggregates), key=per_step.get)
         launches = kernels[dominant][0] / args.profile_steps
         avg_ms = kernels[dominant][1] / kernels[dominant][0]
-        P = n_rays * 768
+        P = min(n_rays, 4096) * 768 if inference else n_rays * 768  # staged inference launches per 4096-ray chunk
         bps = algorithmic_bytes_per_sample(model)
         alg = bps.get(dominant)
         traffic = None
@@ -199,7 +221,7 @@ def main():
     if rank == 0:
         total_rays = n_rays * world * args.steps
         line = {
-            "metric": "training rays/sec (64x1024 LiDAR panorama)",
+            "metric": "inference rays/sec (64x2048 novel-view frame)" if inference else "training rays/sec (64x1024 LiDAR panorama)",
             "value": total_rays / dt,
             "unit": "rays/s",
             "n_gpus": world,
@@ -212,11 +234,16 @@ def main():
             "dtype": "f16 tables/MFMA operands, f32 accumulate",
             "data": "synthetic",
             "config": {"workload": desc, "rays_per_gpu_per_step": n_rays, "samples_per_ray": 768,
-                       "global_rays_per_step": n_rays * world, "parallelism": f"ray-sharded dp{world}, 1 RCCL all-reduce/step",
-                       "step": "forward + backward + Adam, losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else " (no chamfer/flow loss)")},
+                       "global_rays_per_step": n_rays * world,
+                       "parallelism": f"frame-sharded x{world}, no collective" if inference else f"ray-sharded dp{world}, 1 RCCL all-reduce/step",
+                       "step": "no_grad render(staged=True, max_ray_batch=4096) + U-Net + pano_to_lidar + chamfer/F-score" if inference else
+                               "forward + backward + Adam, losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else " (no chamfer/flow loss)")},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if inference:
+            line["eval"] = {"chamfer_distance_m2, f_score@0.05": [float(v) for v in meter.measure()], "frames": meter.N,
+                            "note": "random-init field vs synthetic ground truth: exercises the eval path, not a quality claim"}
+        if world == 1 and not args.no_cpu_baseline and not inference:
             line["cpu_baseline"] = cpu_baseline(51, KITTI360_SCALE)
         print(json.dumps(line))
     if world > 1:

@@ -225,6 +225,22 @@ int l4d_chamfer_bwd(const float* xyz1, const float* xyz2, int32_t b, int32_t n, 
                     const float* grad_dist2, const int32_t* idx1, const int32_t* idx2, float* grad_xyz1,
                     float* grad_xyz2, void* stream);
 
+/* ---- range image <-> point cloud : utils/convert.py:4-156 (SURVEY 8f "next" row 4) ----
+ * pano_to_lidar_with_intensities (convert.py:99-137): pano [H,W] fp32 range image (0 = no return), intensities [H,W]
+ * or null (-> 0); lidar_K = (fov_up, fov) in degrees.  points: room for H*W rows [x,y,z,intensity]; the non-empty
+ * pixels are written in row-major pixel order (np.where order), their number to *count (device int32).
+ * workspace: l4d_pano_to_lidar_workspace() bytes. */
+int64_t l4d_pano_to_lidar_workspace(int32_t H, int32_t W);
+int l4d_pano_to_lidar(const float* pano, const float* intensities, int32_t H, int32_t W, double fov_up, double fov,
+                      float* points, int32_t* count, void* workspace, void* stream);
+/* lidar_to_pano_with_intensities (convert.py:4-66): points [n,4] fp32 (x,y,z,intensity) -> pano [H,W] = range of the
+ * closest point that falls into each pixel (0 if none), intensities [H,W] (or null) = that point's intensity; of equally
+ * close points the first in the array wins, like the reference's sequential loop.  Points at range >= max_depth or
+ * outside the image are dropped.  workspace: l4d_lidar_to_pano_workspace() bytes. */
+int64_t l4d_lidar_to_pano_workspace(int32_t H, int32_t W);
+int l4d_lidar_to_pano(const float* points, int64_t n, int32_t H, int32_t W, double fov_up, double fov, float max_depth,
+                      float* pano, float* intensities, void* workspace, void* stream);
+
 /* ---- optimiser + casts (runner.py:506-508 Adam step; tcnn's per-forward fp32->fp16 param cast) ---- */
 int l4d_cast_f32_to_f16(const float* src, void* dst, int64_t n, void* stream);
 int l4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16 /*or null*/,

@@ -51,7 +51,7 @@ class FieldGrads(C.Structure):
     ]
 
 
-P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+P, I32, I64, F32, F64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 GD, FD, FG = C.POINTER(GridDesc), C.POINTER(FieldDesc), C.POINTER(FieldGrads)
 PI32 = C.POINTER(C.c_int32)
 PI64 = C.POINTER(C.c_int64)
@@ -89,6 +89,10 @@ SIGNATURES = {
     "l4d_chamfer_workspace": [I32, I32, I32],
     "l4d_chamfer_fwd": [P, P, I32, I32, I32, P, P, P, P, P, P],
     "l4d_chamfer_bwd": [P, P, I32, I32, I32, P, P, P, P, P, P, P],
+    "l4d_pano_to_lidar_workspace": [I32, I32],
+    "l4d_pano_to_lidar": [P, P, I32, I32, F64, F64, P, P, P, P],
+    "l4d_lidar_to_pano_workspace": [I32, I32],
+    "l4d_lidar_to_pano": [P, I64, I32, I32, F64, F64, F32, P, P, P, P],
     "l4d_cast_f32_to_f16": [P, P, I64, P],
     "l4d_adam_step": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, F32, F32, P],
 }

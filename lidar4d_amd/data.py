@@ -97,6 +97,20 @@ class SyntheticKitti360:
             frame = int(torch.randint(0, self.num_frames, [1], generator=self.frame_gen))
         return self.batch_for(frame)
 
+    def frame(self, frame, W=None):
+        """Every ray of one frame, as the evaluation / simulation loops feed ``render(staged=True)``
+        (kitti360_dataset.py:150-180 with num_rays = -1).  ``W`` overrides the image width (novel-view renders use
+        2048 columns, BASELINE config 5); ground truth is only attached at the dataset's own width."""
+        W = W or self.W
+        pose = self.poses[frame:frame + 1]
+        rays = get_lidar_rays(pose, self.fov, self.H, W, -1)
+        t = torch.tensor([[frame / (self.num_frames - 1)]], dtype=torch.float32, device=self.device)
+        out = {"rays_o_lidar": rays["rays_o"], "rays_d_lidar": rays["rays_d"], "time": t, "poses_lidar": pose,
+               "H_lidar": self.H, "W_lidar": W, "index": [frame]}
+        if W == self.W:
+            out["images_lidar"] = self.images[frame:frame + 1]
+        return out
+
     def batch_for(self, frame):
         pose = self.poses[frame:frame + 1]
         rays = get_lidar_rays(pose, self.fov, self.H, self.W, self.num_rays, generator=self.gen)

@@ -7,7 +7,8 @@
 * ``density`` / ``attribute`` / ``flow`` -> operator-level modules, for callers that use them directly
   (runner.py:227,252 calls ``flow``).
 
-Not built in this round (SURVEY 8f "next" rows): the U-Net ray-drop refinement (``self.unet`` is None).
+``self.unet`` is the ray-drop refinement network (lidar4d.py:119, lidar4d_amd/unet.py): dense convolutions through
+MIOpen; it is not part of the flat parameter arenas (the reference trains it separately, runner.py:872).
 """
 import numpy as np
 import torch
@@ -21,6 +22,7 @@ from .hash_field import HashGrid4D, _t_device
 from .params import ParamStore
 from .planes_field import Planes4D
 from .renderer import LiDAR_Renderer
+from .unet import UNet
 
 
 class LiDAR4D(LiDAR_Renderer):
@@ -56,7 +58,7 @@ class LiDAR4D(LiDAR_Renderer):
                              hidden_dim_sigma, num_layers_sigma)
         self.intensity_net = net(self.view_encoder.n_output_dims + geo_feat_dim, 1, hidden_dim_lidar, num_layers_lidar)
         self.raydrop_net = net(self.view_encoder.n_output_dims + geo_feat_dim, 1, hidden_dim_lidar, num_layers_lidar)
-        self.unet = None  # SURVEY 8f rank 3, not on the named path
+        self.unet = UNet(in_channels=3, out_channels=1)  # lidar4d.py:119
         self._build_store()
 
     # -- flat parameter arenas -----------------------------------------------------------------------------
@@ -99,8 +101,9 @@ class LiDAR4D(LiDAR_Renderer):
         elif noise is not None:
             noise = noise.to(device=device, dtype=torch.float32).contiguous()
         t_dev = _t_device(time, device)
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        params = [p for p in self.parameters() if p.requires_grad] if train else []
+        field_params = [p for _, p, _, n, _ in self._store.entries if n > 0]
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in field_params)
+        params = [p for p in field_params if p.requires_grad] if train else []
         depth, image, wsum, weights, z_vals, idx, count = RenderFn.apply(self, rays_o, rays_d, t_dev, noise, num_steps,
                                                                         train, *params)
         return {

@@ -1,0 +1,51 @@
+"""Point-cloud evaluation on the device.  Mirror of the reference's ``fscore`` and ``PointsMeter``
+(utils/metrics.py:13-27, 224-274): range image -> points (lidar4d_amd/convert.py instead of numpy) -> chamfer distance
+(lidar4d_amd/chamfer.py instead of the CUDA extension) -> chamfer distance + F-score at 0.05 (squared-distance
+threshold, as the reference uses it).  Nothing leaves the GPU until ``measure()``.
+"""
+import numpy as np
+import torch
+
+from .chamfer import chamfer_3DDist
+from .convert import pano_to_lidar
+
+
+def fscore(dist1, dist2, threshold=0.001):
+    """utils/metrics.py:13-27 (dist1/dist2 are squared distances [B, n])."""
+    precision_1 = torch.mean((dist1 < threshold).float(), dim=1)
+    precision_2 = torch.mean((dist2 < threshold).float(), dim=1)
+    f = 2 * precision_1 * precision_2 / (precision_1 + precision_2)
+    f[torch.isnan(f)] = 0
+    return f, precision_1, precision_2
+
+
+class PointsMeter:
+    def __init__(self, scale, intrinsics):
+        self.V = []
+        self.N = 0
+        self.scale = scale
+        self.intrinsics = intrinsics
+
+    def clear(self):
+        self.V = []
+        self.N = 0
+
+    def update(self, preds, truths):
+        """preds, truths: [B, H, W] range images in scene units (depth * scale); only element 0 is used, like the
+        reference (utils/metrics.py:253-254)."""
+        preds = preds / self.scale
+        truths = truths / self.scale
+        pred_lidar = pano_to_lidar(preds[0], self.intrinsics)
+        gt_lidar = pano_to_lidar(truths[0], self.intrinsics)
+        dist1, dist2, _, _ = chamfer_3DDist()(pred_lidar[None], gt_lidar[None])
+        chamfer_dis = dist1.mean() + dist2.mean()
+        f_score, _, _ = fscore(dist1, dist2, 0.05)
+        self.V.append(torch.stack([chamfer_dis, f_score[0]]))  # stays on the device
+        self.N += 1
+
+    def measure(self):
+        assert self.N == len(self.V)
+        return torch.stack(self.V).mean(0).cpu().numpy().astype(np.float64)
+
+    def report(self):
+        return f"CD f-score = {self.measure()}"

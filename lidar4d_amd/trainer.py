@@ -2,8 +2,9 @@
 schedule, and ray-sharded data parallelism with one RCCL all-reduce of the flat gradient arena.
 
 Restates only what `training rays/s` needs from the reference's Trainer (model/runner.py:166-213,474-551;
-optimizer main_lidar4d.py:298-305); chamfer / flow losses, EMA, checkpoints and logging are out of scope
-(SURVEY.md section 2 row 8, section 8f).
+optimizer main_lidar4d.py:298-305) plus the inference step of the evaluation / simulation loops
+(runner.py:438-470: staged render of a whole frame, U-Net ray-drop refinement, masking).  Flow loss, EMA,
+checkpoints and logging are out of scope.
 """
 import torch
 import torch.distributed as dist
@@ -97,3 +98,26 @@ class Trainer:
             dist.all_reduce(self.model._store.flat_grad, op=dist.ReduceOp.SUM)
         self.opt.step()
         return loss
+
+    @torch.no_grad()
+    def test_step(self, data, refine=True, perturb=False, max_ray_batch=4096, raydrop_loss="mse", alpha_r=0.01):
+        """runner.py:438-470: render every ray of a frame in chunks (staged), refine the ray-drop probability with the
+        U-Net on the stacked [ray-drop, intensity, depth] image, mask intensity and depth by ray-drop > 0.5.
+        data: ``rays_o_lidar``/``rays_d_lidar`` [B, H*W, 3], ``time`` [B,1], ``H_lidar``, ``W_lidar``.
+        Returns (pred_raydrop [1,H,W], pred_intensity [B,H,W], pred_depth [B,H,W])."""
+        H, W = data["H_lidar"], data["W_lidar"]
+        out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=True, perturb=perturb,
+                                max_ray_batch=max_ray_batch, num_steps=self.num_steps)
+        image = out["image_lidar"].reshape(-1, H, W, 2)
+        pred_raydrop, pred_intensity = image[..., 0], image[..., 1]
+        pred_depth = out["depth_lidar"].reshape(-1, H, W)
+        if raydrop_loss == "bce":
+            pred_raydrop = torch.sigmoid(pred_raydrop)
+        if refine:
+            stacked = torch.cat([pred_raydrop, pred_intensity, pred_depth], dim=0).unsqueeze(0)
+            pred_raydrop = self.model.unet(stacked).squeeze(0)
+        raydrop_mask = torch.where(pred_raydrop > 0.5, 1, 0)
+        if alpha_r > 0:
+            pred_intensity = pred_intensity * raydrop_mask
+            pred_depth = pred_depth * raydrop_mask
+        return pred_raydrop, pred_intensity, pred_depth

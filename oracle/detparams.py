@@ -68,3 +68,43 @@ def grad_digest(model):
         probe = torch.from_numpy(unit_hash(g.numel(), "probe:" + name)).double() - 0.5
         out[name] = np.array([g.sum().item(), g.abs().sum().item(), (g * probe).sum().item()])
     return out
+
+
+def fill_unet(unet, seed=0):
+    """Deterministic fill of a U-Net shaped module tree (reference model/unet.py or lidar4d_amd/unet.py: same
+    state-dict keys): conv weights U(-b, b) with b = sqrt(3 / fan_in), conv biases U(-0.1, 0.1), batch-norm scale
+    U(0.5, 1.5), shift and running mean U(-0.2, 0.2), running variance U(0.5, 1.5)."""
+    with torch.no_grad():
+        for name, t in list(unet.named_parameters()) + list(unet.named_buffers()):
+            key = f"unet{seed}:{name}"
+            leaf = name.split(".")[-1]
+            if leaf == "num_batches_tracked":
+                continue
+            if t.dim() == 4:
+                b = float(np.sqrt(3.0 / (t.shape[1] * t.shape[2] * t.shape[3])))
+                lo, hi = -b, b
+            elif leaf == "running_var" or (leaf == "weight" and t.dim() == 1):
+                lo, hi = 0.5, 1.5
+            elif leaf == "running_mean" or leaf == "bias":
+                lo, hi = (-0.2, 0.2) if leaf == "running_mean" or "conv" not in name.split(".")[-2:] else (-0.1, 0.1)
+            else:
+                raise KeyError(name)
+            t.copy_(det_uniform(tuple(t.shape), key, lo, hi).to(t.dtype))
+    return unet
+
+
+def convert_inputs(H=64, W=1024):
+    """(depth [H,W], intensity [H,W], cloud [6000,4]) float32 numpy: the inputs of the conversion fixtures."""
+    depth = det_uniform((H, W), "cv_depth", 1.5, 79.0).numpy()
+    depth[unit_hash(H * W, "cv_drop").reshape(H, W) < 0.1] = 0.0  # 10 % dropped rays
+    inten = det_uniform((H, W), "cv_int", 0.0, 1.0).numpy()
+    # a cloud that does not sit on pixel centres, with duplicates per pixel, far points and out-of-fov points
+    n = 6000
+    az = det_uniform((n,), "cv_az", -np.pi, np.pi).numpy()
+    el = det_uniform((n,), "cv_el", np.deg2rad(-30.0), np.deg2rad(6.0)).numpy()
+    rng = det_uniform((n,), "cv_r", 0.5, 95.0).numpy()
+    cloud = np.stack([rng * np.cos(el) * np.cos(az), rng * np.cos(el) * np.sin(az), rng * np.sin(el),
+                      det_uniform((n,), "cv_i", 0.0, 1.0).numpy()], -1).astype(np.float32)
+    cloud[100:200] = cloud[0:100]            # exact duplicates (first wins)
+    cloud[200:300, :3] = cloud[0:100, :3]    # same position, other intensity
+    return depth, inten, cloud

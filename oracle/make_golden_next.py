@@ -1,0 +1,66 @@
+"""Fixtures for the SURVEY 8f "next" rows (U-Net refinement, range-image <-> point-cloud conversions), produced by
+running the REAL reference code.  Build container only:
+
+    python -m oracle.make_golden_next       # needs /root/reference; writes tests/golden/{unet_eval,convert}.npz
+
+Same policy as make_golden.py: the reference is imported from a throw-away scratch copy, only inputs / expected outputs /
+key lists are saved.  TEST INFRASTRUCTURE.
+"""
+import shutil
+import sys
+
+import numpy as np
+import torch
+
+from oracle.detparams import convert_inputs, det_uniform, fill_unet
+from oracle.make_golden import _import_reference, save
+
+
+def gen_unet():
+    import model.unet as ref_unet  # from the scratch copy (sys.path set by _import_reference)
+
+    net = fill_unet(ref_unet.UNet(in_channels=3, out_channels=1), seed=0).eval()
+    keys = list(net.state_dict().keys())
+    shapes = [list(v.shape) for v in net.state_dict().values()]
+    out = {}
+    for tag, (b, h, w) in {"a": (2, 32, 96), "b": (1, 34, 70)}.items():  # "b": odd sizes exercise the centre padding
+        x = det_uniform((b, 3, h, w), "unet_in_" + tag, 0.0, 1.0).requires_grad_(True)
+        y = net(x)
+        gy = det_uniform(tuple(y.shape), "unet_gy_" + tag, -1.0, 1.0)
+        net.zero_grad()
+        (y * gy).sum().backward()
+        out["x_" + tag], out["y_" + tag], out["gy_" + tag], out["gx_" + tag] = x.detach(), y.detach(), gy, x.grad
+        out["gw_inc_" + tag] = net.inc.conv.weight.grad.clone()
+        g = net.attn.proj_qkv.weight.grad.double()
+        out["gw_attn_digest_" + tag] = np.array([g.sum().item(), g.abs().sum().item()])
+    save("unet_eval", keys=np.array(keys), shapes=np.array([str(s) for s in shapes]),
+         n_params=sum(p.numel() for p in net.parameters()), **out)
+
+
+def gen_convert():
+    import utils.convert as ref_conv
+
+    H, W, K = 64, 1024, (2.0, 26.9)
+    depth, inten, cloud = convert_inputs(H, W)
+    pts = ref_conv.pano_to_lidar_with_intensities(depth, inten, K)
+    pts3 = ref_conv.pano_to_lidar(depth, K)
+    Hs, Ws = 32, 256
+    pano, pint = ref_conv.lidar_to_pano_with_intensities(cloud, Hs, Ws, K, max_depth=80)
+    # round trip of the reference at full size: points of a range image fall back into their own pixels
+    pano_rt, pint_rt = ref_conv.lidar_to_pano_with_intensities(pts.astype(np.float32)[::16], H, W, K)
+    assert pts.dtype == np.float32 and np.array_equal(pts[:, :3], pts3)
+    # inputs are regenerated from the same deterministic formulas by the tests (oracle.detparams.convert_inputs): only outputs are stored
+    save("convert", H=H, W=W, K=np.array(K), pts=pts, Hs=Hs, Ws=Ws, pano=pano.astype(np.float32), pint=pint.astype(np.float32),
+         pano_rt=pano_rt.astype(np.float32), pint_rt=pint_rt.astype(np.float32))
+
+
+def main():
+    torch.set_num_threads(8)
+    R = _import_reference()
+    gen_unet()
+    gen_convert()
+    shutil.rmtree(R["scratch"], ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,8 @@ def test_state_dict_contract_and_param_counts():
             "intensity_net.params", "raydrop_net.params"}
     want |= {f"planes_encoder.planes.{s}.{c}" for s in range(4) for c in range(6)}
     want |= {f"hash_encoder.hash_dynamic.{p}.hash_t.{k}.params" for p in range(3) for k in range(8)}
+    unet_keys = set(np.load(os.path.join(os.path.dirname(__file__), "golden", "unet_eval.npz"))["keys"])
+    want |= {"unet." + k for k in unet_keys}  # lidar4d.py:119; key list recorded from the reference's UNet
     assert set(sd.keys()) == want
     assert tuple(sd["planes_encoder.planes.3.0"].shape) == (1, 8, 256, 256)
     assert tuple(sd["planes_encoder.planes.1.2"].shape) == (1, 8, 8, 64)  # time plane: [1,8,8,R]
@@ -72,7 +74,7 @@ def test_state_dict_contract_and_param_counts():
     assert sd["flow_net.grid_enc.params"].numel() == 14942208
     assert sd["sigma_net.params"].numel() == 9216 and sd["intensity_net.params"].numel() == 11264
     assert tuple(sd["flow_net.mlp.4.weight"].shape) == (6, 64) and sd["view_encoder.params"].numel() == 0
-    n = sum(p.numel() for p in m.parameters())
+    n = sum(p.numel() for k, p in m.named_parameters() if not k.startswith("unet."))
     assert n == 2181120 + 16777216 + 12582912 + 14942208 + 5504 + 31744
     # optimizer groups as lidar4d.py:226-237
     groups = m.get_params(1e-2)

@@ -1,0 +1,181 @@
+"""SURVEY 8f "next" rows 3 and 4: U-Net ray-drop refinement and the range-image <-> point-cloud conversions, against
+fixtures produced by the reference's own code (oracle/make_golden_next.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import convert_ref
+from oracle.detparams import convert_inputs, fill_unet
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _unet():
+    from lidar4d_amd.unet import UNet
+    return fill_unet(UNet(in_channels=3, out_channels=1), seed=0).eval()
+
+
+def _check_unet(dev, tol):
+    g = np.load(os.path.join(GOLD, "unet_eval.npz"))
+    net = _unet().to(dev)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["keys"]), "state-dict keys (and their order) must equal the reference's"
+    assert [str(list(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    for tag in ("a", "b"):
+        x = torch.from_numpy(g["x_" + tag]).to(dev).requires_grad_(True)
+        y = net(x)
+        assert y.shape == g["y_" + tag].shape
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g["y_" + tag], atol=tol, rtol=0)
+        net.zero_grad()
+        (y * torch.from_numpy(g["gy_" + tag]).to(dev)).sum().backward()
+        scale = np.abs(g["gx_" + tag]).max()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g["gx_" + tag], atol=10 * tol * scale, rtol=0)
+        gw = g["gw_inc_" + tag]
+        np.testing.assert_allclose(net.inc.conv.weight.grad.cpu().numpy(), gw, atol=10 * tol * np.abs(gw).max(), rtol=0)
+        ga = net.attn.proj_qkv.weight.grad.double()
+        np.testing.assert_allclose([ga.sum().item(), ga.abs().sum().item()], g["gw_attn_digest_" + tag],
+                                   rtol=100 * tol, atol=1e-6)
+
+
+def test_unet_matches_reference_cpu():
+    _check_unet("cpu", 2e-6)
+
+
+@pytest.mark.gpu
+def test_unet_matches_reference_gpu():
+    # MIOpen convolutions (fp32): different summation order than the CPU run that made the fixture
+    _check_unet("cuda", 2e-5)
+
+
+@pytest.mark.gpu
+def test_model_carries_unet_and_refines():
+    from lidar4d_amd import LiDAR4D
+    from oracle.make_golden import SMALL_MODEL
+    m = LiDAR4D(**SMALL_MODEL).cuda()
+    assert any(k.startswith("unet.inc.conv") for k in m.state_dict())
+    # runner.py:413-416: refine the stacked [raydrop, intensity, depth] image
+    img = torch.rand(3, 32, 64, device="cuda")
+    m.unet.eval()
+    out = m.unet(img.unsqueeze(0)).squeeze(0)
+    assert out.shape == (1, 32, 64) and float(out.min()) >= 0 and float(out.max()) <= 1
+    # the render optimiser groups do not contain the U-Net (lidar4d.py:226-237; it has its own Adam, runner.py:872)
+    ids = {id(p) for g in m.get_params(1e-2) for p in g["params"]}
+    assert not any(id(p) in ids for p in m.unet.parameters())
+
+
+def test_convert_oracle_pinned_to_reference():
+    g = np.load(os.path.join(GOLD, "convert.npz"))
+    depth, inten, cloud = convert_inputs(int(g["H"]), int(g["W"]))
+    K = tuple(g["K"])
+    pts = convert_ref.pano_to_lidar_with_intensities(depth, inten, K)
+    assert pts.dtype == np.float32 and np.array_equal(pts, g["pts"])
+    pano, pint = convert_ref.lidar_to_pano_with_intensities(cloud, int(g["Hs"]), int(g["Ws"]), K)
+    assert np.array_equal(pano, g["pano"]) and np.array_equal(pint, g["pint"])
+    pano, pint = convert_ref.lidar_to_pano_with_intensities(g["pts"][::16], int(g["H"]), int(g["W"]), K)
+    assert np.array_equal(pano, g["pano_rt"]) and np.array_equal(pint, g["pint_rt"])
+
+
+@pytest.mark.gpu
+def test_pano_to_lidar_gpu():
+    from lidar4d_amd import convert
+    g = np.load(os.path.join(GOLD, "convert.npz"))
+    depth, inten, _ = convert_inputs(int(g["H"]), int(g["W"]))
+    K = tuple(g["K"])
+    pts = convert.pano_to_lidar_with_intensities(torch.from_numpy(depth).cuda(), torch.from_numpy(inten).cuda(), K)
+    ref = g["pts"]
+    assert pts.shape == ref.shape, "same pixels kept, same (row-major) order"
+    out = pts.cpu().numpy()
+    assert np.array_equal(out[:, 3], ref[:, 3]), "intensities are copied: bit-exact, which also proves the order"
+    # coordinates: fp32 sin/cos of the device library vs numpy's, <= 2 ulp of the range
+    np.testing.assert_allclose(out[:, :3], ref[:, :3], rtol=0, atol=3e-7 * 80)
+    p3 = convert.pano_to_lidar(torch.from_numpy(depth).cuda(), K)
+    assert torch.equal(p3, pts[:, :3])
+    buf, count = convert.pano_to_lidar_with_intensities(torch.from_numpy(depth).cuda(), None, K, return_count=True)
+    assert int(count) == ref.shape[0] and buf.shape == (depth.size, 4) and float(buf[: int(count), 3].abs().max()) == 0
+    # empty and full images
+    z = torch.zeros(8, 16, device="cuda")
+    assert convert.pano_to_lidar(z, K).shape == (0, 3)
+    assert convert.pano_to_lidar(z + 1, K).shape == (128, 3)
+
+
+@pytest.mark.gpu
+def test_lidar_to_pano_gpu():
+    from lidar4d_amd import convert
+    g = np.load(os.path.join(GOLD, "convert.npz"))
+    _, _, cloud = convert_inputs(int(g["H"]), int(g["W"]))
+    K = tuple(g["K"])
+    for pts, H, W, pano_ref, pint_ref in ((cloud, int(g["Hs"]), int(g["Ws"]), g["pano"], g["pint"]),
+                                          (g["pts"][::16], int(g["H"]), int(g["W"]), g["pano_rt"], g["pint_rt"])):
+        pano, pint = convert.lidar_to_pano_with_intensities(torch.from_numpy(np.ascontiguousarray(pts)).cuda(), H, W, K)
+        pano, pint = pano.cpu().numpy(), pint.cpu().numpy()
+        # a point whose angle sits within an ulp of a pixel boundary may land in the neighbouring pixel (device atan2f
+        # vs libm's); everything else must be bit-identical
+        bad = (pano != pano_ref) | (pint != pint_ref)
+        assert bad.mean() < 2e-3, f"{bad.sum()} of {bad.size} pixels differ"
+    # empty cloud -> empty image
+    pano, pint = convert.lidar_to_pano_with_intensities(torch.zeros(0, 4, device="cuda"), 8, 16, K)
+    assert float(pano.abs().max()) == 0 and float(pint.abs().max()) == 0
+    # pano -> points -> pano is the identity on the occupied pixels (size-independent property, full 64 x 2048 frame)
+    H, W = 64, 2048
+    depth = torch.rand(H, W, device="cuda") * 70 + 2
+    depth[torch.rand(H, W, device="cuda") < 0.1] = 0
+    inten = torch.rand(H, W, device="cuda")
+    pts = convert.pano_to_lidar_with_intensities(depth, inten, K)
+    back, iback = convert.lidar_to_pano_with_intensities(pts, H, W, K)
+    occupied = depth != 0
+    same = (back - depth).abs() <= 1e-5 * depth
+    # (column 0 sits on the atan2 branch cut, beta = +-pi: the reference's projection sends half of it to c = W, out of bounds)
+    assert float(same[:, 1:][occupied[:, 1:]].float().mean()) > 0.999
+    assert float((iback == inten)[:, 1:][occupied[:, 1:]].float().mean()) > 0.999
+
+
+@pytest.mark.gpu
+def test_points_meter_and_test_step_gpu():
+    """utils/metrics.py:249-270 + runner.py:438-470 on the device, against the CPU restatements."""
+    from lidar4d_amd import LiDAR4D
+    from lidar4d_amd.data import KITTI360_FOV, KITTI360_SCALE, SyntheticKitti360
+    from lidar4d_amd.metrics import PointsMeter
+    from lidar4d_amd.trainer import Trainer
+    from oracle import chamfer_ref
+    from oracle.make_golden import SMALL_MODEL
+    torch.manual_seed(0)
+    H, W = 16, 128
+    data = SyntheticKitti360("cuda", H=H, W=W, num_frames=5, num_rays=256)
+    model = LiDAR4D(near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE, num_frames=5, **SMALL_MODEL).cuda().eval()
+    tr = Trainer(model, data, num_steps=96)
+    fr = data.frame(2)
+    assert fr["rays_d_lidar"].shape == (1, H * W, 3) and fr["images_lidar"].shape == (1, H, W, 3)
+    rd, ri, dep = tr.test_step(fr, refine=True, max_ray_batch=300)   # ragged last chunk
+    assert rd.shape == (1, H, W) and ri.shape == (1, H, W) and dep.shape == (1, H, W)
+    # staged == one un-chunked call (rays are independent), and the masking rule
+    with torch.no_grad():
+        full = model.render(fr["rays_o_lidar"], fr["rays_d_lidar"], fr["time"], staged=False, perturb=False, num_steps=96)
+        img = full["image_lidar"].reshape(1, H, W, 2)
+        stacked = torch.cat([img[..., 0], img[..., 1], full["depth_lidar"].reshape(1, H, W)], 0).unsqueeze(0)
+        rd_ref = model.unet(stacked).squeeze(0)
+    assert torch.allclose(rd, rd_ref, atol=1e-5)
+    keep = (rd_ref > 0.5).float()
+    assert torch.allclose(dep, full["depth_lidar"].reshape(1, H, W) * keep, atol=1e-6)
+    rd2, _, dep2 = tr.test_step(fr, refine=False)
+    assert torch.allclose(rd2, img[..., 0], atol=1e-6)
+    # PointsMeter vs numpy conversion + brute-force chamfer
+    gt = fr["images_lidar"]
+    gt_depth = gt[..., 2] * gt[..., 0]
+    pred = gt_depth * (1 + 0.05 * torch.rand_like(gt_depth))
+    pred[0, :2] = 0  # some dropped rows
+    meter = PointsMeter(scale=KITTI360_SCALE, intrinsics=KITTI360_FOV)
+    meter.update(pred, gt_depth)
+    meter.update(gt_depth, gt_depth)
+    p = convert_ref.pano_to_lidar_with_intensities((pred[0] / KITTI360_SCALE).cpu().numpy(), np.zeros((H, W), np.float32), KITTI360_FOV)[:, :3]
+    q = convert_ref.pano_to_lidar_with_intensities((gt_depth[0] / KITTI360_SCALE).cpu().numpy(), np.zeros((H, W), np.float32), KITTI360_FOV)[:, :3]
+    d1, d2, _, _ = chamfer_ref.chamfer(torch.from_numpy(p)[None], torch.from_numpy(q)[None])
+    cd = float(d1.mean() + d2.mean())
+    p1, p2 = float((d1 < 0.05).float().mean()), float((d2 < 0.05).float().mean())
+    f = 2 * p1 * p2 / (p1 + p2)
+    v = torch.stack(meter.V).cpu().numpy()
+    np.testing.assert_allclose(v[0], [cd, f], rtol=2e-4)
+    np.testing.assert_allclose(v[1], [0.0, 1.0], atol=1e-9)
+    assert meter.measure().shape == (2,)
