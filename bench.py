@@ -203,7 +203,7 @@ def main():
         alg = bps.get(dominant)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "c3":  # PMC passes were collected on the default workload
             traffic = json.load(open(tpath)).get(dominant)
         if alg is not None:
             achieved = alg * P / (avg_ms * 1e-3) / 1e9

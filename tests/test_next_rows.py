@@ -60,7 +60,7 @@ def test_model_carries_unet_and_refines():
     img = torch.rand(3, 32, 64, device="cuda")
     m.unet.eval()
     out = m.unet(img.unsqueeze(0)).squeeze(0)
-    assert out.shape == (1, 32, 64) and float(out.min()) >= 0 and float(out.max()) <= 1
+    assert out.shape == (1, 32, 64) and float(out.detach().min()) >= 0 and float(out.detach().max()) <= 1
     # the render optimiser groups do not contain the U-Net (lidar4d.py:226-237; it has its own Adam, runner.py:872)
     ids = {id(p) for g in m.get_params(1e-2) for p in g["params"]}
     assert not any(id(p) in ids for p in m.unet.parameters())
@@ -144,7 +144,7 @@ def test_points_meter_and_test_step_gpu():
     torch.manual_seed(0)
     H, W = 16, 128
     data = SyntheticKitti360("cuda", H=H, W=W, num_frames=5, num_rays=256)
-    model = LiDAR4D(near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE, num_frames=5, **SMALL_MODEL).cuda().eval()
+    model = LiDAR4D(**dict(SMALL_MODEL, num_frames=5, near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE)).cuda().eval()
     tr = Trainer(model, data, num_steps=96)
     fr = data.frame(2)
     assert fr["rays_d_lidar"].shape == (1, H * W, 3) and fr["images_lidar"].shape == (1, H, W, 3)
