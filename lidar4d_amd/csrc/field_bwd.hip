@@ -214,8 +214,6 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
         for (int j = 0; j < 3; ++j) {
           const Tap& t = taps[j];
           const int W = fd.planes.res[s][j];
-          const float wts[4] = {t.wx0 * t.wy0, t.wx1 * t.wy0, t.wx0 * t.wy1, t.wx1 * t.wy1};
-          const int ys[4] = {t.y0, t.y0, t.y1, t.y1}, xs_[4] = {t.x0, t.x1, t.x0, t.x1};
           float gv[C];
 #pragma unroll
           for (int k = 0; k < C; ++k) gv[k] = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
@@ -227,29 +225,39 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
             coord_grad_from_taps<C>(tv, t, gv, gix, giy);
             gflow[(e - 1) * 3 + j] += gix * t.mx;
           }
+          // t is the same for the whole launch, so both time rows (y0, y1) and their weights are wave-uniform: merge the
+          // x0- and x1-column contributions once (2 merges instead of 4) and apply the row weights when issuing
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int rr = ys[q] - r_lo(s);
-            const bool in_win = rr >= 0 && rr < TROWS;
-            const uint32_t key = (uint32_t)(ys[q] * W + xs_[q]);
+          for (int qx = 0; qx < 2; ++qx) {
+            const int xq = qx == 0 ? t.x0 : t.x1;
+            const float wx = qx == 0 ? t.wx0 : t.wx1;
             float vals[C];
 #pragma unroll
-            for (int k = 0; k < C; ++k) vals[k] = gv[k] * wts[q];
-            if (!row_merge<C>(key, active, vals)) continue;
-            if (in_win) {
-              int* dst = &lds_i[lds_off(s, j) + (rr * W + xs_[q]) * C];
+            for (int k = 0; k < C; ++k) vals[k] = gv[k] * wx;
+            if (!row_merge<C>((uint32_t)xq, active, vals)) continue;
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy) {
+              const int yq = qy == 0 ? t.y0 : t.y1;
+              const float wy = qy == 0 ? t.wy0 : t.wy1;
+              if (wy == 0.0f) continue;
+              const int rr = yq - r_lo(s);
+              if (rr >= 0 && rr < TROWS) {
+                int* dst = &lds_i[lds_off(s, j) + (rr * W + xq) * C];
 #ifndef ABL_NO_LDS_ATOMICS
 #pragma unroll
-              for (int k = 0; k < C; ++k)
-                if (vals[k] != 0.0f) atomicAdd(dst + k, __float2int_rn(vals[k] * fxs));
+                for (int k = 0; k < C; ++k) {
+                  const int iv = __float2int_rn(vals[k] * wy * fxs);
+                  if (iv != 0) atomicAdd(dst + k, iv);
+                }
 #else
-              asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
+                asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
 #endif
-            } else {  // outside the LDS window (only for exotic num_frames / time_resolution): direct
-              float* dst = garena + fd.planes.off[s][cis[j]] + ((size_t)ys[q] * W + xs_[q]) * C;
+              } else {  // outside the LDS window (only for exotic num_frames / time_resolution): direct
+                float* dst = garena + fd.planes.off[s][cis[j]] + ((size_t)yq * W + xq) * C;
 #pragma unroll
-              for (int k = 0; k < C; ++k)
-                if (vals[k] != 0.0f) atomicAdd(dst + k, vals[k] * pscale);
+                for (int k = 0; k < C; ++k)
+                  if (vals[k] != 0.0f) atomicAdd(dst + k, vals[k] * wy * pscale);
+              }
             }
           }
         }

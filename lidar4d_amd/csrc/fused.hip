@@ -22,6 +22,9 @@ __global__ void time_setup_kernel(const float* __restrict__ t, int num_frames, f
   tinfo[5] = (float)f;
 }
 
+#ifndef ENC_SCHED_LEVEL
+#define ENC_SCHED_LEVEL 0
+#endif
 template <int C>
 __device__ __forceinline__ void planes_group(const FieldDesc& fd, int s, const float coord[4], bool time_group, float out[C]) {
 #pragma unroll
@@ -37,7 +40,13 @@ __device__ __forceinline__ void planes_group(const FieldDesc& fd, int s, const f
     sample_plane<C>(fd.planes_cl + fd.planes.off[s][ci], W, t, v);
 #pragma unroll
     for (int k = 0; k < C; ++k) out[k] = j == 0 ? v[k] : out[k] * v[k];
+#if ENC_SCHED_LEVEL >= 2
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
+#if ENC_SCHED_LEVEL >= 1
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
@@ -53,15 +62,21 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 // the lanes' rows over the banks) and each wave then writes its 64 rows as full 16-B-per-lane coalesced stores.
 #define ENC_THREADS 128
 #define ENC_MAX_IN_PAD 192  // widest network input row (BASELINE config C2: L = 16 hash levels -> 176 columns)
+#ifndef ENC_WAVES_PER_EU
+#define ENC_WAVES_PER_EU 2
+#endif
 template <bool USE_HDT>
-__global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
+__global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
                                                                         const float* __restrict__ tinfo, int64_t P,
                                                                         const half_t* __restrict__ hdT,
                                                                         half_t* __restrict__ X, int in_pad) {
   constexpr int C = 8;
-  extern __shared__ __attribute__((aligned(16))) half_t stage[];  // [ENC_THREADS][in_pad + 8]
-  const int ENC_PITCH = in_pad + 8;  // halfs per staged row: 16-byte aligned, spreads the lanes' rows over the banks
+  // the row is staged and written out in two parts (planes | everything else) so that the staging buffer is half as
+  // large: LDS is what limits this kernel's occupancy (gather latency needs waves in flight)
+  extern __shared__ __attribute__((aligned(16))) half_t stage[];  // [ENC_THREADS][max(part) + 8]
+  const int colsA = 2 * fd.planes.n_scales * C;
+  const int ENC_PITCH = max(colsA, in_pad - colsA) + 8;  // halfs per staged row: 16-byte aligned, spreads rows over the banks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wave_p0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
   const int64_t pr = wave_p0 + lane;
@@ -95,7 +110,20 @@ __global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDe
     store8h(row + s * C, ps);
     store8h(row + (nS + s) * C, pd);
   }
-  int col = 2 * nS * C;
+  const half_t* wstage = stage + wave * 64 * ENC_PITCH;
+  auto copy_out = [&](int c0, int ncols) {  // this wave's 64 staged rows -> X[:, c0 : c0 + ncols], 16 B per lane, coalesced
+    const int chunks = ncols / 8;
+    for (int idx = lane; idx < 64 * chunks; idx += 64) {
+      const int r = idx / chunks, c = idx - r * chunks;
+      const int64_t grow = wave_p0 + r;
+      if (grow < P) *reinterpret_cast<uint4*>(X + grow * in_pad + c0 + c * 8) = *reinterpret_cast<const uint4*>(wstage + r * ENC_PITCH + c * 8);
+    }
+  };
+  __syncthreads();
+  copy_out(0, colsA);
+  __syncthreads();
+  row -= colsA;  // the second part is staged from column 0 again
+  int col = colsA;
 
   // ---- static 3-D hash grid (hash_field.py:141-144) ----
   {
@@ -137,14 +165,8 @@ __global__ void __launch_bounds__(ENC_THREADS) density_encode_fwd_kernel(FieldDe
   }
   for (; col < in_pad; ++col) row[col] = (half_t)1.0f;  // tcnn pads the network input with ones
 
-  __syncthreads();  // rows of this wave complete (and visible) before the cooperative copy-out
-  const int chunks = in_pad / 8;  // 16-byte chunks per row
-  const half_t* wstage = stage + wave * 64 * ENC_PITCH;
-  for (int idx = lane; idx < 64 * chunks; idx += 64) {
-    const int r = idx / chunks, c = idx - r * chunks;
-    const int64_t grow = wave_p0 + r;
-    if (grow < P) *reinterpret_cast<uint4*>(X + grow * in_pad + c * 8) = *reinterpret_cast<const uint4*>(wstage + r * ENC_PITCH + c * 8);
-  }
+  __syncthreads();  // rows complete (and visible) before the cooperative copy-out
+  copy_out(colsA, in_pad - colsA);
 }
 
 // ---- dynamic hash, forward, with LDS-resident slice tables ---------------------------------------------------
@@ -306,12 +328,13 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, 8192)));
     const int64_t chunk = ceil_div64(P, n_chunks);
     n_chunks = (int)ceil_div64(P, chunk);
-    hipFuncSetAttribute((const void*)dynhash_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DH_MAX_ENTRIES * 8);
+    (void)hipFuncSetAttribute((const void*)dynhash_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DH_MAX_ENTRIES * 8);
     hipLaunchKernelGGL(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
                        2 * DH_MAX_ENTRIES * 8, (hipStream_t)stream, d, xt, (const half_t*)flow16, tinfo, P, chunk, (half_t*)hd_scratch);
   }
   const dim3 egrid((unsigned)ceil_div64(P, ENC_THREADS));
-  const int enc_lds = ENC_THREADS * (in_pad + 8) * 2;
+  const int colsA = 2 * d.planes.n_scales * 8;
+  const int enc_lds = ENC_THREADS * (std::max(colsA, in_pad - colsA) + 8) * 2;
   if (hd_scratch)
     hipLaunchKernelGGL((density_encode_fwd_kernel<true>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
                        (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);

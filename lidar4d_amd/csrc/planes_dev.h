@@ -36,18 +36,23 @@ __device__ __forceinline__ void axis_tap(float c, int size, int& i0, int& i1, fl
   w0 = (f + 1.0f) - p;
 }
 
+// Texel addresses are 32-bit byte offsets from the (wave-uniform) plane base: the loads then use the
+// scalar-base + 32-bit-offset form, which costs one VGPR per tap instead of a 64-bit address pair and
+// no 64-bit integer VALU work (a plane is at most a few MB).
 template <int C>
 __device__ __forceinline__ void sample_plane(const float* __restrict__ base, int W, const Tap& t, float out[C]) {
   const float nw = t.wx0 * t.wy0, ne = t.wx1 * t.wy0, sw = t.wx0 * t.wy1, se = t.wx1 * t.wy1;
-  const float4_t* p00 = reinterpret_cast<const float4_t*>(base + ((size_t)t.y0 * W + t.x0) * C);
-  const float4_t* p01 = reinterpret_cast<const float4_t*>(base + ((size_t)t.y0 * W + t.x1) * C);
-  const float4_t* p10 = reinterpret_cast<const float4_t*>(base + ((size_t)t.y1 * W + t.x0) * C);
-  const float4_t* p11 = reinterpret_cast<const float4_t*>(base + ((size_t)t.y1 * W + t.x1) * C);
+  const char* b = reinterpret_cast<const char*>(base);
+  const uint32_t texel = C * 4u, r0 = (uint32_t)t.y0 * (uint32_t)W, r1 = (uint32_t)t.y1 * (uint32_t)W;
+  const float4_t* p00 = reinterpret_cast<const float4_t*>(b + (r0 + (uint32_t)t.x0) * texel);
+  const float4_t* p01 = reinterpret_cast<const float4_t*>(b + (r0 + (uint32_t)t.x1) * texel);
+  const float4_t* p10 = reinterpret_cast<const float4_t*>(b + (r1 + (uint32_t)t.x0) * texel);
+  const float4_t* p11 = reinterpret_cast<const float4_t*>(b + (r1 + (uint32_t)t.x1) * texel);
 #pragma unroll
   for (int q = 0; q < C / 4; ++q) {
-    float4_t a = p00[q], b = p01[q], c = p10[q], d = p11[q];
+    float4_t a = p00[q], b4 = p01[q], c = p10[q], d = p11[q];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[q * 4 + j] = ((a[j] * nw + b[j] * ne) + c[j] * sw) + d[j] * se;
+    for (int j = 0; j < 4; ++j) out[q * 4 + j] = ((a[j] * nw + b4[j] * ne) + c[j] * sw) + d[j] * se;
   }
 }
 
