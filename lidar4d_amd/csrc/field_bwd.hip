@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
           }
           // t is the same for the whole launch, so both time rows (y0, y1) and their weights are wave-uniform: merge the
           // x0- and x1-column contributions once (2 merges instead of 4) and apply the row weights when issuing
+          const RowRuns runs = row_runs((uint32_t)t.x0);  // lanes of a run share x0, hence x1 too
 #pragma unroll
           for (int qx = 0; qx < 2; ++qx) {
             const int xq = qx == 0 ? t.x0 : t.x1;
@@ -234,7 +235,8 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
             float vals[C];
 #pragma unroll
             for (int k = 0; k < C; ++k) vals[k] = gv[k] * wx;
-            if (!row_merge<C>((uint32_t)xq, active, vals)) continue;
+            row_scan<C>(runs, vals);
+            if (!runs.tail) continue;  // (inactive lanes carry zeros and a valid clamped key: harmless in any run)
 #pragma unroll
             for (int qy = 0; qy < 2; ++qy) {
               const int yq = qy == 0 ? t.y0 : t.y1;
@@ -363,13 +365,17 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
     }
     const float wts[4] = {t.wx0 * t.wy0, t.wx1 * t.wy0, t.wx0 * t.wy1, t.wx1 * t.wy1};
     const int ys[4] = {t.y0, t.y0, t.y1, t.y1}, xs_[4] = {t.x0, t.x1, t.x0, t.x1};
+    // runs of samples in one cell (same y0, x0 => same four taps and the same in0 / in1); inactive lanes form their own run
+    const RowRuns runs = row_runs(active ? (uint32_t)(t.y0 * W + t.x0) : 0xFFFFFFFFu);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool in = q < 2 ? in0 : in1;
+      if (!__any(in)) continue;
       float vals[C];
 #pragma unroll
-      for (int k = 0; k < C; ++k) vals[k] = gv[k] * wts[q];
-      if (!row_merge<C>((uint32_t)(ys[q] * W + xs_[q]), in, vals)) continue;
+      for (int k = 0; k < C; ++k) vals[k] = in ? gv[k] * wts[q] : 0.0f;
+      row_scan<C>(runs, vals);
+      if (!(runs.tail && in)) continue;
       int* dst = &lds_i[((ys[q] - row0) * W + xs_[q]) * C];
 #pragma unroll
       for (int k = 0; k < C; ++k)

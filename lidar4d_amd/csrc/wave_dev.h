@@ -57,6 +57,53 @@ __device__ __forceinline__ bool row_merge(uint32_t key, bool active, float v[K])
   return (lane & 15) == 15;
 }
 
+// Run merge inside DPP rows.  Consecutive lanes are consecutive samples of a ray, so lanes that target the same texel /
+// table entry form contiguous runs.  row_runs() finds the runs inside each 16-lane row from the keys (one row_shr
+// compare + one ballot), row_scan() is a segmented Hillis-Steele scan over them -- per value 4 v_fmac_f32_dpp (pure
+// VALU; the flags f1..f8 switch the adds off across run boundaries) -- after which the LAST lane of every run holds the
+// run's total and is the only one that needs to issue an atomic.  Unlike row_merge this also merges rows that hold
+// several runs (fine scales, where a row of 16 samples crosses 2-3 texels).
+struct RowRuns {
+  float f1, f2, f4, f8;  // 1.0 if the lane 1/2/4/8 to the left is in the same run (and the same row), else 0.0
+  bool tail;             // this lane is the last of its run
+};
+__device__ __forceinline__ RowRuns row_runs(uint32_t key) {
+  const int lane = __lane_id();
+  // old = ~key with bound_ctrl off: the first lane of a row keeps ~key, i.e. always starts a run
+  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+  const unsigned long long H = __ballot(key != prev);                  // run heads
+  const unsigned long long le = H & (~0ull >> (63 - lane));            // heads at or below this lane (never empty)
+  const int off = lane - (63 - __clzll((long long)le));                // distance to this lane's run head, 0..15
+  RowRuns r;
+  r.f1 = off >= 1 ? 1.0f : 0.0f;
+  r.f2 = off >= 2 ? 1.0f : 0.0f;
+  r.f4 = off >= 4 ? 1.0f : 0.0f;
+  r.f8 = off >= 8 ? 1.0f : 0.0f;
+  r.tail = lane == 63 || ((H >> (lane + 1)) & 1ull) != 0ull;
+  return r;
+}
+template <int K>
+__device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
+  // v += flag * dpp_row_shr(v) as ONE instruction.  (hipcc keeps a v_mov_b32_dpp + v_fmac pair for the builtin form.)
+  // Inline asm is invisible to the hazard recogniser: an EXEC write needs 5 wait states before a DPP op and a VALU write
+  // of a DPP source 2, so the sequence starts with s_nop 4, and the steps run value-major (8 independent instructions
+  // between a write of v[k] and its next DPP read).
+#define L4D_FMAC_DPP(x, f, shr) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:" #shr " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x) : "v"(f))
+  asm volatile("s_nop 4");
+#pragma unroll
+  for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f1, 1);
+  if (K < 3) asm volatile("s_nop 1");
+#pragma unroll
+  for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f2, 2);
+  if (K < 3) asm volatile("s_nop 1");
+#pragma unroll
+  for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f4, 4);
+  if (K < 3) asm volatile("s_nop 1");
+#pragma unroll
+  for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f8, 8);
+#undef L4D_FMAC_DPP
+}
+
 // fixed-point scale: largest power of two s with bound * s < 2^bits (bound > 0)
 __device__ __forceinline__ float fx_scale(float bound, int bits) {
   if (!(bound > 0.0f)) return 1.0f;
