@@ -71,6 +71,24 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   bool emit[NC];
   uint32_t pos[NC];
   const bool wave_any = __any(any);
+  // Consecutive lanes are consecutive samples of a ray: on coarse levels several of them sit in one cell and hit the same
+  // 2^D entries.  Binned levels merge such runs inside 16-lane rows with the DPP scan (one record per run and corner);
+  // the dense fallback keeps the wave-wide shuffle reduction (global atomics are the expensive resource there).
+  int n_heads = 64;
+  RowRuns runs;
+  bool use_scan = false;
+  if (binned && wave_any) {
+    bool same = true;  // same cell as the previous lane (the first lane of a row never is: old = ~cell, bound_ctrl off)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp((int)~c.cell[d], (int)c.cell[d], 0x111, 0xf, 0xf, false);
+      same &= pv == c.cell[d];
+    }
+    // key = running id that changes exactly where the cell changes (lanes without a gradient carry zeros: harmless)
+    const unsigned long long brk = __ballot(!same);
+    runs = row_runs((uint32_t)__popcll(brk & (~0ull >> (63 - lane))), &n_heads);
+    use_scan = n_heads <= 56;  // wave-uniform: otherwise there is nothing worth merging
+  }
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     uint32_t gg[D];
@@ -78,7 +96,15 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
     keys[k] = grid_index<D>(gg, desc.res[lvl], size, hashed);
 #pragma unroll
     for (int j = 0; j < NV; ++j) vals[k][j] = w * gv[j];
-    emit[k] = wave_any ? wave_run_reduce<NV>(keys[k], any, vals[k]) : false;
+    if (binned) {
+      emit[k] = any;
+      if (use_scan) {
+        row_scan<NV>(runs, vals[k]);
+        emit[k] = runs.tail;
+      }
+    } else {
+      emit[k] = wave_any ? wave_run_reduce<NV>(keys[k], any, vals[k]) : false;
+    }
     if (emit[k]) {
       bool nz = false;
 #pragma unroll

@@ -67,11 +67,13 @@ struct RowRuns {
   float f1, f2, f4, f8;  // 1.0 if the lane 1/2/4/8 to the left is in the same run (and the same row), else 0.0
   bool tail;             // this lane is the last of its run
 };
-__device__ __forceinline__ RowRuns row_runs(uint32_t key) {
+// n_heads (optional): number of runs in the wave (64 = nothing to merge)
+__device__ __forceinline__ RowRuns row_runs(uint32_t key, int* n_heads = nullptr) {
   const int lane = __lane_id();
   // old = ~key with bound_ctrl off: the first lane of a row keeps ~key, i.e. always starts a run
   const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
   const unsigned long long H = __ballot(key != prev);                  // run heads
+  if (n_heads) *n_heads = __popcll(H);
   const unsigned long long le = H & (~0ull >> (63 - lane));            // heads at or below this lane (never empty)
   const int off = lane - (63 - __clzll((long long)le));                // distance to this lane's run head, 0..15
   RowRuns r;
