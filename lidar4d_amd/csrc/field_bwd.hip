@@ -242,15 +242,13 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
               const int yq = qy == 0 ? t.y0 : t.y1;
               const float wy = qy == 0 ? t.wy0 : t.wy1;
               if (wy == 0.0f) continue;
+              const float wyf = wy * fxs;
               const int rr = yq - r_lo(s);
               if (rr >= 0 && rr < TROWS) {
                 int* dst = &lds_i[lds_off(s, j) + (rr * W + xq) * C];
 #ifndef ABL_NO_LDS_ATOMICS
 #pragma unroll
-                for (int k = 0; k < C; ++k) {
-                  const int iv = __float2int_rn(vals[k] * wy * fxs);
-                  if (iv != 0) atomicAdd(dst + k, iv);
-                }
+                for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k] * wyf));  // (no per-channel zero test: 8 branches cost more than the rare no-op add)
 #else
                 asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
 #endif
@@ -378,8 +376,7 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
       if (!(runs.tail && in)) continue;
       int* dst = &lds_i[((ys[q] - row0) * W + xs_[q]) * C];
 #pragma unroll
-      for (int k = 0; k < C; ++k)
-        if (vals[k] != 0.0f) atomicAdd(dst + k, __float2int_rn(vals[k] * fxs));
+      for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k] * fxs));
     }
     }  // while (todo)
   }

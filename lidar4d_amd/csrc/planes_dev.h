@@ -139,16 +139,11 @@ __device__ __forceinline__ void load_taps(const float* __restrict__ base, int W,
 }
 template <int C>
 __device__ __forceinline__ void coord_grad_from_taps(const TapVals<C>& tv, const Tap& t, const float gv[C], float& gix, float& giy) {
+  // ATen grid_sampler_2d_backward: gix = sum_k g_k [(v01 - v00) wy0 + (v11 - v10) wy1], giy likewise with x and y swapped
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     const float g = gv[k];
-    gix -= tv.v00[k] * t.wy0 * g;
-    giy -= tv.v00[k] * t.wx0 * g;
-    gix += tv.v01[k] * t.wy0 * g;
-    giy -= tv.v01[k] * t.wx1 * g;
-    gix -= tv.v10[k] * t.wy1 * g;
-    giy += tv.v10[k] * t.wx0 * g;
-    gix += tv.v11[k] * t.wy1 * g;
-    giy += tv.v11[k] * t.wx1 * g;
+    gix += ((tv.v01[k] - tv.v00[k]) * t.wy0 + (tv.v11[k] - tv.v10[k]) * t.wy1) * g;
+    giy += ((tv.v10[k] - tv.v00[k]) * t.wx0 + (tv.v11[k] - tv.v01[k]) * t.wx1) * g;
   }
 }
