@@ -69,6 +69,8 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
   const int nS = fd.planes.n_scales;
   const float c0 = 0.5f + (has_fwd ? 0.0f : 0.25f) + (has_bwd ? 0.0f : 0.25f);
   float gd_max = 0.0f;
+  float my_stat = 0.0f;  // lane i collects the wave maximum destined for stats[i] (ST_* indices are all < 64)
+  static_assert(ST_DYN_MAX + 3 * L4D_MAX_LEVELS <= 64, "one lane per statistic");
 
   // ---- hex-planes: static planes' product-rule factors, and the range of the time-plane upstream gradient ----
   for (int s = 0; s < nS; ++s) {
@@ -103,10 +105,10 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
       if (valid) *reinterpret_cast<uint4*>(gvs + ((p * nS + s) * 3 + j) * C) = *reinterpret_cast<uint4*>(hv);
     }
     smax = wave_max(smax);
-    if (lane == 0 && smax > 0.0f) atomic_max_nonneg(stats + ST_GVS_MAX + s, smax);
+    if (lane == ST_GVS_MAX + s) my_stat = smax;
   }
   gd_max = wave_max(gd_max);
-  if (lane == 0 && gd_max > 0.0f) atomic_max_nonneg(stats + ST_GD_MAX, gd_max);
+  if (lane == ST_GD_MAX) my_stat = gd_max;
   int col = 2 * nS * C;
 
   col += fd.hs.n_levels * 4;  // static 3-D hash columns: handled by the sorted scatter (binscatter.hip)
@@ -122,12 +124,14 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
         const float a = valid ? fabsf(h2f(hv)) : 0.0f;
         if (valid) gdynT[(int64_t)cidx * P + p] = hv;
         const float m = wave_max(a);
-        if (lane == 0 && m > 0.0f) atomic_max_nonneg(stats + ST_DYN_MAX + cidx, m);
+        if (lane == ST_DYN_MAX + cidx) my_stat = m;
       }
       col += L;
     }
   }
-
+  // one guarded atomic-max per statistic, all of them in flight together (lane i owns stats[i]); issued one by one as
+  // they were computed, each was a dependent L2 round trip per wave
+  if (my_stat > 0.0f) atomic_max_nonneg(stats + lane, my_stat);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,7 +545,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     for (int s = 0; s < d.planes.n_scales; ++s)
       for (int j = 0; j < 3; ++j) lds += TROWS * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
-    hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
                        tinfo, P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16);
   }

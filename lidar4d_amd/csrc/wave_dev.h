@@ -114,10 +114,20 @@ __device__ __forceinline__ float fx_scale(float bound, int bits) {
   return ldexpf(1.0f, bits - e);
 }
 
+// Maximum over the wave of NON-NEGATIVE values, as a wave-uniform result.  DPP only (v_max_f32 with row_shr 1/2/4/8,
+// then row_bcast:15 / row_bcast:31 carry the row maxima upwards; lane 63 ends up with the total) -- __shfl_xor would be
+// six trips through the LDS crossbar.  old = 0 for lanes a DPP step does not reach: neutral for non-negative inputs.
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-  return v;
+#define L4D_MAX_DPP(ctrl, rmask) \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false)))
+  L4D_MAX_DPP(0x111, 0xf);  // row_shr:1
+  L4D_MAX_DPP(0x112, 0xf);  // row_shr:2
+  L4D_MAX_DPP(0x114, 0xf);  // row_shr:4
+  L4D_MAX_DPP(0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row maximum
+  L4D_MAX_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  L4D_MAX_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave maximum
+#undef L4D_MAX_DPP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // non-negative floats order like their bit patterns
