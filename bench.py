@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chamfer", action="store_true", help="add the reference's ray chamfer loss term (runner.py:215-220) to the step")
+    ap.add_argument("--flow", action="store_true", help="add the reference's scene-flow consistency loss (runner.py:222-253, opt.flow_loss)")
     ap.add_argument("--profile-steps", type=int, default=2)
     args = ap.parse_args()
 
@@ -139,7 +140,7 @@ def main():
     model = LiDAR4D(near_lidar=1.0 * KITTI360_SCALE, far_lidar=81.0 * KITTI360_SCALE, num_frames=51, **model_kw).to(dev)
     inference = args.workload in INFERENCE
     data = SyntheticKitti360(dev, W=2048 if inference else 1024, num_rays=n_rays, seed=1000 + rank)
-    trainer = Trainer(model, data, chamfer=args.chamfer)
+    trainer = Trainer(model, data, chamfer=args.chamfer, flow=args.flow)
     if inference:
         from lidar4d_amd.data import KITTI360_FOV
         from lidar4d_amd.metrics import PointsMeter
@@ -237,7 +238,7 @@ def main():
                        "global_rays_per_step": n_rays * world,
                        "parallelism": f"frame-sharded x{world}, no collective" if inference else f"ray-sharded dp{world}, 1 RCCL all-reduce/step",
                        "step": "no_grad render(staged=True, max_ray_batch=4096) + U-Net + pano_to_lidar + chamfer/F-score" if inference else
-                               "forward + backward + Adam, losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else " (no chamfer/flow loss)")},
+                               "forward + backward + Adam, losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else "") + (" + scene-flow consistency" if args.flow else "") + ("" if args.chamfer or args.flow else " (no chamfer/flow loss)")},
             "roofline": roofline,
         }
         if inference:

@@ -3,8 +3,8 @@ schedule, and ray-sharded data parallelism with one RCCL all-reduce of the flat 
 
 Restates only what `training rays/s` needs from the reference's Trainer (model/runner.py:166-213,474-551;
 optimizer main_lidar4d.py:298-305) plus the inference step of the evaluation / simulation loops
-(runner.py:438-470: staged render of a whole frame, U-Net ray-drop refinement, masking).  Flow loss, EMA,
-checkpoints and logging are out of scope.
+(runner.py:438-470: staged render of a whole frame, U-Net ray-drop refinement, masking) and the optional ray-chamfer and
+scene-flow loss terms (runner.py:215-253).  The line-of-sight (urf) loss, EMA, checkpoints and logging are out of scope.
 """
 import torch
 import torch.distributed as dist
@@ -39,6 +39,55 @@ def ray_chamfer_loss(outputs, data, scale):
     gt_lidar = rays_d * gt_depth.unsqueeze(-1) / scale
     dist1, dist2, _, _ = chamfer_3DDist()(pred_lidar, gt_lidar)
     return (dist1 + dist2).mean() * 0.5
+
+
+def process_pointcloud(dataset, ground_split=None):
+    """runner.py:923-951 on the device: per frame, ground-truth range image -> points (lidar4d_amd.convert) -> split into
+    non-ground / ground -> scene units and world frame.  Returns (pc_list, pc_ground_list), dicts keyed by str(frame).
+    The reference separates the ground with RANSAC + open3d outlier removal (utils/misc.py:128-154), which is dataset
+    preprocessing and out of scope; ``ground_split(points[N,3]) -> bool mask`` stands in for it (default: within 0.15 m
+    of the synthetic scene's ground plane z = -1.7 m, the reference's RANSAC distance threshold)."""
+    from .convert import pano_to_lidar
+    if ground_split is None:
+        ground_split = lambda pts: (pts[:, 2] + 1.7).abs() < 0.15
+    pc_list, pc_ground_list = {}, {}
+    for k in range(dataset.num_frames):
+        img = dataset.images[k]
+        gt_depth = img[..., 2] * img[..., 0]
+        pts = pano_to_lidar(gt_depth / dataset.scale, dataset.fov)          # metres, sensor frame
+        is_ground = ground_split(pts)
+        pose = dataset.poses[k]
+        to_world = lambda q: (q * dataset.scale) @ pose[:3, :3].T + pose[:3, 3]
+        pc_list[f"{k}"] = to_world(pts[~is_ground]).contiguous()
+        pc_ground_list[f"{k}"] = to_world(pts[is_ground]).contiguous()
+    return pc_list, pc_ground_list
+
+
+def flow_loss(model, pc_list, pc_ground_list, time_lidar, num_frames, t_ground=None):
+    """runner.py:222-253: two-step forward / backward chamfer consistency of the scene flow between neighbouring frames'
+    point clouds (sum, not mean, of the squared distances) + 0.001 * L1 of the flow on ground points at a random time.
+    ``t_ground`` replaces the reference's ``torch.rand(1)`` when given (tests)."""
+    from .chamfer import chamfer_3DDist
+    cham = chamfer_3DDist()
+    frame_idx = int(float(time_lidar) * (num_frames - 1))
+    pc = pc_list[f"{frame_idx}"]
+    pred = model.flow(pc, time_lidar)
+    loss = pc.new_zeros(())
+    for step in (1, 2):
+        for sign, key in ((+1, "forward"), (-1, "backward")):
+            other = pc_list.get(f"{frame_idx + sign * step}")
+            if other is None or other.shape[0] == 0 or pc.shape[0] == 0:
+                continue
+            pc_pred = pc + pred[key].float() * step
+            dist1, dist2, _, _ = cham(pc_pred.unsqueeze(0), other.unsqueeze(0))
+            loss = loss + (dist1.sum() + dist2.sum()) * 0.5
+    ground = pc_ground_list[f"{frame_idx}"]
+    if ground.shape[0]:
+        if t_ground is None:
+            t_ground = torch.rand(1, device=ground.device)
+        zero_flow = model.flow(ground, t_ground.reshape(1, 1).to(ground))
+        loss = loss + 0.001 * (zero_flow["forward"].float().abs().sum() + zero_flow["backward"].float().abs().sum())
+    return loss
 
 
 class FlatAdam:
@@ -78,10 +127,15 @@ class Trainer:
     indices -- parameters are replicated and the flat gradient buffer is SUM-all-reduced once per step (the primary
     loss is a sum over rays, so the result equals one big batch)."""
 
-    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=False):
+    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=False, flow=False):
         """chamfer=True adds the reference's ray chamfer term (runner.py:215-220); it is a mean over the rank's own
-        rays, so under data parallelism it is scaled by 1/world before the SUM all-reduce."""
+        rays, so under data parallelism it is scaled by 1/world before the SUM all-reduce.
+        flow=True adds the scene-flow consistency term (runner.py:222-253, ``opt.flow_loss``): a per-frame sum, so under
+        data parallelism it enters each rank's loss as it is (every rank works on its own frame)."""
         self.model, self.dataset, self.num_steps, self.chamfer = model, dataset, num_steps, chamfer
+        self.flow = flow
+        if flow:
+            self.pc_list, self.pc_ground_list = process_pointcloud(dataset)
         self.opt = FlatAdam(model, lr=lr, iters=iters)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -93,7 +147,11 @@ class Trainer:
         loss = lidar_loss(out, data["images_lidar"])
         if self.chamfer:
             loss = loss + ray_chamfer_loss(out, data, self.dataset.scale) / self.world
+        if self.flow:
+            loss = loss + flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames)
         loss.backward()
+        if self.flow:
+            self.model._store.prepare_grads()  # fold gradients autograd produced outside the fused node into the arena
         if self.world > 1:
             dist.all_reduce(self.model._store.flat_grad, op=dist.ReduceOp.SUM)
         self.opt.step()

@@ -179,3 +179,60 @@ def test_points_meter_and_test_step_gpu():
     np.testing.assert_allclose(v[0], [cd, f], rtol=2e-4)
     np.testing.assert_allclose(v[1], [0.0, 1.0], atol=1e-9)
     assert meter.measure().shape == (2,)
+
+
+@pytest.mark.gpu
+def test_flow_loss_vs_oracle():
+    """runner.py:222-253 (scene-flow consistency) through model.flow + the HIP chamfer, against the CPU restatement."""
+    from lidar4d_amd import LiDAR4D
+    from lidar4d_amd.data import KITTI360_SCALE, SyntheticKitti360
+    from lidar4d_amd.trainer import Trainer, flow_loss, process_pointcloud
+    from oracle import chamfer_ref, fields_ref, tcnn_ref
+    from oracle.detparams import fill_model, grad_digest
+    from oracle.make_golden import SMALL_MODEL
+    prev = tcnn_ref.get_precision()
+    tcnn_ref.set_precision("tcnn")
+    try:
+        cfg = dict(SMALL_MODEL, num_frames=5, near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE)
+        ref = fill_model(fields_ref.LiDAR4D(**cfg), seed=3, flow_out_amp=0.002)
+        hip = fill_model(LiDAR4D(**cfg), seed=3, flow_out_amp=0.002).cuda()
+        data = SyntheticKitti360("cuda", H=16, W=64, num_frames=5, num_rays=128)
+        pcs, grounds = process_pointcloud(data)
+        assert set(pcs) == {str(k) for k in range(5)} and all(v.shape[1] == 3 for v in pcs.values())
+        n_pts = sum(v.shape[0] + grounds[k].shape[0] for k, v in pcs.items())
+        assert n_pts == int((data.images[..., 0] > 0).sum()), "every returned pixel is either ground or non-ground"
+        t = torch.tensor([[2 / 4]])
+        tg = torch.tensor([0.37])
+        hip.zero_grad()
+        loss = flow_loss(hip, pcs, grounds, t.cuda(), 5, t_ground=tg.cuda())
+        loss.backward()
+        # oracle: same formula on the CPU restatement
+        ref.zero_grad()
+        pc = pcs["2"].cpu()
+        pred = ref.flow(pc, t)
+        loss_ref = pc.new_zeros(())
+        for step in (1, 2):
+            for sign, key in ((+1, "forward"), (-1, "backward")):
+                other = pcs.get(str(2 + sign * step))
+                if other is None:
+                    continue
+                d1, d2, _, _ = chamfer_ref.chamfer((pc + pred[key] * step)[None], other.cpu()[None])
+                loss_ref = loss_ref + (d1.sum() + d2.sum()) * 0.5
+        zf = ref.flow(grounds["2"].cpu(), tg.reshape(1, 1))
+        loss_ref = loss_ref + 0.001 * (zf["forward"].abs().sum() + zf["backward"].abs().sum())
+        loss_ref.backward()
+        assert abs(float(loss) - float(loss_ref)) <= 2e-3 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+        dig_ref, dig = grad_digest(ref), grad_digest(hip)
+        for n, v in dig_ref.items():
+            if not n.startswith("flow_net."):
+                assert abs(dig[n]).max() == 0
+                continue
+            scale = max(abs(v[1]), 1e-12)
+            assert max(abs(dig[n][k] - v[k]) for k in range(3)) / scale < 3e-2, (n, dig[n], v)
+        # a training step with all optional terms runs and changes the flow parameters
+        tr = Trainer(hip, data, num_steps=64, chamfer=True, flow=True)
+        before = hip.flow_net.grid_enc.params.detach().clone()
+        l0 = float(tr.train_step(data.batch_for(2)))
+        assert np.isfinite(l0) and not torch.equal(before, hip.flow_net.grid_enc.params.detach())
+    finally:
+        tcnn_ref.set_precision(prev)
