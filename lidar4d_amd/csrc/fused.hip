@@ -60,7 +60,9 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 // levels).  Written straight to HBM those partial-line stores cost 17.7 GB of write traffic for a 3.2 GB matrix
 // (profiles/r01_pmc_WRITE_SIZE_c3.txt), so the row is staged in LDS (row pitch in_pad + 8 halfs: 16-B aligned, spreads
 // the lanes' rows over the banks) and each wave then writes its 64 rows as full 16-B-per-lane coalesced stores.
-#define ENC_THREADS 128
+#ifndef ENC_THREADS
+#define ENC_THREADS 64  // one wave per workgroup: measured best (64: 13.8 ms, 128: 14.1, 256: 14.5 for the entry point)
+#endif
 #define ENC_MAX_IN_PAD 192  // widest network input row (BASELINE config C2: L = 16 hash levels -> 176 columns)
 #ifndef ENC_WAVES_PER_EU
 #define ENC_WAVES_PER_EU 2
