@@ -135,9 +135,13 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// 2. time planes: all scales, all three frames, one pass; LDS window = 3 rows around t per plane
+// 2. time planes: all scales, all three frames, one pass
 // ------------------------------------------------------------------------------------------------
-#define TROWS 3
+// The time coordinate of a frame is the same for every sample of the launch, so the two time rows a tap touches and
+// their weights are launch-uniform: LDS accumulates, per (scale, plane, frame e), ONE row  S[x][c] = sum gv * w_x  over
+// the spatial axis only (int32 fixed point), and the flush distributes it to the rows y0(e), y1(e) of the gradient
+// plane with the weights wy0(e), wy1(e).  [scale][plane][frame][W][C] ints = 138 KB at the default configuration.
+#define TFRAMES 3
 __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
                                                             int64_t P, int64_t chunk, const half_t* __restrict__ dX,
@@ -149,37 +153,26 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
   const float t0 = tinfo[0], t1 = tinfo[1], t2 = tinfo[2];
   const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
   const float c0 = 0.5f + (has_fwd ? 0.0f : 0.25f) + (has_bwd ? 0.0f : 0.25f);
-  // LDS layout: [scale][time plane j][TROWS][W][C]; window start row per scale (time res is shared by x/y/z-t planes)
-  __shared__ int lds_off_s[MAX_SCALES * 3], r_lo_s[MAX_SCALES], total_s;
+  __shared__ int lds_off_s[MAX_SCALES * 3], total_s;
   if (threadIdx.x == 0) {
     int tot = 0;
-    for (int s = 0; s < nS; ++s) {
-      const int Ht = fd.planes.res[s][3];
-      int i0, i1;
-      float w0, w1, m;
-      axis_tap(t0, Ht, i0, i1, w0, w1, m);
-      int lo = i0;
-      if (has_fwd) { axis_tap(t1, Ht, i0, i1, w0, w1, m); lo = min(lo, i0); }
-      if (has_bwd) { axis_tap(t2, Ht, i0, i1, w0, w1, m); lo = min(lo, i0); }
-      r_lo_s[s] = lo;
+    for (int s = 0; s < nS; ++s)
       for (int j = 0; j < 3; ++j) {
         lds_off_s[s * 3 + j] = tot;
-        tot += TROWS * fd.planes.res[s][j] * C;  // time plane j pairs spatial axis j with t
+        tot += TFRAMES * fd.planes.res[s][j] * C;  // time plane j pairs spatial axis j with t
       }
-    }
     total_s = tot;
   }
   __syncthreads();
   const int total = total_s;
 #define lds_off(s, j) lds_off_s[(s) * 3 + (j)]
-#define r_lo(s) r_lo_s[(s)]
   for (int i = threadIdx.x; i < total; i += blockDim.x) lds_i[i] = 0;
   __syncthreads();
   const float vmax = stats[ST_VMAX];
   const float fxs = fx_scale((float)chunk * stats[ST_GD_MAX] * vmax * vmax * 1.01f + 1e-30f, 30);
 
   // consecutive lanes = consecutive samples of a ray: the plane gathers stay coherent, and the equal-texel runs this
-  // creates are merged in registers (wave_run_reduce) before they reach the LDS atomics
+  // creates are merged in registers (row_runs / row_scan) before they reach the LDS atomics
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
   const int64_t n_iter = (chunk + blockDim.x - 1) / blockDim.x;
   for (int64_t it = 0; it < n_iter; ++it) {
@@ -229,40 +222,24 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
             coord_grad_from_taps<C>(tv, t, gv, gix, giy);
             gflow[(e - 1) * 3 + j] += gix * t.mx;
           }
-          // t is the same for the whole launch, so both time rows (y0, y1) and their weights are wave-uniform: merge the
-          // x0- and x1-column contributions once (2 merges instead of 4) and apply the row weights when issuing
           const RowRuns runs = row_runs((uint32_t)t.x0);  // lanes of a run share x0, hence x1 too
+          int* acc = &lds_i[lds_off(s, j) + e * W * C];
 #pragma unroll
           for (int qx = 0; qx < 2; ++qx) {
             const int xq = qx == 0 ? t.x0 : t.x1;
-            const float wx = qx == 0 ? t.wx0 : t.wx1;
+            const float wxf = (qx == 0 ? t.wx0 : t.wx1) * fxs;
             float vals[C];
 #pragma unroll
-            for (int k = 0; k < C; ++k) vals[k] = gv[k] * wx;
+            for (int k = 0; k < C; ++k) vals[k] = gv[k] * wxf;
             row_scan<C>(runs, vals);
             if (!runs.tail) continue;  // (inactive lanes carry zeros and a valid clamped key: harmless in any run)
-#pragma unroll
-            for (int qy = 0; qy < 2; ++qy) {
-              const int yq = qy == 0 ? t.y0 : t.y1;
-              const float wy = qy == 0 ? t.wy0 : t.wy1;
-              if (wy == 0.0f) continue;
-              const float wyf = wy * fxs;
-              const int rr = yq - r_lo(s);
-              if (rr >= 0 && rr < TROWS) {
-                int* dst = &lds_i[lds_off(s, j) + (rr * W + xq) * C];
+            int* dst = acc + xq * C;
 #ifndef ABL_NO_LDS_ATOMICS
 #pragma unroll
-                for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k] * wyf));  // (no per-channel zero test: 8 branches cost more than the rare no-op add)
+            for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k]));
 #else
-                asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
+            asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
 #endif
-              } else {  // outside the LDS window (only for exotic num_frames / time_resolution): direct
-                float* dst = garena + fd.planes.off[s][cis[j]] + ((size_t)yq * W + xq) * C;
-#pragma unroll
-                for (int k = 0; k < C; ++k)
-                  if (vals[k] != 0.0f) atomicAdd(dst + k, vals[k] * wy * pscale);
-              }
-            }
           }
         }
       }
@@ -277,22 +254,31 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
     }
   }
   __syncthreads();
+  // flush: row S of (scale, plane, frame e) goes to the time rows y0(e), y1(e) of the gradient plane
   const float inv = pscale / fxs;
   for (int s = 0; s < nS; ++s) {
     const int Ht = fd.planes.res[s][3];
-    int j = 0;
-    for (int ci = 0; ci < NPLANES; ++ci) {
-      if (COMB_B[ci] != 3) continue;
-      const int W = fd.planes.res[s][j];
-      float* g = garena + fd.planes.off[s][ci];
-      for (int i = threadIdx.x; i < TROWS * W * C; i += blockDim.x) {
-        const int rr = i / (W * C);
-        const int v = lds_i[lds_off(s, j) + i];
-        if (v != 0 && r_lo(s) + rr < Ht) atomicAdd(g + (size_t)(r_lo(s) + rr) * W * C + (i - rr * W * C), (float)v * inv);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      if ((e == 1 && !has_fwd) || (e == 2 && !has_bwd)) continue;
+      int y0, y1;
+      float wy0, wy1, my;
+      axis_tap(e == 0 ? t0 : e == 1 ? t1 : t2, Ht, y0, y1, wy0, wy1, my);
+      for (int j = 0; j < 3; ++j) {
+        const int W = fd.planes.res[s][j];
+        float* g = garena + fd.planes.off[s][group_ci(true, j)];
+        const int* acc = &lds_i[lds_off(s, j) + e * W * C];
+        for (int i = threadIdx.x; i < W * C; i += blockDim.x) {
+          const int v = acc[i];
+          if (v == 0) continue;
+          const float fv = (float)v * inv;
+          atomicAdd(g + (size_t)y0 * W * C + i, fv * wy0);
+          if (wy1 != 0.0f) atomicAdd(g + (size_t)y1 * W * C + i, fv * wy1);
+        }
       }
-      ++j;
     }
   }
+#undef lds_off
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -543,7 +529,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   {
     int lds = 0;
     for (int s = 0; s < d.planes.n_scales; ++s)
-      for (int j = 0; j < 3; ++j) lds += TROWS * d.planes.res[s][j] * 8 * 4;
+      for (int j = 0; j < 3; ++j) lds += TFRAMES * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
     (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
