@@ -22,6 +22,9 @@
 
 #define BS_THREADS 512
 #define BS_MAX_BINS 128
+#ifndef BS_GROUP
+#define BS_GROUP 8
+#endif
 
 template <int NV>
 struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
@@ -200,13 +203,16 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) acc[i] = 0;
   __syncthreads();
   const float fxs = fx_scale((float)P * gmax * 1.01f, 61);
-  const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;  // 64 groups of 16 lanes, one pass-1 workgroup's run each
-  for (int w = grp; w < n_wg; w += 64) {
+  // groups of BS_GROUP lanes, one pass-1 workgroup's run each.  Every run costs a dependent pair of loads (its offsets,
+  // then its records): small groups = many independent chains in flight, which is what hides that latency
+  constexpr int NGRP = 1024 / BS_GROUP;
+  const int grp = threadIdx.x / BS_GROUP, l16 = threadIdx.x % BS_GROUP;
+  for (int w = grp; w < n_wg; w += NGRP) {
     const uint64_t slot = (uint64_t)lvl * n_wg + w;
     const uint16_t* o = offs + slot * (BS_MAX_BINS + 1);
     const uint32_t s0 = o[b], s1 = o[b + 1];
     const uint32_t* rec = bins + slot * (uint64_t)(BS_THREADS * NC * NW);
-    for (uint32_t r = s0 + l16; r < s1; r += 16) {
+    for (uint32_t r = s0 + l16; r < s1; r += BS_GROUP) {
       const uint32_t key = rec[r * NW] - lo;
       uint32_t wd[NW - 1];
 #pragma unroll
@@ -229,7 +235,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-static int bs_shift(int NV) { return NV == 4 ? 12 : NV == 2 ? 13 : 14; }  // 128 KB of int64 per bin
+static int bs_shift(int NV) { return NV == 4 ? 12 : NV == 2 ? 12 : 13; }  // <= 128 KB of int64 per bin; more, smaller bins also spread the pass-1 histogram atomics
 
 BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
   BsPlan pl;
