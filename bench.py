@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chamfer", action="store_true", help="add the reference's ray chamfer loss term (runner.py:215-220) to the step")
     ap.add_argument("--flow", action="store_true", help="add the reference's scene-flow consistency loss (runner.py:222-253, opt.flow_loss)")
+    ap.add_argument("--sort-rays", action="store_true", help="serve the random pixels of a batch in 8x8-pixel-block order (locality experiment; measured slower)")
     ap.add_argument("--profile-steps", type=int, default=2)
     args = ap.parse_args()
 
@@ -139,7 +140,7 @@ def main():
     torch.manual_seed(0)  # identical initial replicas on every rank
     model = LiDAR4D(near_lidar=1.0 * KITTI360_SCALE, far_lidar=81.0 * KITTI360_SCALE, num_frames=51, **model_kw).to(dev)
     inference = args.workload in INFERENCE
-    data = SyntheticKitti360(dev, W=2048 if inference else 1024, num_rays=n_rays, seed=1000 + rank)
+    data = SyntheticKitti360(dev, W=2048 if inference else 1024, num_rays=n_rays, seed=1000 + rank, sort_pixels=args.sort_rays)
     trainer = Trainer(model, data, chamfer=args.chamfer, flow=args.flow)
     if inference:
         from lidar4d_amd.data import KITTI360_FOV

@@ -32,7 +32,7 @@ struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed
 template <int D, int NV>
 __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
                                                               BsCols cols, const half_t* __restrict__ g, int g_stride, int g_col,
-                                                              float pre_scale, int shift,
+                                                              float pre_scale, int shift, int64_t n_wg,
                                                               uint16_t* __restrict__ offs, uint32_t* __restrict__ bins,
                                                               float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
@@ -43,9 +43,18 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
   __shared__ uint32_t stage[BS_THREADS * NC * NW];
   __shared__ uint32_t total_s;
-  const int lvl = blockIdx.y;
+  // Block order: the n_levels passes over one tile of samples read the same xyz rows and the same cache lines of the
+  // gradient rows (a level's 2-8 bytes out of a 128-B line).  They are placed next to each other in time AND on one XCD
+  // (blocks b, b+8, b+16, ... share an XCD and its L2): block = (8 L) q + 8 level + x  ->  tile 8 q + x.
+  // (With level as the slow grid dimension every line was fetched from the fabric once per level: 16.7 GB instead of ~5.)
+  const int n_lv = desc.n_levels;
+  const int64_t bq = blockIdx.x / (8 * n_lv);
+  const int br = (int)(blockIdx.x - bq * 8 * n_lv);
+  const int lvl = br >> 3;
+  const int64_t tile = bq * 8 + (br & 7);
+  if (tile >= n_wg) return;  // block-uniform, before any barrier
   const int lane = __lane_id();
-  const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t pr = tile * blockDim.x + threadIdx.x;
   const bool valid = pr < P;
   const int64_t p = valid ? pr : P - 1;
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
@@ -144,7 +153,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
     boff[threadIdx.x] = run;  // temporarily the bin total
   }
   __syncthreads();
-  const uint64_t wg_slot = (uint64_t)lvl * gridDim.x + blockIdx.x;
+  const uint64_t wg_slot = (uint64_t)lvl * n_wg + tile;
   if (threadIdx.x < 64) {  // exclusive scan of <= 128 bins by one wave
     uint32_t c0 = lane < nbins ? boff[lane] : 0u, c1 = lane + 64 < nbins ? boff[lane + 64] : 0u;
     uint32_t inc0 = c0, inc1 = c1;
@@ -265,14 +274,14 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   int max_bins = 1;
   for (int l = 0; l < desc.n_levels; ++l) max_bins = std::max<int>(max_bins, (int)(((int64_t)desc.size[l] + (1 << pl.shift) - 1) >> pl.shift));
   max_bins = std::min(max_bins, BS_MAX_BINS);
-  dim3 grid1((unsigned)pl.n_wg, desc.n_levels);
+  dim3 grid1((unsigned)(ceil_div64(pl.n_wg, 8) * 8 * desc.n_levels));
   dim3 grid2(max_bins, desc.n_levels);
   const int lds2 = (1 << pl.shift) * NV * 8;
 #define BS_LAUNCH(D, V)                                                                                                      \
   {                                                                                                                          \
     hipLaunchKernelGGL((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
-                       g_col, pre_scale, pl.shift, offs, bins, lvl_max, out, out_scale);                                     \
-    hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);              \
+                       g_col, pre_scale, pl.shift, (int64_t)pl.n_wg, offs, bins, lvl_max, out, out_scale);                                     \
+    (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);              \
     hipLaunchKernelGGL((bin_pass2_kernel<D, V>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
                        lvl_max, out, out_scale);                                                                            \
   }

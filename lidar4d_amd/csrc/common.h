@@ -32,6 +32,17 @@ __device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }  // round-t
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// XCD-aware tile order.  The dispatcher deals workgroups round-robin to the 8 XCDs (block b runs on XCD b % 8), each
+// with its own 4 MB L2.  Mapping block b to tile (b % 8) * (n / 8) + b / 8 gives every XCD one CONTIGUOUS eighth of the
+// tiles -- with rays sorted by pixel neighbourhood that is one sector of the scene, so the table lines a sector
+// touches are fetched into one L2 instead of all eight.  Launch xcd_grid(n) blocks; tiles >= n are idle.
+static inline int64_t xcd_grid(int64_t n_tiles) { return ceil_div64(n_tiles, 8) * 8; }
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t xcd_tile(int64_t block, int64_t n_blocks /* multiple of 8 */) {
+  return (block & 7) * (n_blocks >> 3) + (block >> 3);
+}
+#endif
+
 // Device copy of l4d_grid_desc passed by value as a kernel argument (236 bytes).
 struct GridDesc {
   int n_levels;

@@ -9,7 +9,7 @@
 //
 //   0. static 3-D hash grid: sorted scatter (binscatter.hip).
 //   1. prep (one thread per sample): reads dX; writes the static planes' per-plane gradient factors
-//      gvs[p][scale][plane][8] (product rule already applied), the dynamic-hash upstream gradient transposed
+//      gvs[scale][plane][p][8] (product rule already applied; plane-major so that a (scale, plane) pass reads it densely), the dynamic-hash upstream gradient transposed
 //      gdynT[col][p], and running maxima for the fixed-point scales.
 //   2. planes_dyn (one pass): all time planes of all scales fit in LDS as the 3 rows around t -> int32 accumulation;
 //      also the coordinate adjoint of the two warped lookups = d(flow).
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
         hv[k] = f2h(fminf(fmaxf(gv, -65504.f), 65504.f));
         smax = fmaxf(smax, fabsf(h2f(hv[k])));
       }
-      if (valid) *reinterpret_cast<uint4*>(gvs + ((p * nS + s) * 3 + j) * C) = *reinterpret_cast<uint4*>(hv);
+      if (valid) *reinterpret_cast<uint4*>(gvs + ((int64_t)(s * 3 + j) * P + p) * C) = *reinterpret_cast<uint4*>(hv);
     }
     smax = wave_max(smax);
     if (lane == ST_GVS_MAX + s) my_stat = smax;
@@ -302,7 +302,6 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
   const int ci = j == 0 ? 0 : j == 1 ? 1 : 3;
   const int a = COMB_A[ci], b = COMB_B[ci];
   const int W = fd.planes.res[s][a], H = fd.planes.res[s][b];
-  const int nS = fd.planes.n_scales;
   const int n_el = nrows * W * C;
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) lds_i[i] = 0;
   __syncthreads();
@@ -346,7 +345,7 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
     axis_tap(ca, W, t.x0, t.x1, t.wx0, t.wx1, t.mx);
     float gv[C];
     {
-      const uint4 u = *reinterpret_cast<const uint4*>(gvs + ((p * nS + s) * 3 + j) * C);
+      const uint4 u = *reinterpret_cast<const uint4*>(gvs + ((int64_t)(s * 3 + j) * P + p) * C);  // dense: 16 B per lane, consecutive
       const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
       for (int k = 0; k < C; ++k) gv[k] = h2f(h[k]);
@@ -553,7 +552,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
           ++t.n;
         }
       }
-    hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    (void)hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     hipLaunchKernelGGL(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
                        wave_skip, gvs, param_scale, stats);
   }
@@ -576,7 +575,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       }
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
-    hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xt, P, chunk, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;

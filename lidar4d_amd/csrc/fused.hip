@@ -58,7 +58,7 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 
 // Each thread assembles its sample's whole input row, but in pieces (16-B plane groups, 8-B hash levels, 2-B dynamic
 // levels).  Written straight to HBM those partial-line stores cost 17.7 GB of write traffic for a 3.2 GB matrix
-// (profiles/r01_pmc_WRITE_SIZE_c3.txt), so the row is staged in LDS (row pitch in_pad + 8 halfs: 16-B aligned, spreads
+// (profiles/r01_pmc_WRITE_SIZE_c3_v6.txt), so the row is staged in LDS (row pitch in_pad + 8 halfs: 16-B aligned, spreads
 // the lanes' rows over the banks) and each wave then writes its 64 rows as full 16-B-per-lane coalesced stores.
 #ifndef ENC_THREADS
 #define ENC_THREADS 64  // one wave per workgroup: measured best (64: 13.8 ms, 128: 14.1, 256: 14.5 for the entry point)
@@ -80,7 +80,9 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
   const int colsA = 2 * fd.planes.n_scales * C;
   const int ENC_PITCH = max(colsA, in_pad - colsA) + 8;  // halfs per staged row: 16-byte aligned, spreads rows over the banks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t wave_p0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+  const int64_t blk_p0 = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x;
+  if (blk_p0 >= P) return;  // idle tile of the rounded-up grid (block-uniform)
+  const int64_t wave_p0 = blk_p0 + wave * 64;
   const int64_t pr = wave_p0 + lane;
   const int64_t p = pr < P ? pr : P - 1;
   const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
@@ -334,7 +336,7 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     hipLaunchKernelGGL(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
                        2 * DH_MAX_ENTRIES * 8, (hipStream_t)stream, d, xt, (const half_t*)flow16, tinfo, P, chunk, (half_t*)hd_scratch);
   }
-  const dim3 egrid((unsigned)ceil_div64(P, ENC_THREADS));
+  const dim3 egrid((unsigned)xcd_grid(ceil_div64(P, ENC_THREADS)));
   const int colsA = 2 * d.planes.n_scales * 8;
   const int enc_lds = ENC_THREADS * (std::max(colsA, in_pad - colsA) + 8) * 2;
   if (hd_scratch)

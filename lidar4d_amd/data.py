@@ -16,10 +16,21 @@ KITTI360_SCALE = 0.010504329815187737  # configs/kitti360_4950.txt:6
 KITTI360_FOV = (2.0, 26.9)
 
 
-def get_lidar_rays(poses, intrinsics, H, W, N=-1, patch_size=1, generator=None):
+def pixel_block_order(rows, cols):
+    """Permutation that puts pixels of the same 8 x 8 block of the range image next to each other (block columns left to
+    right, blocks top to bottom inside a column).  Neighbouring pixels are neighbouring rays: their samples touch the
+    same plane texels and coarse hash cells, and processed together (and on one XCD: csrc/common.h xcd_tile) those
+    table lines are fetched into L2 once.  The result of a training step does not depend on the ray order (the losses
+    are sums over rays), so this is a free choice of the data loader.  (Measured: not a win -- see SyntheticKitti360.)"""
+    key = ((cols >> 3) << 9) | ((rows >> 3) << 6) | ((cols & 7) << 3) | (rows & 7)
+    return torch.argsort(key)
+
+
+def get_lidar_rays(poses, intrinsics, H, W, N=-1, patch_size=1, generator=None, sort_pixels=False):
     """poses [B,4,4] sensor-to-world, intrinsics (fov_up, fov) in degrees -> dict(rays_o, rays_d [B,n,3], inds [B,n]).
     N > 0 draws N random pixels the way the reference does for patch_size == 1: row in [0, H-1), column in [0, W)
-    (base_dataset.py:50-53 -- the last row is never sampled)."""
+    (base_dataset.py:50-53 -- the last row is never sampled).  sort_pixels: return the drawn pixels in
+    pixel_block_order (same set of rays, cache-friendly order)."""
     device = poses.device
     B = poses.shape[0]
     if N > 0:
@@ -28,6 +39,9 @@ def get_lidar_rays(poses, intrinsics, H, W, N=-1, patch_size=1, generator=None):
             raise NotImplementedError("get_lidar_rays: patch sampling other than patch_size=1 is not implemented")
         rows = torch.randint(0, H - 1, size=[N], device=device, generator=generator)
         cols = torch.randint(0, W, size=[N], device=device, generator=generator)
+        if sort_pixels:
+            order = pixel_block_order(rows, cols)
+            rows, cols = rows[order], cols[order]
         inds = (rows * W + cols).expand([B, N])
     else:
         inds = torch.arange(H * W, device=device).expand([B, H * W])
@@ -66,8 +80,11 @@ class SyntheticKitti360:
     """Pre-loads ``num_frames`` synthetic range images [H,W,3] = (ray-drop mask, intensity, depth*scale) on ``device``
     and serves per-step ray batches like KITTI360Dataset.collate (one frame per step)."""
 
-    def __init__(self, device, H=64, W=1024, num_frames=51, num_rays=4096, scale=KITTI360_SCALE, fov=KITTI360_FOV, seed=0):
+    def __init__(self, device, H=64, W=1024, num_frames=51, num_rays=4096, scale=KITTI360_SCALE, fov=KITTI360_FOV, seed=0,
+                 sort_pixels=False):
         self.device, self.H, self.W, self.num_frames, self.num_rays = device, H, W, num_frames, num_rays
+        self.sort_pixels = sort_pixels  # pixel_block_order; measured SLOWER on MI355X (66.3 vs 63.5 ms/step: neighbouring rays
+        # pile onto the same LDS histogram bins / cache lines), kept as an option for experiments
         self.scale, self.fov = scale, fov
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
@@ -113,7 +130,7 @@ class SyntheticKitti360:
 
     def batch_for(self, frame):
         pose = self.poses[frame:frame + 1]
-        rays = get_lidar_rays(pose, self.fov, self.H, self.W, self.num_rays, generator=self.gen)
+        rays = get_lidar_rays(pose, self.fov, self.H, self.W, self.num_rays, generator=self.gen, sort_pixels=self.sort_pixels)
         inds = rays["inds"]
         images = torch.gather(self.images[frame].view(1, -1, 3), 1, inds[..., None].expand(-1, -1, 3))
         t = torch.tensor([[frame / (self.num_frames - 1)]], dtype=torch.float32, device=self.device)
