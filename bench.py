@@ -36,6 +36,7 @@ WORKLOADS = {
     "c2": (dict(n_levels_hash=16, num_layers_sigma=3), 4096,
            "C2-shaped: L=16 hash + 3-layer-64 sigma MLP, 4096 rays/batch (the reference has no static-only switch: the full 4D field runs)"),
     "c3-4k": (dict(), 4096, "full 4D, 4096 rays/batch/GPU training (staged-chunk size)"),
+    "c3-l2": (dict(log2_hashmap_size=15), 16384, "analysis only: C3 work with hash tables shrunk 16x (all tables L2-resident): isolates the cost of L2 misses"),
     "c3-1k": (dict(), 1024, "full 4D, 1024 rays/batch/GPU training (the reference's own num_rays_lidar)"),
     # inference (BASELINE configs[4]): one step = one 64 x 2048 novel-view frame per GPU under no_grad --
     # render(staged=True, 32 chunks of 4096 rays) + U-Net ray-drop refinement + masking (runner.py:438-470) +

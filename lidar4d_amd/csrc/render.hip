@@ -293,13 +293,26 @@ __global__ void __launch_bounds__(256) attr_gather_kernel(const int32_t* __restr
   if (j >= M) return;
   const int64_t p = idx ? idx[j] : j;
   const int64_t ray = p / T;
+  if ((n_enc & 7) == 0 && ch * 8 + 8 <= n_enc) {  // chunk inside the direction encoding: one aligned 16-byte copy
+    *reinterpret_cast<uint4*>(xa + j * in_pad + ch * 8) = *reinterpret_cast<const uint4*>(dir_enc + ray * n_enc + ch * 8);
+    return;
+  }
+  half_t hrow[16];  // the sample's sigma-net output row: geo_feat = columns 1 .. n_geo
+  *reinterpret_cast<uint4*>(hrow) = *reinterpret_cast<const uint4*>(h + p * 16);
+  *reinterpret_cast<uint4*>(hrow + 8) = *reinterpret_cast<const uint4*>(h + p * 16 + 8);
   half_t v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int col = ch * 8 + e;
     half_t val = (half_t)1.0f;
     if (col < n_enc) val = dir_enc[ray * n_enc + col];
-    else if (col < n_enc + n_geo) val = h[p * 16 + 1 + (col - n_enc)];
+    else if (col < n_enc + n_geo) {
+      const int g = 1 + (col - n_enc);
+      half_t t = hrow[0];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) t = (g == q) ? hrow[q] : t;  // register select: no dynamic indexing
+      val = t;
+    }
     v[e] = val;
   }
   *reinterpret_cast<uint4*>(xa + j * in_pad + ch * 8) = *reinterpret_cast<uint4*>(v);
