@@ -159,6 +159,8 @@ int l4d_attr_scatter(const int32_t* idx, const int32_t* count, int64_t cap, cons
 int l4d_attr_scatter_bwd(const int32_t* idx, const int32_t* count, int64_t cap, const float* d_attr,
                          const float* attr_compact, float loss_scale, void* dy_raydrop, void* dy_intensity,
                          void* stream);
+/* dh [P,16] fp16 (zero-filled by the caller): columns 1..n_geo of row idx[j] <- dxa_raydrop[j] + dxa_intensity[j] (geo
+ * columns); column 0 of those rows is written as 0 -- call l4d_sigma_bwd AFTER this to fill it. */
 int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int64_t cap, const void* dxa_raydrop,
                         const void* dxa_intensity, int32_t in_pad, int32_t n_enc, int32_t n_geo, void* dh,
                         void* stream);

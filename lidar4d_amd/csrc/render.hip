@@ -2,10 +2,10 @@
 // glue of the renderer for gfx950.  Replaces the torch op chains of model/renderer.py:59-129 and the
 // masked gather / scatter of model/lidar4d.py:196-219, plus tcnn's Frequency encoding (lidar4d.py:68-74).
 //
-// Compositing runs one 64-lane wave per ray: each lane owns a contiguous run of T/64 samples, forms its
-// local transmittance product, the wave combines lane products with a shuffle scan, and the
-// `weights > 1e-4` test is compacted with the same scan (wave-level compaction): lanes write their
-// surviving sample indices into a slot range reserved by ONE atomicAdd per ray.
+// Compositing runs one 64-lane wave per ray over chunks of 64 consecutive samples (lane = sample, dense accesses): the
+// wave combines the lanes' (1 - alpha) with a scan and carries the transmittance from chunk to chunk; the
+// `weights > 1e-4` test is compacted with ballots (wave-level compaction): lanes write their surviving sample indices
+// into a slot range reserved by ONE atomicAdd per ray.
 #include "common.h"
 
 #define MAXC 16  // samples per lane per segment -> segments of 1024 samples
@@ -32,18 +32,6 @@ __device__ __forceinline__ float wave_excl_scan_add(float v, int lane, float& to
   total = __shfl(inc, 63, 64);
   float ex = __shfl_up(inc, 1, 64);
   return lane == 0 ? 0.0f : ex;
-}
-
-__device__ __forceinline__ int wave_excl_scan_int(int v, int lane, int& total) {
-  int inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  total = __shfl(inc, 63, 64);
-  int ex = __shfl_up(inc, 1, 64);
-  return lane == 0 ? 0 : ex;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -95,57 +83,55 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
   if (ray >= N) return;
   const float* sg = sigma + ray * T;
   const float* zv = z_vals + ray * T;
-  float carry = 1.0f;  // transmittance entering the segment
+  float carry = 1.0f;  // transmittance entering the chunk
   float wsum = 0.0f, dsum = 0.0f;
+  // Chunks of 64 CONSECUTIVE samples, lane = sample: every load and store is one dense 256-byte access.  (Lane-owned
+  // runs of T/64 samples made each instruction touch 24 cache lines that were refetched for every k: the backward
+  // kernel fetched 4 GB for 0.3 GB of inputs, profiles/r01_pmc_FETCH_SIZE_c3_v10.txt.)
   for (int seg0 = 0; seg0 < T; seg0 += 64 * MAXC) {
     const int seg_len = min(T - seg0, 64 * MAXC);
-    const int c = (seg_len + 63) / 64;  // samples per lane in this segment
-    const int j0 = seg0 + lane * c;
-    float a[MAXC];
-    float prod = 1.0f;
+    const int c = (seg_len + 63) / 64;  // chunks in this segment
+    unsigned long long keep[MAXC];
+    int n_keep = 0;
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
-      const int j = j0 + k;
-      a[k] = 0.0f;
-      if (k < c && j < seg0 + seg_len) {
-        const float delta = (j + 1 < T) ? (zv[j + 1] - zv[j]) : sample_dist;
-        a[k] = alpha_of(delta, sg[j], density_scale, active);
-        prod *= (1.0f - a[k]) + 1e-15f;
+      keep[k] = 0ull;
+      if (k >= c) continue;  // wave-uniform
+      const int j = seg0 + k * 64 + lane;
+      const bool in = j < seg0 + seg_len;
+      float a = 0.0f, f = 1.0f, z = 0.0f;
+      if (in) {
+        z = zv[j];
+        const float delta = (j + 1 < T) ? (zv[j + 1] - z) : sample_dist;
+        a = alpha_of(delta, sg[j], density_scale, active);
+        f = (1.0f - a) + 1e-15f;
       }
-    }
-    float total;
-    float tr = carry * wave_excl_scan_mul(prod, lane, total);
-    int cnt = 0;
-    uint32_t keep = 0;
-    float w[MAXC];
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      const int j = j0 + k;
-      w[k] = 0.0f;
-      if (k < c && j < seg0 + seg_len) {
-        w[k] = a[k] * tr;
-        tr *= (1.0f - a[k]) + 1e-15f;
-        weights[ray * T + j] = w[k];
-        wsum += w[k];
-        dsum += w[k] * zv[j];
-        const bool m = w[k] > 1e-4f;
+      float total;
+      const float tr = carry * wave_excl_scan_mul(f, lane, total);
+      carry *= total;
+      const float w = a * tr;
+      bool m = false;
+      if (in) {
+        weights[ray * T + j] = w;
+        wsum += w;
+        dsum += w * z;
+        m = w > 1e-4f;
         if (mask) mask[ray * T + j] = m ? 1 : 0;
-        if (m) {
-          keep |= 1u << k;
-          ++cnt;
-        }
       }
+      keep[k] = __ballot(m);
+      n_keep += __popcll(keep[k]);
     }
-    carry *= total;
-    if (mask_idx) {
-      int tot;
-      int off = wave_excl_scan_int(cnt, lane, tot);
+    if (mask_idx && n_keep > 0) {  // wave-level compaction: ONE atomicAdd per ray segment reserves the slots
       int base = 0;
-      if (lane == 0 && tot > 0) base = atomicAdd(mask_count, tot);
+      if (lane == 0) base = atomicAdd(mask_count, n_keep);
       base = __shfl(base, 0, 64);
 #pragma unroll
-      for (int k = 0; k < MAXC; ++k)
-        if (keep & (1u << k)) mask_idx[base + off++] = (int32_t)(ray * T + j0 + k);
+      for (int k = 0; k < MAXC; ++k) {
+        if (k >= c) continue;
+        const unsigned long long below = keep[k] & ((1ull << lane) - 1ull);
+        if ((keep[k] >> lane) & 1ull) mask_idx[base + __popcll(below)] = (int32_t)(ray * T + seg0 + k * 64 + lane);
+        base += __popcll(keep[k]);
+      }
     }
   }
   wsum = wave_sum(wsum);
@@ -191,8 +177,9 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
   float gi[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < C && c < 4; ++c) gi[c] = d_image ? d_image[ray * C + c] : 0.0f;
   const float kappa = active ? 2.0f : 1.0f;
-  // walk segments from the far end so the suffix sum is available; transmittance entering a segment is
-  // recovered from a first forward pass over segment products
+  // Same chunking as the forward kernel (lane = sample inside a chunk of 64 consecutive samples: dense accesses).
+  // Segments are walked from the far end so the suffix sum is available; the transmittance entering a segment comes
+  // from a first pass over the segment products, the one entering a chunk from a forward pass inside the segment.
   const int nseg = (T + 64 * MAXC - 1) / (64 * MAXC);
   float seg_in[8];  // supports T <= 8192
   {
@@ -202,9 +189,10 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
       const int seg0 = s * 64 * MAXC, seg_len = min(T - seg0, 64 * MAXC), c = (seg_len + 63) / 64;
       float prod = 1.0f;
       for (int k = 0; k < c; ++k) {
-        const int j = seg0 + lane * c + k;
+        const int j = seg0 + k * 64 + lane;
         if (j < seg0 + seg_len) {
-          const float delta = (j + 1 < T) ? (zv[j + 1] - zv[j]) : sample_dist;
+          const float z = zv[j];
+          const float delta = (j + 1 < T) ? (zv[j + 1] - z) : sample_dist;
           prod *= (1.0f - alpha_of(delta, sg[j], density_scale, active)) + 1e-15f;
         }
       }
@@ -213,51 +201,54 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
       carry *= total;
     }
   }
-  float suffix_carry = 0.0f;  // sum_{k in later segments} gw_k w_k
+  float suffix_carry = 0.0f;  // sum_{k in later chunks / segments} gw_k w_k
   for (int s = nseg - 1; s >= 0; --s) {
     const int seg0 = s * 64 * MAXC, seg_len = min(T - seg0, 64 * MAXC), c = (seg_len + 63) / 64;
-    const int j0 = seg0 + lane * c;
-    float a[MAXC], dl[MAXC], gw[MAXC], w[MAXC];
-    float prod = 1.0f, gsum = 0.0f;
+    float a[MAXC], dl[MAXC], trv[MAXC];
+    float carry = seg_in[s];
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      const int j = j0 + k;
-      a[k] = 0.0f; dl[k] = 0.0f; gw[k] = 0.0f; w[k] = 0.0f;
-      if (k < c && j < seg0 + seg_len) {
-        dl[k] = (j + 1 < T) ? (zv[j + 1] - zv[j]) : sample_dist;
+    for (int k = 0; k < MAXC; ++k) {  // forward: alpha and the transmittance of every sample
+      a[k] = 0.0f; dl[k] = 0.0f; trv[k] = 0.0f;
+      if (k >= c) continue;
+      const int j = seg0 + k * 64 + lane;
+      float f = 1.0f;
+      if (j < seg0 + seg_len) {
+        const float z = zv[j];
+        dl[k] = (j + 1 < T) ? (zv[j + 1] - z) : sample_dist;
         a[k] = alpha_of(dl[k], sg[j], density_scale, active);
-        prod *= (1.0f - a[k]) + 1e-15f;
-        w[k] = weights[ray * T + j];
-        float g = gd * zv[j] + gs;
+        f = (1.0f - a[k]) + 1e-15f;
+      }
+      float total;
+      trv[k] = carry * wave_excl_scan_mul(f, lane, total);
+      carry *= total;
+    }
+#pragma unroll
+    for (int k = MAXC - 1; k >= 0; --k) {  // backward: suffix sums
+      if (k >= c) continue;
+      const int j = seg0 + k * 64 + lane;
+      const bool in = j < seg0 + seg_len;
+      float g = 0.0f, w = 0.0f;
+      if (in) {
+        w = weights[ray * T + j];
+        g = gd * zv[j] + gs;
         if (d_weights) g += d_weights[ray * T + j];
         if (attr) {
           for (int cc = 0; cc < C && cc < 4; ++cc) g += gi[cc] * attr[(ray * T + j) * C + cc];
         }
-        gw[k] = g;
-        gsum += g * w[k];
         if (d_attr)
-          for (int cc = 0; cc < C && cc < 4; ++cc) d_attr[(ray * T + j) * C + cc] = w[k] * gi[cc];
+          for (int cc = 0; cc < C && cc < 4; ++cc) d_attr[(ray * T + j) * C + cc] = w * gi[cc];
       }
-    }
-    float total, gtotal;
-    float tr = seg_in[s] * wave_excl_scan_mul(prod, lane, total);
-    const float before = wave_excl_scan_add(gsum, lane, gtotal);
-    // suffix over lanes after this one (exclusive of own run) + later segments
-    float suf = (gtotal - before - gsum) + suffix_carry;
-    // within the lane: iterate forward, keeping the suffix of the remaining own samples
-    float own_after = gsum;
-#pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      const int j = j0 + k;
-      if (k < c && j < seg0 + seg_len) {
-        own_after -= gw[k] * w[k];
+      const float q = g * w;
+      float qtotal;
+      const float before = wave_excl_scan_add(q, lane, qtotal);
+      const float suf = (qtotal - before - q) + suffix_carry;  // samples after this one
+      if (in) {
         const float one_m = (1.0f - a[k]) + 1e-15f;
-        const float da = gw[k] * tr - (own_after + suf) / one_m;
+        const float da = g * trv[k] - suf / one_m;
         d_sigma[ray * T + j] = da * (kappa * dl[k] * density_scale * (1.0f - a[k]));
-        tr *= one_m;
       }
+      suffix_carry += qtotal;
     }
-    suffix_carry += gtotal;
   }
 }
 
@@ -377,6 +368,32 @@ __global__ void __launch_bounds__(256) attr_gather_bwd_kernel(const int32_t* __r
   dh[p * 16 + 1 + k] = f2h(fminf(fmaxf(v, -65504.f), 65504.f));
 }
 
+// Same, one thread per row with 16-byte accesses, for the usual layout (n_enc a multiple of 8, 16 columns available):
+// reads columns n_enc .. n_enc+15 of both gradients, writes the whole 32-byte dh row (column 0, the sigma gradient, is
+// written afterwards by sigma_bwd_kernel; rows outside idx keep their zeros).
+__global__ void __launch_bounds__(256) attr_gather_bwd_rows_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+                                                                  int64_t cap, const half_t* __restrict__ dxa_r,
+                                                                  const half_t* __restrict__ dxa_i, int in_pad, int n_enc,
+                                                                  int n_geo, half_t* __restrict__ dh) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t M = count ? min((int64_t)*count, cap) : cap;
+  if (j >= M) return;
+  const int64_t p = idx ? idx[j] : j;
+  half_t r[16], q[16], o[16];
+  *reinterpret_cast<uint4*>(r) = *reinterpret_cast<const uint4*>(dxa_r + j * in_pad + n_enc);
+  *reinterpret_cast<uint4*>(r + 8) = *reinterpret_cast<const uint4*>(dxa_r + j * in_pad + n_enc + 8);
+  *reinterpret_cast<uint4*>(q) = *reinterpret_cast<const uint4*>(dxa_i + j * in_pad + n_enc);
+  *reinterpret_cast<uint4*>(q + 8) = *reinterpret_cast<const uint4*>(dxa_i + j * in_pad + n_enc + 8);
+  o[0] = (half_t)0.0f;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    const float v = h2f(r[k]) + h2f(q[k]);
+    o[1 + k] = k < n_geo ? f2h(fminf(fmaxf(v, -65504.f), 65504.f)) : (half_t)0.0f;
+  }
+  *reinterpret_cast<uint4*>(dh + p * 16) = *reinterpret_cast<uint4*>(o);
+  *reinterpret_cast<uint4*>(dh + p * 16 + 8) = *reinterpret_cast<uint4*>(o + 8);
+}
+
 // sigma = trunc_exp(h[:,0]) (activation.py:6-20) and its backward into dh[:,0] (fp16, loss-scaled)
 __global__ void __launch_bounds__(256) sigma_from_h_kernel(const half_t* __restrict__ h, int64_t P, float* __restrict__ sigma) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -482,9 +499,14 @@ extern "C" int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int
                                    const void* dxa_intensity, int32_t in_pad, int32_t n_enc, int32_t n_geo, void* dh,
                                    void* stream) {
   if (cap == 0) return 0;
-  hipLaunchKernelGGL(attr_gather_bwd_kernel, dim3((unsigned)ceil_div64(cap * n_geo, 256)), dim3(256), 0, (hipStream_t)stream,
-                     idx, count, cap, (const half_t*)dxa_raydrop, (const half_t*)dxa_intensity, in_pad, n_enc, n_geo,
-                     (half_t*)dh);
+  if ((n_enc & 7) == 0 && n_enc + 16 <= in_pad && n_geo <= 15)
+    hipLaunchKernelGGL(attr_gather_bwd_rows_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream,
+                       idx, count, cap, (const half_t*)dxa_raydrop, (const half_t*)dxa_intensity, in_pad, n_enc, n_geo,
+                       (half_t*)dh);
+  else
+    hipLaunchKernelGGL(attr_gather_bwd_kernel, dim3((unsigned)ceil_div64(cap * n_geo, 256)), dim3(256), 0, (hipStream_t)stream,
+                       idx, count, cap, (const half_t*)dxa_raydrop, (const half_t*)dxa_intensity, in_pad, n_enc, n_geo,
+                       (half_t*)dh);
   L4D_LAUNCH_CHECK("l4d_attr_gather_bwd");
   return 0;
 }
