@@ -93,27 +93,6 @@ __device__ __forceinline__ void scatter_plane(float* __restrict__ gbase, const f
 }
 
 
-// d(sample)/d(ix), d(sample)/d(iy) contracted with gv (ATen grid_sampler_2d_backward, no parameter scatter).
-template <int C>
-__device__ __forceinline__ void plane_coord_grad(const float* __restrict__ base, int W, const Tap& t, const float gv[C],
-                                                 float& gix, float& giy) {
-  const size_t o00 = ((size_t)t.y0 * W + t.x0) * C, o01 = ((size_t)t.y0 * W + t.x1) * C;
-  const size_t o10 = ((size_t)t.y1 * W + t.x0) * C, o11 = ((size_t)t.y1 * W + t.x1) * C;
-#pragma unroll
-  for (int k = 0; k < C; ++k) {
-    const float g = gv[k];
-    const float v00 = base[o00 + k], v01 = base[o01 + k], v10 = base[o10 + k], v11 = base[o11 + k];
-    gix -= v00 * t.wy0 * g;
-    giy -= v00 * t.wx0 * g;
-    gix += v01 * t.wy0 * g;
-    giy -= v01 * t.wx1 * g;
-    gix -= v10 * t.wy1 * g;
-    giy += v10 * t.wx0 * g;
-    gix += v11 * t.wy1 * g;
-    giy += v11 * t.wx1 * g;
-  }
-}
-
 // Bilinear sample that also returns d(sample . gv)/d(ix), d/d(iy) pieces: loads the four taps ONCE (8 x 16 B) and
 // gives the interpolated value; call coord_grad_from_taps afterwards with the same tap registers.
 template <int C>

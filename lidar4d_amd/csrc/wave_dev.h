@@ -35,34 +35,12 @@ __device__ __forceinline__ bool wave_run_reduce(uint32_t key, bool active, float
   return head && active;
 }
 
-// Row merge: when all 16 lanes of a DPP row (16 consecutive samples of a ray) target the same address -- the normal
-// case on coarse planes / levels -- sum them with 4 v_add_f32_dpp (pure VALU, no LDS traffic; __shfl goes through the
-// LDS crossbar like the atomics it is meant to spare) and let lane 15 of the row issue the add.  Rows that are not
-// uniform keep one add per lane.  Returns true for lanes that must issue.
-template <int K>
-__device__ __forceinline__ bool row_merge(uint32_t key, bool active, float v[K]) {
-  const int lane = __lane_id();
-  const uint32_t k0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x150 /*row_newbcast:0*/, 0xf, 0xf, false);
-  const unsigned long long same = __ballot(active && key == k0);
-  if (((same >> (lane & 48)) & 0xFFFFull) != 0xFFFFull) return active;  // uniform per row: all 16 lanes agree
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    float x = v[k];
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
-    v[k] = x;
-  }
-  return (lane & 15) == 15;
-}
-
 // Run merge inside DPP rows.  Consecutive lanes are consecutive samples of a ray, so lanes that target the same texel /
 // table entry form contiguous runs.  row_runs() finds the runs inside each 16-lane row from the keys (one row_shr
 // compare + one ballot), row_scan() is a segmented Hillis-Steele scan over them -- per value 4 v_fmac_f32_dpp (pure
 // VALU; the flags f1..f8 switch the adds off across run boundaries) -- after which the LAST lane of every run holds the
-// run's total and is the only one that needs to issue an atomic.  Unlike row_merge this also merges rows that hold
-// several runs (fine scales, where a row of 16 samples crosses 2-3 texels).
+// run's total and is the only one that needs to issue an atomic.  Rows that hold several runs (fine scales, where 16
+// samples cross 2-3 texels) are merged run by run.
 struct RowRuns {
   float f1, f2, f4, f8;  // 1.0 if the lane 1/2/4/8 to the left is in the same run (and the same row), else 0.0
   bool tail;             // this lane is the last of its run
