@@ -12,10 +12,9 @@ from . import _lib, ops
 class chamfer_3DFunction(Function):
     @staticmethod
     def forward(ctx, xyz1, xyz2):
-        batchsize, n, dim = xyz1.size()
-        assert dim == 3, "Wrong last dimension for the chamfer distance 's input! Check with .size()"
-        _, m, dim = xyz2.size()
-        assert dim == 3, "Wrong last dimension for the chamfer distance 's input! Check with .size()"
+        if xyz1.dim() != 3 or xyz2.dim() != 3 or xyz1.shape[-1] != 3 or xyz2.shape[-1] != 3 or xyz1.shape[0] != xyz2.shape[0]:
+            raise ValueError(f"chamfer_3DDist expects clouds [B, n, 3] and [B, m, 3]; got {tuple(xyz1.shape)} and {tuple(xyz2.shape)}")
+        batchsize, n, m = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
         xyz1 = xyz1.detach().float().contiguous()
         xyz2 = xyz2.detach().float().contiguous()
         ops._chk(xyz1, torch.float32, "xyz1"), ops._chk(xyz2, torch.float32, "xyz2")

@@ -11,12 +11,14 @@ from .convert import pano_to_lidar
 
 
 def fscore(dist1, dist2, threshold=0.001):
-    """utils/metrics.py:13-27 (dist1/dist2 are squared distances [B, n])."""
-    precision_1 = torch.mean((dist1 < threshold).float(), dim=1)
-    precision_2 = torch.mean((dist2 < threshold).float(), dim=1)
-    f = 2 * precision_1 * precision_2 / (precision_1 + precision_2)
-    f[torch.isnan(f)] = 0
-    return f, precision_1, precision_2
+    """utils/metrics.py:13-27.  dist1 [B, n] / dist2 [B, m]: SQUARED nearest-neighbour distances of the two directions
+    (so ``threshold`` is a squared distance too).  Returns (F-score, precision, recall), each [B]; F is 0 where both
+    precision and recall are 0."""
+    precision = (dist1 < threshold).float().mean(dim=1)
+    recall = (dist2 < threshold).float().mean(dim=1)
+    denom = precision + recall
+    f = torch.where(denom > 0, 2 * precision * recall / denom.clamp_min(1e-30), torch.zeros_like(denom))
+    return f, precision, recall
 
 
 class PointsMeter:
