@@ -26,6 +26,7 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));  // arithmetic on it compiles to v_pk_*_f32 (2 fp32 ops per lane-instruction)
 
 __device__ __forceinline__ float h2f(half_t h) { return (float)h; }
 __device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }  // round-to-nearest-even

@@ -97,10 +97,15 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
     for (int j = 0; j < 3; ++j) {
       half_t hv[C];
 #pragma unroll
-      for (int k = 0; k < C; ++k) {
-        const float gv = gs[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
-        hv[k] = f2h(fminf(fmaxf(gv, -65504.f), 65504.f));
-        smax = fmaxf(smax, fabsf(h2f(hv[k])));
+      for (int k = 0; k < C; k += 2) {  // packed fp32 products, two channels per instruction
+        const float2_t g2 = {gs[k], gs[k + 1]}, va = {v[(j + 1) % 3][k], v[(j + 1) % 3][k + 1]};
+        const float2_t vb = {v[(j + 2) % 3][k], v[(j + 2) % 3][k + 1]};
+        const float2_t gv = g2 * va * vb;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          hv[k + u] = f2h(fminf(fmaxf(gv[u], -65504.f), 65504.f));
+          smax = fmaxf(smax, fabsf(h2f(hv[k + u])));
+        }
       }
       if (valid) *reinterpret_cast<uint4*>(gvs + ((int64_t)(s * 3 + j) * P + p) * C) = *reinterpret_cast<uint4*>(hv);
     }
@@ -213,7 +218,13 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
           const int W = fd.planes.res[s][j];
           float gv[C];
 #pragma unroll
-          for (int k = 0; k < C; ++k) gv[k] = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
+          for (int k = 0; k < C; k += 2) {  // packed fp32: two channels per instruction
+            const float2_t g2 = {gd[k], gd[k + 1]}, va = {v[(j + 1) % 3][k], v[(j + 1) % 3][k + 1]};
+            const float2_t vb = {v[(j + 2) % 3][k], v[(j + 2) % 3][k + 1]};
+            const float2_t r = coef * g2 * va * vb;
+            gv[k] = r[0];
+            gv[k + 1] = r[1];
+          }
           if (e > 0) {  // coordinate adjoint of the warped lookups (time plane j pairs spatial axis j with t)
             TapVals<C> tv;
             float dummy[C];
@@ -230,7 +241,11 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
             const float wxf = (qx == 0 ? t.wx0 : t.wx1) * fxs;
             float vals[C];
 #pragma unroll
-            for (int k = 0; k < C; ++k) vals[k] = gv[k] * wxf;
+            for (int k = 0; k < C; k += 2) {
+              const float2_t r = float2_t{gv[k], gv[k + 1]} * wxf;
+              vals[k] = r[0];
+              vals[k + 1] = r[1];
+            }
             row_scan<C>(runs, vals);
             if (!runs.tail) continue;  // (inactive lanes carry zeros and a valid clamped key: harmless in any run)
             int* dst = acc + xq * C;
@@ -359,13 +374,18 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
       const bool in = q < 2 ? in0 : in1;
       if (!__any(in)) continue;
       float vals[C];
+      const float wq = in ? wts[q] * fxs : 0.0f;  // fixed-point scale folded into the tap weight
 #pragma unroll
-      for (int k = 0; k < C; ++k) vals[k] = in ? gv[k] * wts[q] : 0.0f;
+      for (int k = 0; k < C; k += 2) {
+        const float2_t r = float2_t{gv[k], gv[k + 1]} * wq;
+        vals[k] = r[0];
+        vals[k + 1] = r[1];
+      }
       row_scan<C>(runs, vals);
       if (!(runs.tail && in)) continue;
       int* dst = &lds_i[((ys[q] - row0) * W + xs_[q]) * C];
 #pragma unroll
-      for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k] * fxs));
+      for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k]));
     }
     }  // while (todo)
   }

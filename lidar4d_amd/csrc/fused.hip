@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
                                                                     const half_t* __restrict__ flow16,
                                                                     const float* __restrict__ tinfo, int64_t P, int64_t chunk,
                                                                     half_t* __restrict__ hdT) {
-  extern __shared__ uint2 lds_tab[];
+  extern __shared__ uint4 lds_tab[];  // [entry] = {slice i1: 4 halfs, slice i2: 4 halfs}: both slices of a corner in ONE ds_read_b128
   // task = (plane in {xz, yz}, level); hdT column = levels(xy) + ...
   int task = blockIdx.y, plane = 1;
   if (task >= fd.hd[1].n_levels) { task -= fd.hd[1].n_levels; plane = 2; }
@@ -210,8 +210,11 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
     const uint2* t1p = reinterpret_cast<const uint2*>(fd.hd_tables[plane][tc[0].sp.i1] + (size_t)g.offset[lvl] * 4);
     const uint2* t2p = reinterpret_cast<const uint2*>(fd.hd_tables[plane][tc[0].sp.i2] + (size_t)g.offset[lvl] * 4);
     for (uint32_t i = threadIdx.x * 2; i < size; i += DH_THREADS * 2) {  // sizes are multiples of 8 entries
-      *reinterpret_cast<uint4*>(&lds_tab[i]) = *reinterpret_cast<const uint4*>(&t1p[i]);
-      if (two) *reinterpret_cast<uint4*>(&lds_tab[size + i]) = *reinterpret_cast<const uint4*>(&t2p[i]);
+      const uint4 a2 = *reinterpret_cast<const uint4*>(&t1p[i]);  // entries i, i+1 of slice i1
+      uint4 b2 = a2;
+      if (two) b2 = *reinterpret_cast<const uint4*>(&t2p[i]);
+      lds_tab[i] = make_uint4(a2.x, a2.y, b2.x, b2.y);
+      lds_tab[i + 1] = make_uint4(a2.z, a2.w, b2.z, b2.w);
     }
   }
   __syncthreads();
@@ -240,15 +243,21 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
         uint32_t gv[2];
         const float w = corner<2>(c, cn, gv);
         const uint32_t idx = grid_index<2>(gv, res, size, hashed);
-        const uint2 ra = lds_tab[idx];
-        const half_t* ha = reinterpret_cast<const half_t*>(&ra);
+        const uint4 rab = lds_tab[idx];
+        const half_t* ha = reinterpret_cast<const half_t*>(&rab);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) a[f] += w * h2f(ha[f]);
+        for (int f = 0; f < 4; f += 2) {  // packed fp32: two features per instruction
+          const float2_t ra = float2_t{a[f], a[f + 1]} + float2_t{h2f(ha[f]), h2f(ha[f + 1])} * w;
+          a[f] = ra[0];
+          a[f + 1] = ra[1];
+        }
         if (two) {
-          const uint2 rb = lds_tab[size + idx];
-          const half_t* hb = reinterpret_cast<const half_t*>(&rb);
 #pragma unroll
-          for (int f = 0; f < 4; ++f) b[f] += w * h2f(hb[f]);
+          for (int f = 0; f < 4; f += 2) {
+            const float2_t rb = float2_t{b[f], b[f + 1]} + float2_t{h2f(ha[4 + f]), h2f(ha[5 + f])} * w;
+            b[f] = rb[0];
+            b[f + 1] = rb[1];
+          }
         }
       }
       if (two) {

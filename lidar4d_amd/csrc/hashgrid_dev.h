@@ -95,8 +95,17 @@ __device__ __forceinline__ void level_lookup(const half_t* level_table, float sc
     uint32_t idx = grid_index<D>(g, res, size, hashed);
     float v[F];
     load_entry<F>(level_table + (size_t)idx * F, v);
+    if (F % 2 == 0) {
 #pragma unroll
-    for (int f = 0; f < F; ++f) out[f] += w * v[f];
+      for (int f = 0; f + 1 < F; f += 2) {  // v_pk_mul_f32 + v_pk_add_f32: two features per instruction, same roundings
+        const float2_t r = float2_t{out[f], out[f + 1]} + float2_t{v[f], v[f + 1]} * w;
+        out[f] = r[0];
+        out[f + 1] = r[1];
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) out[f] += w * v[f];
+    }
   }
 }
 
