@@ -218,13 +218,7 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
           const int W = fd.planes.res[s][j];
           float gv[C];
 #pragma unroll
-          for (int k = 0; k < C; k += 2) {  // packed fp32: two channels per instruction
-            const float2_t g2 = {gd[k], gd[k + 1]}, va = {v[(j + 1) % 3][k], v[(j + 1) % 3][k + 1]};
-            const float2_t vb = {v[(j + 2) % 3][k], v[(j + 2) % 3][k + 1]};
-            const float2_t r = coef * g2 * va * vb;
-            gv[k] = r[0];
-            gv[k + 1] = r[1];
-          }
+          for (int k = 0; k < C; ++k) gv[k] = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
           if (e > 0) {  // coordinate adjoint of the warped lookups (time plane j pairs spatial axis j with t)
             TapVals<C> tv;
             float dummy[C];
@@ -241,11 +235,7 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
             const float wxf = (qx == 0 ? t.wx0 : t.wx1) * fxs;
             float vals[C];
 #pragma unroll
-            for (int k = 0; k < C; k += 2) {
-              const float2_t r = float2_t{gv[k], gv[k + 1]} * wxf;
-              vals[k] = r[0];
-              vals[k + 1] = r[1];
-            }
+            for (int k = 0; k < C; ++k) vals[k] = gv[k] * wxf;
             row_scan<C>(runs, vals);
             if (!runs.tail) continue;  // (inactive lanes carry zeros and a valid clamped key: harmless in any run)
             int* dst = acc + xq * C;

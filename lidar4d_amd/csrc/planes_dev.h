@@ -52,13 +52,7 @@ __device__ __forceinline__ void sample_plane(const float* __restrict__ base, int
   for (int q = 0; q < C / 4; ++q) {
     float4_t a = p00[q], b4 = p01[q], c = p10[q], d = p11[q];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {  // two channels per v_pk_mul_f32 / v_pk_add_f32 (same roundings as the scalar form)
-      const float2_t av = {a[2 * h], a[2 * h + 1]}, bv = {b4[2 * h], b4[2 * h + 1]};
-      const float2_t cv = {c[2 * h], c[2 * h + 1]}, dv = {d[2 * h], d[2 * h + 1]};
-      const float2_t r = ((av * nw + bv * ne) + cv * sw) + dv * se;
-      out[q * 4 + 2 * h] = r[0];
-      out[q * 4 + 2 * h + 1] = r[1];
-    }
+    for (int j = 0; j < 4; ++j) out[q * 4 + j] = ((a[j] * nw + b4[j] * ne) + c[j] * sw) + d[j] * se;
   }
 }
 
@@ -118,29 +112,17 @@ __device__ __forceinline__ void load_taps(const float* __restrict__ base, int W,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       tv.v00[q * 4 + j] = a[j]; tv.v01[q * 4 + j] = b[j]; tv.v10[q * 4 + j] = c[j]; tv.v11[q * 4 + j] = d[j];
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float2_t av = {a[2 * h], a[2 * h + 1]}, bv = {b[2 * h], b[2 * h + 1]};
-      const float2_t cv = {c[2 * h], c[2 * h + 1]}, dv = {d[2 * h], d[2 * h + 1]};
-      const float2_t r = ((av * nw + bv * ne) + cv * sw) + dv * se;
-      out[q * 4 + 2 * h] = r[0];
-      out[q * 4 + 2 * h + 1] = r[1];
+      out[q * 4 + j] = ((a[j] * nw + b[j] * ne) + c[j] * sw) + d[j] * se;
     }
   }
 }
 template <int C>
 __device__ __forceinline__ void coord_grad_from_taps(const TapVals<C>& tv, const Tap& t, const float gv[C], float& gix, float& giy) {
   // ATen grid_sampler_2d_backward: gix = sum_k g_k [(v01 - v00) wy0 + (v11 - v10) wy1], giy likewise with x and y swapped
-  float2_t ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f};
 #pragma unroll
-  for (int k = 0; k < C; k += 2) {
-    const float2_t g = {gv[k], gv[k + 1]};
-    const float2_t v00 = {tv.v00[k], tv.v00[k + 1]}, v01 = {tv.v01[k], tv.v01[k + 1]};
-    const float2_t v10 = {tv.v10[k], tv.v10[k + 1]}, v11 = {tv.v11[k], tv.v11[k + 1]};
-    ax += ((v01 - v00) * t.wy0 + (v11 - v10) * t.wy1) * g;
-    ay += ((v10 - v00) * t.wx0 + (v11 - v01) * t.wx1) * g;
+  for (int k = 0; k < C; ++k) {
+    const float g = gv[k];
+    gix += ((tv.v01[k] - tv.v00[k]) * t.wy0 + (tv.v11[k] - tv.v10[k]) * t.wy1) * g;
+    giy += ((tv.v10[k] - tv.v00[k]) * t.wx0 + (tv.v11[k] - tv.v01[k]) * t.wx1) * g;
   }
-  gix += ax[0] + ax[1];
-  giy += ay[0] + ay[1];
 }
