@@ -129,7 +129,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # L4D_FORCE_DIST=1: take the multi-rank code path (RCCL init, barrier, gradient all-reduce) even with one rank --
+    # lets the data-parallel path be exercised on a single-GPU box (python -m torch.distributed.run --nproc-per-node 1)
+    force_dist = os.environ.get("L4D_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
@@ -161,7 +164,7 @@ def main():
         step = trainer.train_step
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +176,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -249,7 +252,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not inference:
             line["cpu_baseline"] = cpu_baseline(51, KITTI360_SCALE)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

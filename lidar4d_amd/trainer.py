@@ -6,6 +6,8 @@ optimizer main_lidar4d.py:298-305) plus the inference step of the evaluation / s
 (runner.py:438-470: staged render of a whole frame, U-Net ray-drop refinement, masking) and the optional ray-chamfer and
 scene-flow loss terms (runner.py:215-253).  The line-of-sight (urf) loss, EMA, checkpoints and logging are out of scope.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -138,6 +140,8 @@ class Trainer:
             self.pc_list, self.pc_ground_list = process_pointcloud(dataset)
         self.opt = FlatAdam(model, lr=lr, iters=iters)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # a one-rank process group still runs the collective when asked to (bench.py L4D_FORCE_DIST: exercises RCCL on one GPU)
+        self.force_allreduce = dist.is_available() and dist.is_initialized() and os.environ.get("L4D_FORCE_DIST") == "1"
 
     def train_step(self, data=None):
         data = data if data is not None else self.dataset.batch()
@@ -152,7 +156,7 @@ class Trainer:
         loss.backward()
         if self.flow:
             self.model._store.prepare_grads()  # fold gradients autograd produced outside the fused node into the arena
-        if self.world > 1:
+        if self.world > 1 or self.force_allreduce:
             dist.all_reduce(self.model._store.flat_grad, op=dist.ReduceOp.SUM)
         self.opt.step()
         return loss
