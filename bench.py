@@ -8,8 +8,9 @@ A step = forward + backward + Adam of ``render(staged=False, perturb=True)`` wit
 losses (runner.py:179-213) on one batch of synthetic KITTI-360-shaped rays (64 x 1024 panorama, T = 768 samples per
 ray).  Default workload = BASELINE.json configs[2] ("C3": full 4D field -- hash + hex-planes + flow --
 16,384 rays/batch/GPU), whose 8-GPU weak-scaled form is configs[3] (131,072 rays/step), the configuration the
-headline ">= 10 M training rays/s on 8 x MI355X" is quoted on.  Rank r draws its own frames and ray indices; the
-flat gradient buffer is SUM-all-reduced over RCCL once per step.  Inputs are resident in HBM before the timed region.
+headline ">= 10 M training rays/s on 8 x MI355X" is quoted on.  Rank r draws its own ray indices (all ranks step through the same
+frame sequence, so that the per-step work is the same everywhere); the flat gradient buffer is SUM-all-reduced over RCCL
+once per step.  Inputs are resident in HBM before the timed region.
 
 The JSON line also carries `roofline` (dominant kernel: algorithmic bytes / measured launch time vs the 8 TB/s HBM
 peak; per-kernel times come from HIP events recorded around every launch on the launch stream in a separate
@@ -144,7 +145,8 @@ def main():
     torch.manual_seed(0)  # identical initial replicas on every rank
     model = LiDAR4D(near_lidar=1.0 * KITTI360_SCALE, far_lidar=81.0 * KITTI360_SCALE, num_frames=51, **model_kw).to(dev)
     inference = args.workload in INFERENCE
-    data = SyntheticKitti360(dev, W=2048 if inference else 1024, num_rays=n_rays, seed=1000 + rank, sort_pixels=args.sort_rays)
+    data = SyntheticKitti360(dev, W=2048 if inference else 1024, num_rays=n_rays, seed=1000 + rank, sort_pixels=args.sort_rays,
+                             frame_seed=1000)  # every rank: its own rays, the same frame sequence (equal work per step)
     trainer = Trainer(model, data, chamfer=args.chamfer, flow=args.flow)
     if inference:
         from lidar4d_amd.data import KITTI360_FOV

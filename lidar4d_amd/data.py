@@ -81,14 +81,16 @@ class SyntheticKitti360:
     and serves per-step ray batches like KITTI360Dataset.collate (one frame per step)."""
 
     def __init__(self, device, H=64, W=1024, num_frames=51, num_rays=4096, scale=KITTI360_SCALE, fov=KITTI360_FOV, seed=0,
-                 sort_pixels=False):
+                 sort_pixels=False, frame_seed=None):
         self.device, self.H, self.W, self.num_frames, self.num_rays = device, H, W, num_frames, num_rays
         self.sort_pixels = sort_pixels  # pixel_block_order; measured SLOWER on MI355X (66.3 vs 63.5 ms/step: neighbouring rays
         # pile onto the same LDS histogram bins / cache lines), kept as an option for experiments
         self.scale, self.fov = scale, fov
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
-        self.frame_gen = torch.Generator().manual_seed(seed)  # host-side frame choice: no device sync
+        # host-side frame choice: no device sync.  frame_seed: data-parallel ranks that share it step through the same
+        # frame sequence (each with its own rays) -- the per-step work depends on the frame, so this keeps ranks in step
+        self.frame_gen = torch.Generator().manual_seed(seed if frame_seed is None else frame_seed)
         g_cpu = torch.Generator().manual_seed(1234)
         self.poses, self.images = [], []
         for k in range(num_frames):
