@@ -165,6 +165,10 @@ class RenderFn(torch.autograd.Function):
         ops.planes_relayout(pe.layout, views, gcl, to_channel_last=False)
         for p, v in zip(planes, views):
             store.grad_view(p).add_(v.reshape(-1))
+        # every gradient except the flow field's is final now: a data-parallel trainer starts reducing them here
+        hook = getattr(model, "_grads_ready_hook", None)
+        if hook is not None:
+            hook()
         # flow network + grid
         fn = model.flow_net
         dxf = ops.mlp_bwd(xf, act_f, dflow16, _flow_w16(model), fn.n_hidden, _flow_wgrad(model), inv)

@@ -47,10 +47,22 @@ def _worker(rank, world, port, out):
     shard = n_total // world
     g = grads_for(rank * shard, (rank + 1) * shard).clone()
     dist.all_reduce(g, op=dist.ReduceOp.SUM)  # what Trainer.train_step does on flat_grad
+    # the trainer's two-phase (overlapped) reduction must give exactly what one all-reduce of the arena gives
+    from lidar4d_amd.trainer import GradReducer
+    red = GradReducer(shell)
+    mine = grads_for(rank * shard, (rank + 1) * shard)   # = store.flat_grad, this rank's shard gradient again
+    assert mine.data_ptr() == store.flat_grad.data_ptr()
+    red.early()      # what the fused backward triggers once the non-flow gradients are final
+    red.finish()     # flow range + wait
+    two_phase_equal = bool(torch.equal(store.flat_grad, g))
+    mine = grads_for(rank * shard, (rank + 1) * shard)
+    red.finish()     # no early(): single all-reduce fallback
+    fallback_equal = bool(torch.equal(store.flat_grad, g))
     if rank == 0:
         full = grads_for(0, n_total)
         err = float((g - full).abs().max() / full.abs().max())
-        out.put(("err", err, int(full.numel()), [list(r) for r in store.group_ranges]))
+        out.put(("err", err, int(full.numel()), [list(r) for r in store.group_ranges], two_phase_equal, fallback_equal,
+                 [red.flow_lo, red.flow_hi]))
     dist.destroy_process_group()
 
 
@@ -64,6 +76,8 @@ def test_ray_sharded_allreduce_equals_single_batch():
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    tag, err, numel, ranges = out.get(timeout=10)
+    tag, err, numel, ranges, two_phase_equal, fallback_equal, flow_range = out.get(timeout=10)
     assert tag == "err" and err < 1e-5, err
+    assert two_phase_equal and fallback_equal
+    assert ranges[1][0] == flow_range[0] < flow_range[1] < numel  # the flow field opens lr group 1
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == numel  # two contiguous lr groups
