@@ -108,3 +108,33 @@ def convert_inputs(H=64, W=1024):
     cloud[100:200] = cloud[0:100]            # exact duplicates (first wins)
     cloud[200:300, :3] = cloud[0:100, :3]    # same position, other intensity
     return depth, inten, cloud
+
+
+def write_kitti360_fixture(root, H=8, W=32, n_train=4, n_val=2):
+    """A tiny sequence in the reference's preprocessed KITTI-360 layout (transforms_<seq>_<split>.json + range-view
+    .npy files) with deterministic contents; returns the dataset arguments that go with it."""
+    import json
+    import os
+
+    cfg = {"sequence_id": "4950", "scale": 0.010504329815187737, "offset": [1012.5, 3792.25, 115.75], "fov_lidar": [2.0, 26.9]}
+    start = 4950
+    ids = {"train": [start + 1 + 3 * k for k in range(n_train)], "val": [start + 2 + 5 * k for k in range(n_val)]}
+    for split, frame_ids in ids.items():
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        frames = []
+        for fid in reversed(frame_ids):  # unsorted on purpose: the reader sorts by file path
+            ang = float(det_uniform((1,), f"k360a{fid}", -0.5, 0.5))
+            c, s = float(np.cos(ang)), float(np.sin(ang))
+            pos = det_uniform((3,), f"k360p{fid}", -20.0, 20.0).numpy() + np.asarray(cfg["offset"], dtype=np.float32)
+            pose = [[c, -s, 0.0, float(pos[0])], [s, c, 0.0, float(pos[1])], [0.0, 0.0, 1.0, float(pos[2])], [0.0, 0.0, 0.0, 1.0]]
+            view = np.zeros((H, W, 3), dtype=np.float32)
+            view[:, :, 1] = det_uniform((H, W), f"k360i{fid}", 0.0, 1.0).numpy()
+            depth = det_uniform((H, W), f"k360d{fid}", 2.0, 78.0).numpy()
+            depth[unit_hash(H * W, f"k360m{fid}").reshape(H, W) < 0.15] = 0.0
+            view[:, :, 2] = depth
+            rel = os.path.join(split, f"{fid:010d}.npy")
+            np.save(os.path.join(root, rel), view)
+            frames.append({"frame_id": fid, "lidar_file_path": rel, "lidar2world": pose})
+        with open(os.path.join(root, f"transforms_{cfg['sequence_id']}_{split}.json"), "w") as fh:
+            json.dump({"h_lidar": H, "w_lidar": W, "frames": frames}, fh)
+    return cfg

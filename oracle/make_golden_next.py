@@ -54,11 +54,40 @@ def gen_convert():
          pano_rt=pano_rt.astype(np.float32), pint_rt=pint_rt.astype(np.float32))
 
 
+def gen_kitti360():
+    """The reference's KITTI360Dataset on a tiny synthetic sequence written by oracle.detparams.write_kitti360_fixture."""
+    import tempfile
+
+    import data.kitti360_dataset as ref_ds
+    from oracle.detparams import write_kitti360_fixture
+
+    root = tempfile.mkdtemp(prefix="l4d_k360_")
+    cfg = write_kitti360_fixture(root)
+    out = {}
+    for split, n_rays in (("train", 48), ("val", 48)):
+        ds = ref_ds.KITTI360Dataset(device="cpu", split=split, root_path=root, sequence_id=cfg["sequence_id"], preload=True,
+                                    scale=cfg["scale"], offset=cfg["offset"], fp16=False, num_rays_lidar=n_rays,
+                                    fov_lidar=cfg["fov_lidar"])
+        torch.manual_seed(11)
+        b = ds.collate([1])
+        out.update({f"{split}_poses": ds.poses_lidar, f"{split}_images": ds.images_lidar, f"{split}_times": ds.times,
+                    f"{split}_rays_o": b["rays_o_lidar"], f"{split}_rays_d": b["rays_d_lidar"],
+                    f"{split}_batch_images": b["images_lidar"], f"{split}_time": b["time"],
+                    f"{split}_len": len(ds), f"{split}_num_rays": ds.num_rays_lidar})
+    half = ref_ds.KITTI360Dataset(device="cpu", split="train", root_path=root, sequence_id=cfg["sequence_id"], preload=True,
+                                  scale=cfg["scale"], offset=cfg["offset"], fp16=True, num_rays_lidar=16,
+                                  fov_lidar=cfg["fov_lidar"])
+    out["half_images"] = half.images_lidar.float()
+    save("kitti360_reader", **out)
+    shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     torch.set_num_threads(8)
     R = _import_reference()
     gen_unet()
     gen_convert()
+    gen_kitti360()
     shutil.rmtree(R["scratch"], ignore_errors=True)
 
 

@@ -236,3 +236,36 @@ def test_flow_loss_vs_oracle():
         assert np.isfinite(l0) and not torch.equal(before, hip.flow_net.grid_enc.params.detach())
     finally:
         tcnn_ref.set_precision(prev)
+
+
+def test_kitti360_reader_matches_reference(tmp_path):
+    """lidar4d_amd.kitti360.KITTI360Dataset on the reference's on-disk layout, against what the reference's own reader and
+    collate produce for the same files and the same torch seed (oracle/make_golden_next.py::gen_kitti360).  Host logic:
+    runs wherever torch runs."""
+    from lidar4d_amd.kitti360 import KITTI360Dataset
+    from oracle.detparams import write_kitti360_fixture
+    g = np.load(os.path.join(GOLD, "kitti360_reader.npz"))
+    cfg = write_kitti360_fixture(str(tmp_path))
+    for split in ("train", "val"):
+        ds = KITTI360Dataset(device="cpu", split=split, root_path=str(tmp_path), sequence_id=cfg["sequence_id"], preload=True,
+                             scale=cfg["scale"], offset=cfg["offset"], fp16=False, num_rays_lidar=48, fov_lidar=cfg["fov_lidar"])
+        assert len(ds) == int(g[f"{split}_len"]) and ds.num_rays_lidar == int(g[f"{split}_num_rays"])
+        assert np.array_equal(ds.poses_lidar.numpy(), g[f"{split}_poses"]), "normalised sensor poses (frames sorted by file)"
+        assert np.array_equal(ds.images_lidar.numpy(), g[f"{split}_images"]), "[ray-drop mask, intensity, depth * scale]"
+        assert np.array_equal(ds.times.numpy(), g[f"{split}_times"])
+        torch.manual_seed(11)
+        b = ds.collate([1])
+        assert b["H_lidar"] == 8 and b["W_lidar"] == 32 and b["poses_lidar"].shape == (1, 4, 4)
+        # same seed -> same random pixels as the reference's collate (row in [0, H-1), column in [0, W))
+        assert np.array_equal(b["images_lidar"].numpy(), g[f"{split}_batch_images"])
+        assert np.array_equal(b["time"].numpy(), g[f"{split}_time"])
+        np.testing.assert_allclose(b["rays_o_lidar"].numpy(), g[f"{split}_rays_o"], rtol=0, atol=0)
+        np.testing.assert_allclose(b["rays_d_lidar"].numpy(), g[f"{split}_rays_d"], rtol=0, atol=1e-7)
+    half = KITTI360Dataset(device="cpu", split="refine", root_path=str(tmp_path), sequence_id=cfg["sequence_id"], preload=True,
+                           scale=cfg["scale"], offset=cfg["offset"], fp16=True, num_rays_lidar=16, fov_lidar=cfg["fov_lidar"])
+    assert half.images_lidar.dtype == torch.half and np.array_equal(half.images_lidar.float().numpy(), g["half_images"])
+    assert half.num_rays_lidar == -1 and not half.training and half.split == "train"  # 'refine': whole training frames
+    loader = ds.dataloader()
+    assert loader._data is ds and loader.has_gt and len(list(loader)) == len(ds)
+    with pytest.raises(ValueError):
+        KITTI360Dataset(root_path=str(tmp_path), sequence_id="42")
