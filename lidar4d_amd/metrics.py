@@ -51,3 +51,38 @@ class PointsMeter:
 
     def report(self):
         return f"CD f-score = {self.measure()}"
+
+
+class RaydropMeter:
+    """utils/metrics.py:172-226: RMSE, accuracy and F1 of the ray-drop probability image against the 0/1 ground truth,
+    thresholded at ``ratio``.  Torch on whatever device the inputs live on; one host transfer in ``measure()``."""
+
+    def __init__(self, ratio=0.5):
+        self.V = []
+        self.N = 0
+        self.ratio = ratio
+
+    def clear(self):
+        self.V = []
+        self.N = 0
+
+    def update(self, preds, truths):
+        preds = torch.as_tensor(preds).detach().double()
+        truths = torch.as_tensor(truths).detach().to(preds)
+        rmse = ((truths - preds) ** 2).mean().sqrt()
+        hit = (preds > self.ratio).to(preds)
+        acc = (hit == truths).double().mean()
+        tp = ((truths == 1) & (hit == 1)).sum().double()
+        fp = ((truths == 0) & (hit == 1)).sum().double()
+        fn = ((truths == 1) & (hit == 0)).sum().double()
+        precision, recall = tp / (tp + fp), tp / (tp + fn)
+        f1 = 2 * (precision * recall) / (precision + recall)  # nan when nothing is predicted / present, like the reference
+        self.V.append(torch.stack([rmse, acc, f1]))
+        self.N += 1
+
+    def measure(self):
+        assert self.N == len(self.V)
+        return torch.stack(self.V).mean(0).cpu().numpy()
+
+    def report(self):
+        return f"Rdrop_error (RMSE, Acc, F1) = {self.measure()}"

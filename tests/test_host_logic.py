@@ -152,3 +152,26 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_raydrop_meter_formulas():
+    """lidar4d_amd.metrics.RaydropMeter against the reference's numpy formulas (utils/metrics.py:190-214), restated here."""
+    from lidar4d_amd.metrics import RaydropMeter
+    rng = np.random.default_rng(0)
+    m = RaydropMeter()
+    want = []
+    for _ in range(3):
+        preds = rng.random((1, 16, 64)).astype(np.float32)
+        truths = (rng.random((1, 16, 64)) > 0.3).astype(np.float32)
+        m.update(torch.from_numpy(preds), torch.from_numpy(truths))
+        rmse = np.sqrt(((truths - preds) ** 2).mean())
+        mask = np.where(preds > 0.5, 1, 0)
+        acc = (mask == truths).mean()
+        tp, fp = np.sum((truths == 1) & (mask == 1)), np.sum((truths == 0) & (mask == 1))
+        fn = np.sum((truths == 1) & (mask == 0))
+        p, r = tp / (tp + fp), tp / (tp + fn)
+        want.append([rmse, acc, 2 * p * r / (p + r)])
+    np.testing.assert_allclose(m.measure(), np.array(want).mean(0), rtol=1e-6)
+    assert "Rdrop_error" in m.report()
+    m.clear()
+    assert m.N == 0 and m.V == []
