@@ -28,17 +28,34 @@ def pixel_block_order(rows, cols):
 
 def get_lidar_rays(poses, intrinsics, H, W, N=-1, patch_size=1, generator=None, sort_pixels=False):
     """poses [B,4,4] sensor-to-world, intrinsics (fov_up, fov) in degrees -> dict(rays_o, rays_d [B,n,3], inds [B,n]).
-    N > 0 draws N random pixels the way the reference does for patch_size == 1: row in [0, H-1), column in [0, W)
-    (base_dataset.py:50-53 -- the last row is never sampled).  sort_pixels: return the drawn pixels in
-    pixel_block_order (same set of rays, cache-friendly order)."""
+    N > 0 draws pixels the way the reference does (base_dataset.py:36-70): ``N // (px * py)`` patches of px x py pixels
+    (``patch_size`` an int or [px, py]) with the top row in [0, H - px) and the left column in [0, W), columns wrapping
+    around the panorama; px <= 0 draws N pixels anywhere, possibly repeated.  With the default patch_size = 1 that is
+    a row in [0, H-1) -- the last row is never sampled -- and a column in [0, W).  Same torch RNG consumption as the
+    reference, so equal seeds give equal pixels.  sort_pixels: serve the drawn pixels in pixel_block_order."""
     device = poses.device
     B = poses.shape[0]
     if N > 0:
         N = min(N, H * W)
-        if patch_size != 1:
-            raise NotImplementedError("get_lidar_rays: patch sampling other than patch_size=1 is not implemented")
-        rows = torch.randint(0, H - 1, size=[N], device=device, generator=generator)
-        cols = torch.randint(0, W, size=[N], device=device, generator=generator)
+        if isinstance(patch_size, int):
+            px, py = patch_size, patch_size
+        elif len(patch_size) == 1:
+            px, py = patch_size[0], patch_size[0]
+        else:
+            px, py = patch_size
+        if px > 0:
+            n_patch = N // (px * py)
+            top = torch.randint(0, H - px, size=[n_patch], device=device, generator=generator)
+            left = torch.randint(0, W, size=[n_patch], device=device, generator=generator)
+            dr = torch.arange(px, device=device).repeat_interleave(py)  # row offsets, patch-row major
+            dc = torch.arange(py, device=device).repeat(px)             # column offsets
+            rows = (top[:, None] + dr[None, :]).reshape(-1)
+            cols = ((left[:, None] + dc[None, :]) % W).reshape(-1)
+        else:
+            flat = torch.randint(0, H * W, size=[N], device=device, generator=generator)
+            rows, cols = torch.div(flat, W, rounding_mode="floor"), flat % W
+        if rows.numel() != N:
+            raise ValueError(f"get_lidar_rays: N = {N} is not a multiple of the patch size {px} x {py}")
         if sort_pixels:
             order = pixel_block_order(rows, cols)
             rows, cols = rows[order], cols[order]

@@ -82,12 +82,29 @@ def gen_kitti360():
     shutil.rmtree(root, ignore_errors=True)
 
 
+def gen_random_rays():
+    """get_lidar_rays with N > 0: the reference's random pixel draws (single pixels, patches, anywhere) for fixed seeds."""
+    import data.base_dataset as ref_data
+
+    c, s = np.cos(0.4), np.sin(0.4)
+    pose = torch.tensor([[[c, -s, 0, 0.3], [s, c, 0, -0.1], [0, 0, 1, 0.05], [0, 0, 0, 1]]], dtype=torch.float32)
+    out = {"pose": pose}
+    for tag, (H, W, N, patch) in {"p1": (16, 64, 96, 1), "p2": (16, 64, 96, 2), "p24": (16, 64, 96, [2, 4]), "any": (16, 64, 50, 0),
+                                  "wrap": (8, 8, 48, [2, 4])}.items():
+        torch.manual_seed(21)
+        r = ref_data.get_lidar_rays(pose, [2.0, 26.9], H, W, N, patch)
+        out[f"inds_{tag}"], out[f"rays_d_{tag}"] = r["inds"], r["rays_d"]
+        out[f"cfg_{tag}"] = np.array([H, W, N] + (patch if isinstance(patch, list) else [patch, patch]))
+    save("rays_random", **out)
+
+
 def main():
     torch.set_num_threads(8)
     R = _import_reference()
     gen_unet()
     gen_convert()
     gen_kitti360()
+    gen_random_rays()
     shutil.rmtree(R["scratch"], ignore_errors=True)
 
 

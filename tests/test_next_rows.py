@@ -269,3 +269,19 @@ def test_kitti360_reader_matches_reference(tmp_path):
     assert loader._data is ds and loader.has_gt and len(list(loader)) == len(ds)
     with pytest.raises(ValueError):
         KITTI360Dataset(root_path=str(tmp_path), sequence_id="42")
+
+
+def test_random_ray_draws_match_reference():
+    """get_lidar_rays(N > 0): same seed -> the reference's pixels, for single pixels, square and rectangular patches,
+    unconstrained draws and patches that wrap around the panorama (base_dataset.py:36-70)."""
+    from lidar4d_amd.data import get_lidar_rays
+    g = np.load(os.path.join(GOLD, "rays_random.npz"))
+    pose = torch.from_numpy(g["pose"])
+    for tag in ("p1", "p2", "p24", "any", "wrap"):
+        H, W, N, px, py = (int(v) for v in g[f"cfg_{tag}"])
+        torch.manual_seed(21)
+        r = get_lidar_rays(pose, [2.0, 26.9], H, W, N, px if px == py else [px, py])
+        assert np.array_equal(r["inds"].numpy(), g[f"inds_{tag}"]), tag
+        np.testing.assert_allclose(r["rays_d"].numpy(), g[f"rays_d_{tag}"], rtol=0, atol=1e-7)
+    with pytest.raises(ValueError):
+        get_lidar_rays(pose, [2.0, 26.9], 16, 64, 50, 4)  # 50 rays cannot be cut into 4 x 4 patches
