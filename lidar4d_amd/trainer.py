@@ -4,7 +4,7 @@ schedule, and ray-sharded data parallelism with one RCCL all-reduce of the flat 
 Restates only what `training rays/s` needs from the reference's Trainer (model/runner.py:166-213,474-551;
 optimizer main_lidar4d.py:298-305) plus the inference step of the evaluation / simulation loops
 (runner.py:438-470: staged render of a whole frame, U-Net ray-drop refinement, masking) and the optional ray-chamfer and
-scene-flow loss terms (runner.py:215-253).  The line-of-sight (urf) loss, EMA, checkpoints and logging are out of scope.
+scene-flow and line-of-sight loss terms (runner.py:215-276).  The patch gradient loss, EMA, checkpoints and logging are out of scope.
 """
 import os
 
@@ -41,6 +41,27 @@ def ray_chamfer_loss(outputs, data, scale):
     gt_lidar = rays_d * gt_depth.unsqueeze(-1) / scale
     dist1, dist2, _, _ = chamfer_3DDist()(pred_lidar, gt_lidar)
     return (dist1 + dist2).mean() * 0.5
+
+
+def urf_loss(outputs, gt_depth, global_step, iters):
+    """runner.py:255-276 (``--urf_loss``, the line-of-sight loss of Urban Radiance Fields): with a tolerance eps that
+    shrinks from 0.02 to 0.002 over training, weights outside [depth - eps, depth + eps] are pushed to zero and the
+    weights inside towards a (peak-normalised) Gaussian of sigma = eps / 3 around the measured depth; both terms are
+    sums over all samples divided by the number of rays with a return, and enter the loss with weight 0.1.
+    outputs: ``weights`` [n, T], ``z_vals`` [n, T] of the render call; gt_depth: [1, n] (already masked by ray-drop)."""
+    import math
+    eps = 0.02 * 0.1 ** min(global_step / iters, 1)
+    weights, z = outputs["weights"], outputs["z_vals"]
+    d = gt_depth.reshape(z.shape[0], 1)
+    n_hit = (d > 0.0).sum()
+    near = (z > d - eps) & (z < d + eps)
+    empty = (z < d - eps) | (z > d + eps)
+    loss_empty = ((empty * weights) ** 2).sum() / n_hit
+    sigma = eps / 3.0
+    bell = torch.exp(-((near * (z - d)) ** 2) / (2 * sigma ** 2)) / (sigma * math.sqrt(2 * math.pi))
+    bell = bell / bell.max() * near
+    loss_near = ((near * weights - bell) ** 2).sum() / n_hit
+    return 0.1 * loss_empty + 0.1 * loss_near
 
 
 def process_pointcloud(dataset, ground_split=None):
@@ -162,13 +183,13 @@ class Trainer:
     indices -- parameters are replicated and the flat gradient buffer is SUM-all-reduced once per step (the primary
     loss is a sum over rays, so the result equals one big batch)."""
 
-    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=False, flow=False):
+    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=False, flow=False, urf=False):
         """chamfer=True adds the reference's ray chamfer term (runner.py:215-220); it is a mean over the rank's own
         rays, so under data parallelism it is scaled by 1/world before the SUM all-reduce.
         flow=True adds the scene-flow consistency term (runner.py:222-253, ``opt.flow_loss``): a per-frame sum, so under
         data parallelism it enters each rank's loss as it is (every rank works on its own frame)."""
         self.model, self.dataset, self.num_steps, self.chamfer = model, dataset, num_steps, chamfer
-        self.flow = flow
+        self.flow, self.urf, self.iters = flow, urf, iters
         if flow:
             self.pc_list, self.pc_ground_list = process_pointcloud(dataset)
         self.opt = FlatAdam(model, lr=lr, iters=iters)
@@ -191,6 +212,9 @@ class Trainer:
             loss = loss + ray_chamfer_loss(out, data, self.dataset.scale) / self.world
         if self.flow:
             loss = loss + flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames)
+        if self.urf:  # a per-ray mean like the chamfer term
+            gt = data["images_lidar"]
+            loss = loss + urf_loss(out, gt[:, :, 2] * gt[:, :, 0], self.opt.step_count, self.iters) / self.world
         loss.backward()
         if self.flow:
             self.model._store.prepare_grads()  # fold gradients autograd produced outside the fused node into the arena

@@ -175,3 +175,32 @@ def test_raydrop_meter_formulas():
     assert "Rdrop_error" in m.report()
     m.clear()
     assert m.N == 0 and m.V == []
+
+
+def test_urf_loss_formula():
+    """trainer.urf_loss against a literal transcription of runner.py:255-276 (pure torch: runs anywhere)."""
+    from lidar4d_amd.trainer import urf_loss
+    g = torch.Generator().manual_seed(5)
+    n, T = 12, 40
+    z = torch.sort(torch.rand(n, T, generator=g) * 0.8 + 0.01, dim=1).values
+    w = torch.rand(n, T, generator=g, dtype=torch.float32).requires_grad_(True)
+    depth = torch.rand(1, n, generator=g) * 0.8
+    depth[0, :3] = 0.0  # dropped rays
+    for step, iters in ((0, 100), (50, 100), (500, 100)):
+        eps = 0.02 * 0.1 ** min(step / iters, 1)
+        d = depth.reshape(n, 1)
+        depth_mask = d > 0.0
+        mask_empty = (z < (d - eps)) | (z > (d + eps))
+        loss_empty = ((mask_empty * w) ** 2).sum() / depth_mask.sum()
+        mask_near = (z > (d - eps)) & (z < (d + eps))
+        distance = mask_near * (z - d)
+        sigma = eps / 3.0
+        distr = 1.0 / (sigma * np.sqrt(2 * np.pi)) * torch.exp(-(distance ** 2 / (2 * sigma ** 2)))
+        distr = distr / distr.max()
+        distr = distr * mask_near
+        loss_near = ((mask_near * w - distr) ** 2).sum() / depth_mask.sum()
+        want = 0.1 * loss_empty + 0.1 * loss_near
+        got = urf_loss({"weights": w, "z_vals": z}, depth, step, iters)
+        assert torch.allclose(got, want, rtol=1e-6), (float(got), float(want))
+    got.backward()
+    assert w.grad is not None and torch.isfinite(w.grad).all()
