@@ -100,6 +100,7 @@ class SyntheticKitti360:
     def __init__(self, device, H=64, W=1024, num_frames=51, num_rays=4096, scale=KITTI360_SCALE, fov=KITTI360_FOV, seed=0,
                  sort_pixels=False, frame_seed=None):
         self.device, self.H, self.W, self.num_frames, self.num_rays = device, H, W, num_frames, num_rays
+        self.patch_size_lidar = 1  # settable like the reference's dataset attribute (runner.py:700-705): int or [px, py]
         self.sort_pixels = sort_pixels  # pixel_block_order; measured SLOWER on MI355X (66.3 vs 63.5 ms/step: neighbouring rays
         # pile onto the same LDS histogram bins / cache lines), kept as an option for experiments
         self.scale, self.fov = scale, fov
@@ -149,7 +150,8 @@ class SyntheticKitti360:
 
     def batch_for(self, frame):
         pose = self.poses[frame:frame + 1]
-        rays = get_lidar_rays(pose, self.fov, self.H, self.W, self.num_rays, generator=self.gen, sort_pixels=self.sort_pixels)
+        rays = get_lidar_rays(pose, self.fov, self.H, self.W, self.num_rays, self.patch_size_lidar, generator=self.gen,
+                              sort_pixels=self.sort_pixels and self.patch_size_lidar == 1)
         inds = rays["inds"]
         images = torch.gather(self.images[frame].view(1, -1, 3), 1, inds[..., None].expand(-1, -1, 3))
         t = torch.tensor([[frame / (self.num_frames - 1)]], dtype=torch.float32, device=self.device)

@@ -64,6 +64,62 @@ def urf_loss(outputs, gt_depth, global_step, iters):
     return 0.1 * loss_empty + 0.1 * loss_near
 
 
+def _patch_grads(img, sobel):
+    """img [n_patch, 1, px, py] -> (d/dx, d/dy): Sobel responses (same size) or forward differences (one shorter)."""
+    if sobel:
+        kx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=torch.float32, device=img.device).view(1, 1, 3, 3)
+        ky = torch.tensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], dtype=torch.float32, device=img.device).view(1, 1, 3, 3)
+        return torch.nn.functional.conv2d(img, kx, padding=1), torch.nn.functional.conv2d(img, ky, padding=1)
+    return img[:, :, :, :-1] - img[:, :, :, 1:], img[:, :, :-1, :] - img[:, :, 1:, :]
+
+
+def depth_grad_loss(pred_depth, gt_depth, gt_raydrop, patch_size, scale, alpha_grad=0.1, kind="l1", sobel_grad=False,
+                    grad_loss=True, grad_norm_smooth=False, spatial_smooth=False, tv_loss=False, alpha_grad_norm=0.1,
+                    alpha_spatial=0.1, alpha_tv=0.1):
+    """runner.py:277-367: structure terms on depth PATCHES (rays drawn as px x py pixel blocks, get_lidar_rays).  The
+    main term compares the horizontal depth gradient of prediction and ground truth (in metres) where the ground truth
+    is smooth (|gradient| < 0.01) and has a return -- the reference only uses the x direction there, which is kept --
+    summed and weighted by alpha_grad; the optional smoothness terms are means over the patch gradients.
+    pred_depth / gt_depth / gt_raydrop: [1, n] in ray order (patch-major), depths already masked by the ray-drop."""
+    px, py = (patch_size, patch_size) if isinstance(patch_size, int) else \
+        ((patch_size[0], patch_size[0]) if len(patch_size) == 1 else tuple(patch_size))
+    loss = pred_depth.new_zeros(())
+    if px <= 1:
+        return loss
+    as_patches = lambda v: v.reshape(-1, px, py, 1).permute(0, 3, 1, 2).contiguous()
+    pred = as_patches(pred_depth) / scale
+    if sobel_grad:
+        pgx, pgy = _patch_grads(pred, True)
+    else:  # the reference takes magnitudes of the forward differences on the prediction side
+        pgx, pgy = (g.abs() for g in _patch_grads(pred, False))
+    dx, dy = pgx.abs(), pgy.abs()
+    if grad_norm_smooth:
+        loss = loss + alpha_grad_norm * (torch.exp(-dx).mean() + torch.exp(-dy).mean())
+    if spatial_smooth:
+        loss = loss + alpha_spatial * ((dx ** 2).mean() + (dy ** 2).mean())
+    if tv_loss:
+        loss = loss + alpha_tv * (dx.mean() + dy.mean())
+    if grad_loss:
+        gt = as_patches(gt_depth) / scale
+        hit = as_patches(gt_raydrop)
+        ggx, _ = _patch_grads(gt, sobel_grad)
+        smooth_x = (ggx.abs() < 0.01).to(gt)
+        mask = (hit if sobel_grad else hit[:, :, :, :-1]) * smooth_x
+        a, b = pgx * mask, ggx * mask
+        if kind == "cos":
+            term = 1 - torch.nn.functional.cosine_similarity(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1))
+        elif kind == "l1":
+            term = (a - b).abs()
+        elif kind == "mse":
+            term = (a - b) ** 2
+        elif kind == "huber":
+            term = torch.nn.functional.huber_loss(a, b, reduction="none", delta=0.2 * scale)
+        else:
+            raise ValueError(f"depth_grad_loss: unknown kind {kind!r}")
+        loss = loss + alpha_grad * term.sum()
+    return loss
+
+
 def process_pointcloud(dataset, ground_split=None):
     """runner.py:923-951 on the device: per frame, ground-truth range image -> points (lidar4d_amd.convert) -> split into
     non-ground / ground -> scene units and world frame.  Returns (pc_list, pc_ground_list), dicts keyed by str(frame).
@@ -212,6 +268,11 @@ class Trainer:
             loss = loss + ray_chamfer_loss(out, data, self.dataset.scale) / self.world
         if self.flow:
             loss = loss + flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames)
+        patch = getattr(self.dataset, "patch_size_lidar", 1)
+        if patch != 1:  # rays were drawn as pixel patches (runner.py:277-367); a sum over this rank's patches
+            gt = data["images_lidar"]
+            loss = loss + depth_grad_loss(out["depth_lidar"] * gt[:, :, 0], gt[:, :, 2] * gt[:, :, 0], gt[:, :, 0], patch,
+                                          self.dataset.scale)
         if self.urf:  # a per-ray mean like the chamfer term
             gt = data["images_lidar"]
             loss = loss + urf_loss(out, gt[:, :, 2] * gt[:, :, 0], self.opt.step_count, self.iters) / self.world

@@ -204,3 +204,43 @@ def test_urf_loss_formula():
         assert torch.allclose(got, want, rtol=1e-6), (float(got), float(want))
     got.backward()
     assert w.grad is not None and torch.isfinite(w.grad).all()
+
+
+@pytest.mark.parametrize("sobel,kind", [(False, "l1"), (True, "l1"), (False, "mse"), (False, "cos")])
+def test_depth_grad_loss_formula(sobel, kind):
+    """trainer.depth_grad_loss against a literal transcription of runner.py:277-367 (pure torch)."""
+    import torch.nn.functional as F
+    from lidar4d_amd.trainer import depth_grad_loss
+    g = torch.Generator().manual_seed(9)
+    px, py, n_patch, scale = 2, 8, 6, 0.0105
+    n = n_patch * px * py
+    gt_raydrop = (torch.rand(1, n, generator=g) > 0.2).float()
+    gt_depth = (0.3 + 0.002 * torch.arange(n).float().view(1, n) % 0.05 + 0.01 * torch.rand(1, n, generator=g)) * scale * 30 * gt_raydrop
+    pred_depth = ((gt_depth + 0.001 * torch.randn(1, n, generator=g)) * gt_raydrop).requires_grad_(True)
+    # --- transcription
+    pd = pred_depth.view(-1, px, py, 1).permute(0, 3, 1, 2).contiguous() / scale
+    kx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=torch.float32).unsqueeze(0).unsqueeze(0)
+    ky = torch.tensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], dtype=torch.float32).unsqueeze(0).unsqueeze(0)
+    if sobel:
+        pgx, pgy = F.conv2d(pd, kx, padding=1), F.conv2d(pd, ky, padding=1)
+    else:
+        pgy = torch.abs(pd[:, :, :-1, :] - pd[:, :, 1:, :])
+        pgx = torch.abs(pd[:, :, :, :-1] - pd[:, :, :, 1:])
+    dy, dx = torch.abs(pgy), torch.abs(pgx)
+    want = 0.1 * (torch.mean(dx) + torch.mean(dy))  # tv term switched on below
+    gd = gt_depth.view(-1, px, py, 1).permute(0, 3, 1, 2).contiguous() / scale
+    gr = gt_raydrop.view(-1, px, py, 1).permute(0, 3, 1, 2).contiguous()
+    ggx = F.conv2d(gd, kx, padding=1) if sobel else gd[:, :, :, :-1] - gd[:, :, :, 1:]
+    mask_x = torch.where(torch.abs(ggx) < 0.01, 1, 0)
+    mask_dx = gr * mask_x if sobel else gr[:, :, :, :-1] * mask_x
+    crit = {"l1": torch.nn.L1Loss(reduction="none"), "mse": torch.nn.MSELoss(reduction="none"), "cos": torch.nn.CosineSimilarity()}[kind]
+    if kind == "cos":
+        gl = 1 - crit((pgx * mask_dx).reshape(n_patch, -1), (ggx * mask_dx).reshape(n_patch, -1))
+    else:
+        gl = crit(pgx * mask_dx, ggx * mask_dx)
+    want = want + 0.1 * gl.sum()
+    got = depth_grad_loss(pred_depth, gt_depth, gt_raydrop, [px, py], scale, kind=kind, sobel_grad=sobel, tv_loss=True)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-7), (float(got), float(want))
+    got.backward()
+    assert torch.isfinite(pred_depth.grad).all()
+    assert float(depth_grad_loss(pred_depth, gt_depth, gt_raydrop, 1, scale)) == 0.0

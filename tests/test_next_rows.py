@@ -308,3 +308,15 @@ def test_training_step_with_all_loss_terms():
         losses[name] = [float(tr.train_step(data.batch_for(2))) for _ in range(2)]
         assert all(np.isfinite(losses[name])) and not torch.equal(before, m._store.flat)
     assert losses["urf"][0] > losses["plain"][0] and losses["all"][0] > losses["urf"][0]  # the terms are non-negative
+    # rays drawn as 2 x 8 pixel patches switch the depth-gradient term on (runner.py:277-367, 700-705)
+    m = fill_model(LiDAR4D(**cfg), seed=3, flow_out_amp=0.002).cuda()
+    tr = Trainer(m, data, num_steps=64, iters=10)
+    data.patch_size_lidar = [2, 8]
+    try:
+        b = data.batch_for(2)
+        inds = b["rays_d_lidar"].shape[1]
+        assert inds == 128
+        l_patch = float(tr.train_step(b))
+    finally:
+        data.patch_size_lidar = 1
+    assert np.isfinite(l_patch)
