@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--flow", action="store_true", help="add the reference's scene-flow consistency loss (runner.py:222-253, opt.flow_loss)")
     ap.add_argument("--sort-rays", action="store_true", help="serve the random pixels of a batch in 8x8-pixel-block order (locality experiment; measured slower)")
     ap.add_argument("--urf", action="store_true", help="add the line-of-sight loss (runner.py:255-276, opt.urf_loss)")
+    ap.add_argument("--no-ema", action="store_true", help="skip the parameter EMA update the reference does after every step (--ema_decay 0.95 by default there)")
     ap.add_argument("--profile-steps", type=int, default=2)
     args = ap.parse_args()
 
@@ -148,7 +149,7 @@ def main():
     inference = args.workload in INFERENCE
     data = SyntheticKitti360(dev, W=2048 if inference else 1024, num_rays=n_rays, seed=1000 + rank, sort_pixels=args.sort_rays,
                              frame_seed=1000)  # every rank: its own rays, the same frame sequence (equal work per step)
-    trainer = Trainer(model, data, chamfer=args.chamfer, flow=args.flow, urf=args.urf)
+    trainer = Trainer(model, data, chamfer=args.chamfer, flow=args.flow, urf=args.urf, ema_decay=None if args.no_ema else 0.95)
     if inference:
         from lidar4d_amd.data import KITTI360_FOV
         from lidar4d_amd.metrics import PointsMeter
@@ -246,7 +247,7 @@ def main():
                        "global_rays_per_step": n_rays * world,
                        "parallelism": f"frame-sharded x{world}, no collective" if inference else f"ray-sharded dp{world}, 1 RCCL all-reduce/step",
                        "step": "no_grad render(staged=True, max_ray_batch=4096) + U-Net + pano_to_lidar + chamfer/F-score" if inference else
-                               "forward + backward + Adam, losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else "") + (" + scene-flow consistency" if args.flow else "") + (" + line-of-sight" if args.urf else "") + ("" if args.chamfer or args.flow or args.urf else " (no chamfer/flow loss)")},
+                               "forward + backward + Adam" + ("" if args.no_ema else " + parameter EMA") + ", losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else "") + (" + scene-flow consistency" if args.flow else "") + (" + line-of-sight" if args.urf else "") + ("" if args.chamfer or args.flow or args.urf else " (no chamfer/flow loss)")},
             "roofline": roofline,
         }
         if inference:

@@ -188,6 +188,46 @@ class FlatAdam:
     def zero_grad(self):
         self.store.zero_grad() if self.store.flat_grad is not None else self.store.prepare_grads()
 
+    # -- checkpoint interchange with torch.optim.Adam(model.get_params(lr), betas, eps) (runner.py:966,1056-1059) ----------
+    def _torch_layout(self):
+        """[(group index, parameter)] in the order torch.optim.Adam numbers them for LiDAR4D.get_params."""
+        return [(gi, p) for gi, g in enumerate(self.model.get_params(self.lr0)) for p in g["params"]]
+
+    def state_dict(self):
+        """A state dict a ``torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)`` can load: per-parameter
+        ``step`` / ``exp_avg`` / ``exp_avg_sq`` cut out of the flat moment buffers."""
+        layout = self._torch_layout()
+        groups, state, lr_now = [], {}, self.lr()
+        for gi, g in enumerate(self.model.get_params(self.lr0)):
+            ids = [k for k, (gj, _) in enumerate(layout) if gj == gi]
+            groups.append({"lr": lr_now * (g["lr"] / self.lr0), "initial_lr": g["lr"], "betas": tuple(self.betas), "eps": self.eps,
+                           "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                           "differentiable": False, "fused": None, "params": ids})
+        if self.step_count > 0:
+            for k, (_, p) in enumerate(layout):
+                if p.numel() == 0 or id(p) not in self.store.by_param:
+                    continue
+                off, n = self.store.by_param[id(p)]
+                state[k] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        """Accepts the optimiser state of a checkpoint written by the reference's Trainer (or by ``state_dict`` above)."""
+        layout = self._torch_layout()
+        steps = set()
+        for k, st in sd["state"].items():
+            _, p = layout[int(k)]
+            if p.numel() == 0 or id(p) not in self.store.by_param:
+                continue
+            off, n = self.store.by_param[id(p)]
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].to(self.exp_avg).reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].to(self.exp_avg_sq).reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdam: parameters with different step counts {sorted(steps)} cannot share one flat state")
+        self.step_count = steps.pop() if steps else 0
+
     def step(self, grad_scale=1.0):
         st = self.store
         lr = self.lr()
@@ -199,6 +239,63 @@ class FlatAdam:
         bump_epoch()          # parameters changed behind torch's version counters ...
         st.mark16_current()   # ... and the fp16 copies were refreshed by the same kernel
         self.model.planes_encoder._cl_key = None  # channel-last plane copy must be rebuilt
+
+
+class FlatEMA:
+    """Exponential moving average of the parameters over the flat arena: what the reference keeps with
+    ``torch_ema.ExponentialMovingAverage(model.parameters(), decay)`` (runner.py:97-98; updated after every optimiser
+    step, :534-535; swapped in for evaluation with store / copy_to / restore, :565-567,679-680; ``--ema_decay`` 0.95 by
+    default).  One fused elementwise launch over one buffer instead of a python loop over ~70 tensors.
+    Update rule (torch_ema): decay_t = min(decay, (1 + t) / (10 + t)) for the t-th update; shadow -= (1 - decay_t) *
+    (shadow - param).  The U-Net is not part of the arena and is left alone (the reference trains it after the field)."""
+
+    def __init__(self, model, decay=0.95, use_num_updates=True):
+        self.model, self._st = model, model._store
+        self.decay = decay
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow = self._st.flat.detach().clone()
+        self.backup = None
+
+    def update(self):
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        self.shadow.lerp_(self._st.flat.detach(), 1.0 - decay)
+
+    def _write(self, src):
+        with torch.no_grad():
+            self._st.flat.copy_(src)
+        bump_epoch()                                  # fp16 compute copies must be refreshed
+        self.model.planes_encoder._cl_key = None      # and the channel-last plane copy
+
+    def store(self):
+        self.backup = self._st.flat.detach().clone()
+
+    def copy_to(self):
+        self._write(self.shadow)
+
+    def restore(self):
+        if self.backup is None:
+            raise RuntimeError("FlatEMA.restore() without a preceding store()")
+        self._write(self.backup)
+        self.backup = None
+
+    def _views(self, flat):
+        return [flat[off:off + n].view(p.shape) for _, p, off, n, _ in self._st.entries]
+
+    def state_dict(self):
+        """torch_ema's keys; shadow_params in the order of the arena (= LiDAR4D.get_params order)."""
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": [v.clone() for v in self._views(self.shadow)],
+                "collected_params": None}
+
+    def load_state_dict(self, sd):
+        self.decay, self.num_updates = sd["decay"], sd["num_updates"]
+        views = self._views(self.shadow)
+        if len(sd["shadow_params"]) != len(views):
+            raise ValueError(f"FlatEMA: {len(sd['shadow_params'])} shadow tensors for {len(views)} parameters")
+        for v, t in zip(views, sd["shadow_params"]):
+            v.copy_(t.to(v).reshape(v.shape))
 
 
 class GradReducer:
@@ -239,13 +336,15 @@ class Trainer:
     indices -- parameters are replicated and the flat gradient buffer is SUM-all-reduced once per step (the primary
     loss is a sum over rays, so the result equals one big batch)."""
 
-    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=False, flow=False, urf=False):
+    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=False, flow=False, urf=False,
+                 ema_decay=None):
         """chamfer=True adds the reference's ray chamfer term (runner.py:215-220); it is a mean over the rank's own
         rays, so under data parallelism it is scaled by 1/world before the SUM all-reduce.
         flow=True adds the scene-flow consistency term (runner.py:222-253, ``opt.flow_loss``): a per-frame sum, so under
         data parallelism it enters each rank's loss as it is (every rank works on its own frame)."""
         self.model, self.dataset, self.num_steps, self.chamfer = model, dataset, num_steps, chamfer
         self.flow, self.urf, self.iters = flow, urf, iters
+        self.ema = FlatEMA(model, ema_decay) if ema_decay is not None else None  # runner.py:97-98
         if flow:
             self.pc_list, self.pc_ground_list = process_pointcloud(dataset)
         self.opt = FlatAdam(model, lr=lr, iters=iters)
@@ -282,6 +381,8 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()
+        if self.ema is not None:
+            self.ema.update()  # runner.py:534-535
         return loss
 
     @torch.no_grad()

@@ -244,3 +244,70 @@ def test_depth_grad_loss_formula(sobel, kind):
     got.backward()
     assert torch.isfinite(pred_depth.grad).all()
     assert float(depth_grad_loss(pred_depth, gt_depth, gt_raydrop, 1, scale)) == 0.0
+
+
+def test_flat_ema_matches_torch_ema_rule():
+    """trainer.FlatEMA against torch_ema's update rule applied tensor by tensor (runner.py:97-98,534-535,565-567)."""
+    from lidar4d_amd import LiDAR4D
+    from lidar4d_amd.trainer import FlatEMA
+    from oracle.make_golden import SMALL_MODEL
+    m = LiDAR4D(**SMALL_MODEL)
+    params = [p for _, p, _, n, _ in m._store.entries]
+    shadow = [p.detach().clone() for p in params]
+    ema = FlatEMA(m, decay=0.95)
+    g = torch.Generator().manual_seed(1)
+    for t in range(1, 5):
+        with torch.no_grad():
+            m._store.flat.add_(torch.randn(m._store.numel, generator=g) * 0.01)
+        ema.update()
+        decay = min(0.95, (1 + t) / (10 + t))
+        for s_, p in zip(shadow, params):
+            s_.sub_((1 - decay) * (s_ - p.detach()))
+    for s_, v in zip(shadow, ema._views(ema.shadow)):
+        assert torch.allclose(s_, v, rtol=1e-5, atol=1e-7)
+    live = m._store.flat.clone()
+    ema.store()
+    ema.copy_to()
+    assert torch.equal(m._store.flat, ema.shadow) and torch.equal(params[0].detach().reshape(-1), ema.shadow[: params[0].numel()])
+    ema.restore()
+    assert torch.equal(m._store.flat, live)
+    sd = ema.state_dict()
+    assert set(sd) == {"decay", "num_updates", "shadow_params", "collected_params"} and sd["num_updates"] == 4
+    other = FlatEMA(m, decay=0.5)
+    other.load_state_dict(sd)
+    assert other.decay == 0.95  # (alignment gaps of the arena are not parameters: compare the views)
+    assert all(torch.equal(a, b) for a, b in zip(other._views(other.shadow), ema._views(ema.shadow)))
+
+
+def test_flat_adam_state_dict_interchange_with_torch_adam():
+    """FlatAdam.state_dict()/load_state_dict() speak torch.optim.Adam's format for LiDAR4D.get_params (what the reference's
+    checkpoints hold under "optimizer", runner.py:966,1056-1059)."""
+    from lidar4d_amd import LiDAR4D
+    from lidar4d_amd.trainer import FlatAdam
+    from oracle.make_golden import SMALL_MODEL
+    m = LiDAR4D(**SMALL_MODEL)
+    ref_opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    g = torch.Generator().manual_seed(2)
+    for _ in range(3):  # real torch.optim.Adam steps on CPU build a genuine state
+        for p in m.parameters():
+            if p.numel() and not any(p is q for q in m.unet.parameters()):
+                p.grad = torch.randn(p.shape, generator=g) * 1e-3
+        ref_opt.step()
+    sd = ref_opt.state_dict()
+    fa = FlatAdam(m, lr=1e-2)
+    fa.load_state_dict(sd)
+    assert fa.step_count == 3
+    for k, st in sd["state"].items():
+        p = [q for grp in ref_opt.param_groups for q in grp["params"]][k]
+        off, n = m._store.by_param[id(p)]
+        assert torch.equal(fa.exp_avg[off:off + n], st["exp_avg"].reshape(-1))
+        assert torch.equal(fa.exp_avg_sq[off:off + n], st["exp_avg_sq"].reshape(-1))
+    # and back: a fresh torch optimiser accepts FlatAdam's state and holds the same moments
+    out = fa.state_dict()
+    assert [len(g_["params"]) for g_ in out["param_groups"]] == [len(g_["params"]) for g_ in sd["param_groups"]]
+    fresh = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    fresh.load_state_dict(out)
+    for k, st in sd["state"].items():
+        p = [q for grp in fresh.param_groups for q in grp["params"]][k]
+        assert torch.equal(fresh.state[p]["exp_avg"], st["exp_avg"]) and float(fresh.state[p]["step"]) == 3.0
+    assert abs(fresh.param_groups[3]["lr"] - 0.1 * fa.lr()) < 1e-12 and abs(fresh.param_groups[0]["lr"] - fa.lr()) < 1e-12
