@@ -285,17 +285,27 @@ class FlatEMA:
         return [flat[off:off + n].view(p.shape) for _, p, off, n, _ in self._st.entries]
 
     def state_dict(self):
-        """torch_ema's keys; shadow_params in the order of the arena (= LiDAR4D.get_params order)."""
-        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": [v.clone() for v in self._views(self.shadow)],
-                "collected_params": None}
+        """torch_ema's keys.  ``shadow_params`` follows ``model.parameters()`` like torch_ema's list does (the registration
+        order equals the reference's: tests/golden/param_order.npz); parameters outside the arena (the zero-size
+        Frequency-encoding tensor, the U-Net) appear with their current values."""
+        shadows = []
+        for p in self.model.parameters():
+            if id(p) in self._st.by_param and p.numel():
+                off, n = self._st.by_param[id(p)]
+                shadows.append(self.shadow[off:off + n].view(p.shape).clone())
+            else:
+                shadows.append(p.detach().clone())
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": shadows, "collected_params": None}
 
     def load_state_dict(self, sd):
+        params = list(self.model.parameters())
+        if len(sd["shadow_params"]) != len(params):
+            raise ValueError(f"FlatEMA: {len(sd['shadow_params'])} shadow tensors for {len(params)} model parameters")
         self.decay, self.num_updates = sd["decay"], sd["num_updates"]
-        views = self._views(self.shadow)
-        if len(sd["shadow_params"]) != len(views):
-            raise ValueError(f"FlatEMA: {len(sd['shadow_params'])} shadow tensors for {len(views)} parameters")
-        for v, t in zip(views, sd["shadow_params"]):
-            v.copy_(t.to(v).reshape(v.shape))
+        for p, t in zip(params, sd["shadow_params"]):
+            if id(p) in self._st.by_param and p.numel():
+                off, n = self._st.by_param[id(p)]
+                self.shadow[off:off + n].copy_(t.to(self.shadow).reshape(-1))
 
 
 class GradReducer:

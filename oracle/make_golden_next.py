@@ -98,6 +98,16 @@ def gen_random_rays():
     save("rays_random", **out)
 
 
+def gen_param_order():
+    """Registration order of the reference model's parameters and state-dict keys: positional formats (torch.optim state,
+    torch_ema shadow lists) in its checkpoints rely on it."""
+    import model.lidar4d as ref_lidar4d
+    from oracle.make_golden import SMALL_MODEL
+
+    ref = ref_lidar4d.LiDAR4D(**SMALL_MODEL)
+    save("param_order", names=np.array([n for n, _ in ref.named_parameters()]), state_keys=np.array(list(ref.state_dict().keys())))
+
+
 def main():
     torch.set_num_threads(8)
     R = _import_reference()
@@ -105,6 +115,7 @@ def main():
     gen_convert()
     gen_kitti360()
     gen_random_rays()
+    gen_param_order()
     shutil.rmtree(R["scratch"], ignore_errors=True)
 
 
