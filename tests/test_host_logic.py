@@ -367,3 +367,33 @@ def test_checkpoint_roundtrip_and_reference_style_file(tmp_path):
     opt4 = FlatAdam(m3, lr=1e-2)
     load_checkpoint(path, m3, opt4, model_only=True)
     assert opt4.step_count == 0
+
+
+def test_ctypes_signatures_match_header_prototypes():
+    """Every prototype of include/lidar4d_hip.h against lidar4d_amd._lib.SIGNATURES: same number of arguments and the same
+    kind (pointer / int32 / int64 / float / double) in every position -- a drifted binding would pass garbage silently."""
+    from lidar4d_amd import _lib
+    header = open(os.path.join(ROOT, "include", "lidar4d_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = dict(re.findall(r"\b(?:int|int64_t)\s+(l4d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S))
+
+    def kind(arg):
+        arg = arg.strip()
+        if "*" in arg:
+            return "ptr"
+        for name, k in (("int64_t", "i64"), ("int32_t", "i32"), ("double", "f64"), ("float", "f32"), ("int ", "i32")):
+            if arg.startswith(name):
+                return k
+        raise AssertionError(f"unparsed argument {arg!r}")
+
+    ckind = {_lib.P: "ptr", _lib.I32: "i32", _lib.I64: "i64", _lib.F32: "f32", _lib.F64: "f64", _lib.GD: "ptr", _lib.FD: "ptr",
+             _lib.FG: "ptr", _lib.PI32: "ptr", _lib.PI64: "ptr", _lib.PP: "ptr"}
+    checked = 0
+    for name, argtypes in _lib.SIGNATURES.items():
+        assert name in protos, f"{name} bound but no prototype found"
+        args = [a for a in protos[name].split(",") if a.strip() and a.strip() != "void"]
+        want = [kind(a) for a in args]
+        got = [ckind[t] for t in argtypes]
+        assert want == got, (name, want, got)
+        checked += 1
+    assert checked == len(_lib.SIGNATURES) >= 36
