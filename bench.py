@@ -245,7 +245,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "rays_per_gpu_per_step": n_rays, "samples_per_ray": 768,
                        "global_rays_per_step": n_rays * world,
-                       "parallelism": f"frame-sharded x{world}, no collective" if inference else f"ray-sharded dp{world}, 1 RCCL all-reduce/step",
+                       "parallelism": f"frame-sharded x{world}, no collective" if inference else f"ray-sharded dp{world}, one RCCL gradient all-reduce per step in two phases, overlapped with the tail of the backward pass",
                        "step": "no_grad render(staged=True, max_ray_batch=4096) + U-Net + pano_to_lidar + chamfer/F-score" if inference else
                                "forward + backward + Adam" + ("" if args.no_ema else " + parameter EMA") + ", losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else "") + (" + scene-flow consistency" if args.flow else "") + (" + line-of-sight" if args.urf else "") + ("" if args.chamfer or args.flow or args.urf else " (no chamfer/flow loss)")},
             "roofline": roofline,
