@@ -1,7 +1,5 @@
 """Chamfer distance.  Mirror of the reference's utils/chamfer3D/dist_chamfer_3D.py:31-83 (``chamfer_3DDist`` module and
 its autograd function) on the HIP kernels of lidar4d_amd/csrc/chamfer.hip (which replace utils/chamfer3D/chamfer3D.cu)."""
-import ctypes as C
-
 import torch
 from torch import nn
 from torch.autograd import Function

@@ -7,8 +7,6 @@ data/kitti360_dataset.py (the KITTI-360 files are not available): same per-step 
 1 m/frame track, scale/offset convention of configs/kitti360_4950.txt, ground truth from an analytic scene
 (ground plane + boxes, 10 % random ray drops); SURVEY.md section 8(d).
 """
-import math
-
 import numpy as np
 import torch
 

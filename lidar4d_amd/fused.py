@@ -11,8 +11,6 @@ Backward is the exact adjoint, accumulating parameter gradients straight into th
 (ParamStore); autograd sees one node.  fp16 adjoint operands carry ``model.loss_scale`` (tiny-cuda-nn uses the
 same device: SURVEY A.1/A.3, loss_scale 128).
 """
-import ctypes as C
-
 import numpy as np
 import torch
 

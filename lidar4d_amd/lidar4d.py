@@ -12,7 +12,6 @@ MIOpen; it is not part of the flat parameter arenas (the reference trains it sep
 """
 import numpy as np
 import torch
-import torch.nn as nn
 
 from . import tcnn
 from .activation import trunc_exp

@@ -10,7 +10,6 @@ Lagrange coefficients, compositing recurrences) rather than through ``F.grid_sam
 HIP kernels can be read against it line by line.
 """
 import itertools
-import math
 
 import numpy as np
 import torch

@@ -7,7 +7,6 @@ Same policy as make_golden.py: the reference is imported from a throw-away scrat
 key lists are saved.  TEST INFRASTRUCTURE.
 """
 import shutil
-import sys
 
 import numpy as np
 import torch
