@@ -397,3 +397,74 @@ def test_ctypes_signatures_match_header_prototypes():
         assert want == got, (name, want, got)
         checked += 1
     assert checked == len(_lib.SIGNATURES) >= 36
+
+
+def test_shift_trajectory_matches_reference_script():
+    """simulator.shift_trajectory against a transcription of main_lidar4d_sim.py:249-275."""
+    import torch.nn.functional as F
+    from lidar4d_amd.simulator import shift_trajectory
+    g = torch.Generator().manual_seed(3)
+    origins = torch.cumsum(torch.rand(6, 1, 3, generator=g) * 0.02, dim=0)
+    rays_o = origins.expand(6, 5, 3).contiguous()
+    for align in (False, True):
+        sx, sy, sz, scale = 1.5, -0.7, 0.3, 0.0105
+        want = rays_o.clone()
+        shift_x, shift_y = sx, sy
+        forward = torch.tensor([[1, 0, 0]]).to(rays_o)
+        for i in range(rays_o.shape[0]):
+            if align:
+                if i < rays_o.shape[0] - 1:
+                    forward = F.normalize((rays_o[i + 1, 0, :] - rays_o[i, 0, :]).unsqueeze(0), p=2)
+                left = torch.tensor([-forward[:, 1], forward[:, 0], forward[:, 2]]).to(forward)
+                shift_x = (sx * forward + sy * left)[:, 0]
+                shift_y = (sx * forward + sy * left)[:, 1]
+            want[i, :, 0] = want[i, :, 0] + shift_x * scale
+            want[i, :, 1] = want[i, :, 1] + shift_y * scale
+            want[i, :, 2] = want[i, :, 2] + sz * scale
+        got = shift_trajectory(rays_o, sx, sy, sz, scale, align_axis=align)
+        assert torch.allclose(got, want, rtol=0, atol=1e-7), align
+
+
+def test_simulator_pipeline_with_stub_model(tmp_path):
+    """Simulator.render's frame loop (simulator.py:104-195): staged render -> U-Net -> mask -> range image to points ->
+    files, with a stub model and the numpy conversion standing in for the device parts (each of which has its own GPU
+    parity test); what is under test is the glue."""
+    import types
+    from lidar4d_amd.simulator import Simulator
+    from oracle import convert_ref
+    H, W = 8, 32
+
+    class Stub:
+        calls = []
+
+        def render(self, rays_o, rays_d, time, staged=False, perturb=True, **kw):
+            Stub.calls.append((tuple(rays_o.shape), staged, perturb, kw.get("num_steps")))
+            n = rays_o.shape[1]
+            depth = (torch.arange(n, dtype=torch.float32).view(1, n) % 7 + 1) * 0.05 + float(time)
+            drop = (torch.arange(n).view(1, n) % 3 != 0).float()
+            return {"depth_lidar": depth, "image_lidar": torch.stack([drop, torch.full((1, n), 0.25)], -1)}
+
+        def unet(self, x):  # [1, 3, H, W] -> [1, 1, H, W]: pass the ray-drop channel through, but drop the first row
+            out = x[:, :1].clone()
+            out[:, :, 0] = 0.0
+            return out
+
+    opt = types.SimpleNamespace(scale=0.01, fov_lidar=[2.0, 26.9], num_steps=64)
+    to_points = lambda d, i, fov: convert_ref.pano_to_lidar_with_intensities(d.numpy().astype(np.float32), i.numpy().astype(np.float32), fov)
+    sim = Simulator("stub", opt, Stub(), device="cpu", mute=True, workspace=str(tmp_path), use_checkpoint="scratch",
+                    H_lidar=H, W_lidar=W, to_points=to_points)
+    frames = 3
+    rays_o, rays_d = torch.zeros(frames, H * W, 3), torch.zeros(frames, H * W, 3)
+    times = torch.tensor([[0.0], [0.5], [1.0]])
+    last = sim.render(rays_o, rays_d, times)
+    assert Stub.calls == [((1, H * W, 3), True, False, 64)] * frames
+    for i in range(frames):
+        pts = np.load(tmp_path / "points" / f"lidar4d_{i:04d}.npy")
+        keep = (np.arange(H * W) % 3 != 0).reshape(H, W)
+        keep[0] = False  # the stub U-Net vetoes the first row
+        assert pts.shape == (int(keep.sum()), 4) and np.all(pts[:, 3] == 0.25)
+        rng = np.linalg.norm(pts[:, :3], axis=1)
+        want = (((np.arange(H * W) % 7 + 1) * 0.05 + float(times[i])) / 0.01).reshape(H, W)[keep]
+        np.testing.assert_allclose(rng, want, rtol=1e-5)
+    assert np.array_equal(last, np.load(tmp_path / "points" / f"lidar4d_{frames - 1:04d}.npy"))
+    assert os.path.exists(tmp_path / "images" / "lidar4d_0000.png") and os.path.exists(tmp_path / "log_stub.txt")
