@@ -107,6 +107,48 @@ def gen_param_order():
     save("param_order", names=np.array([n for n, _ in ref.named_parameters()]), state_keys=np.array(list(ref.state_dict().keys())))
 
 
+C2_LIKE = dict(n_levels_hash=16, n_levels_plane=4, min_resolution=8, num_layers_sigma=3, density_scale=30.0)
+
+
+def gen_c2_like():
+    """BASELINE configs[1] shape (L = 16 hash levels, 3-layer sigma network) through the reference's glue: density,
+    flow and a render with gradient digests, so the oracle is pinned for this configuration as well."""
+    import model.lidar4d as ref_lidar4d
+    from oracle import tcnn_ref
+    from oracle.detparams import fill_model, grad_digest
+    from oracle.make_golden import SMALL_MODEL, test_rays
+
+    tcnn_ref.set_precision("fp32")
+    cfg = dict(SMALL_MODEL, **C2_LIKE)
+    model = fill_model(ref_lidar4d.LiDAR4D(**cfg), seed=9)
+    pts = det_uniform((256, 3), "c2pts", -1.0, 1.0)
+    arrays = {}
+    for fi in (0, 30):
+        model.zero_grad()
+        t = torch.tensor([[fi / 50]])
+        out = model.density(pts, t)
+        gsig, ggeo = det_uniform((256,), f"c2gs{fi}", -1, 1), det_uniform((256, 15), f"c2gg{fi}", -1, 1)
+        ((out["sigma"] * gsig).sum() + (out["geo_feat"] * ggeo).sum()).backward()
+        arrays[f"sigma_f{fi}"], arrays[f"geo_f{fi}"] = out["sigma"], out["geo_feat"]
+        for n, v in grad_digest(model).items():
+            arrays[f"gdig_f{fi}.{n}"] = v
+    ro, rd = test_rays(24, 8)
+    noise = det_uniform((24, 96), "c2n", 0.0, 1.0)
+    orig_rand = torch.rand
+    torch.rand = lambda *a, **k: noise.clone()
+    try:
+        model.zero_grad()
+        out = model.render(ro, rd, torch.tensor([[0.6]]), staged=False, num_steps=96, perturb=True)
+    finally:
+        torch.rand = orig_rand
+    gd_, gi_ = det_uniform(tuple(out["depth_lidar"].shape), "c2gd", -1, 1), det_uniform(tuple(out["image_lidar"].shape), "c2gi", -1, 1)
+    ((out["depth_lidar"] * gd_).sum() + (out["image_lidar"] * gi_).sum()).backward()
+    for n, v in grad_digest(model).items():
+        arrays[f"gdig_render.{n}"] = v
+    save("c2_like", pts=pts, rays_o=ro, rays_d=rd, noise=noise, depth=out["depth_lidar"], image=out["image_lidar"],
+         weights=out["weights"], z_vals=out["z_vals"], **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     R = _import_reference()
@@ -115,6 +157,7 @@ def main():
     gen_kitti360()
     gen_random_rays()
     gen_param_order()
+    gen_c2_like()
     shutil.rmtree(R["scratch"], ignore_errors=True)
 
 

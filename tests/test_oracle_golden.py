@@ -179,3 +179,37 @@ def test_render_small(golden, small_model, tag):
                                 num_steps=int(g["num_steps"]), perturb=False)
     close(st["depth_lidar"], gs["depth"], rtol=1e-4)
     close(st["image_lidar"], gs["image"], rtol=1e-4, atol=1e-6)
+
+
+def test_c2_like_configuration(golden):
+    """BASELINE configs[1] shape (L = 16 hash levels -> 176-wide sigma-net input, 3-layer sigma network): the oracle against
+    the reference's own glue for this configuration too (oracle/make_golden_next.py::gen_c2_like); the HIP path is compared
+    with the oracle on the same configuration in tests/test_gpu_model.py::test_render_c2_like_config_vs_oracle."""
+    from oracle import tcnn_ref
+    from oracle.make_golden_next import C2_LIKE
+    g = golden("c2_like")
+    prev = tcnn_ref.get_precision()
+    tcnn_ref.set_precision("fp32")
+    try:
+        model = fill_model(fields_ref.LiDAR4D(**dict(SMALL_MODEL, **C2_LIKE)), seed=9)
+        pts = T(g["pts"])
+        for fi in (0, 30):
+            model.zero_grad()
+            out = model.density(pts, torch.tensor([[fi / 50]]))
+            close(out["sigma"], g[f"sigma_f{fi}"], rtol=1e-4)
+            close(out["geo_feat"], g[f"geo_f{fi}"], rtol=1e-4, atol=1e-5)
+            gsig, ggeo = det_uniform((256,), f"c2gs{fi}", -1, 1), det_uniform((256, 15), f"c2gg{fi}", -1, 1)
+            ((out["sigma"] * gsig).sum() + (out["geo_feat"] * ggeo).sum()).backward()
+            _digest_close(model, g, f"gdig_f{fi}.")
+        model.zero_grad()
+        out = model.render(T(g["rays_o"]), T(g["rays_d"]), torch.tensor([[0.6]]), staged=False, num_steps=96, perturb=True,
+                           noise=T(g["noise"]))
+        assert torch.equal(out["z_vals"], T(g["z_vals"]))
+        close(out["weights"], g["weights"], rtol=1e-4, atol=1e-7)
+        close(out["depth_lidar"], g["depth"], rtol=1e-4, atol=1e-7)
+        close(out["image_lidar"], g["image"], rtol=1e-4, atol=1e-6)
+        gd_, gi_ = det_uniform(tuple(out["depth_lidar"].shape), "c2gd", -1, 1), det_uniform(tuple(out["image_lidar"].shape), "c2gi", -1, 1)
+        ((out["depth_lidar"] * gd_).sum() + (out["image_lidar"] * gi_).sum()).backward()
+        _digest_close(model, g, "gdig_render.")
+    finally:
+        tcnn_ref.set_precision(prev)
