@@ -149,6 +149,39 @@ def gen_c2_like():
          weights=out["weights"], z_vals=out["z_vals"], **arrays)
 
 
+VARIANTS = {"frames4": (dict(num_frames=4), 2 / 3), "active": (dict(active_sensor=True), 0.5),
+            "tres4": (dict(time_resolution=4, num_frames=9), 0.375)}
+
+
+def gen_variants():
+    """Configurations off the default path (few frames, active sensor, another time resolution) through the reference's
+    glue: the render of tests/test_gpu_model.py::test_render_variants_vs_oracle, so the oracle is pinned there too."""
+    import model.lidar4d as ref_lidar4d
+    from oracle import tcnn_ref
+    from oracle.detparams import fill_model, grad_digest
+    from oracle.make_golden import SMALL_MODEL, test_rays
+
+    tcnn_ref.set_precision("fp32")
+    ro, rd = test_rays(16, 3)   # small: the CPU suite re-renders this with the oracle
+    noise = det_uniform((16, 64), "vn", 0.0, 1.0)
+    arrays = {"rays_o": ro, "rays_d": rd, "noise": noise}
+    for tag, (kw, frame_t) in VARIANTS.items():
+        model = fill_model(ref_lidar4d.LiDAR4D(**dict(SMALL_MODEL, density_scale=30.0, **kw)), seed=5)
+        orig_rand = torch.rand
+        torch.rand = lambda *a, **k: noise.clone()
+        try:
+            out = model.render(ro, rd, torch.tensor([[frame_t]], dtype=torch.float32), staged=False, num_steps=64, perturb=True)
+        finally:
+            torch.rand = orig_rand
+        gd_, gi_ = det_uniform((1, 16), "vgd", -1, 1), det_uniform((1, 16, 2), "vgi", -1, 1)
+        ((out["depth_lidar"] * gd_).sum() + (out["image_lidar"] * gi_).sum()).backward()
+        arrays.update({f"{tag}.depth": out["depth_lidar"], f"{tag}.image": out["image_lidar"], f"{tag}.wsum": out["weights_sum_lidar"],
+                       f"{tag}.z_vals_sum": out["z_vals"].double().sum()})
+        for n, v in grad_digest(model).items():
+            arrays[f"{tag}.gdig.{n}"] = v
+    save("render_variants", **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     R = _import_reference()
@@ -158,6 +191,7 @@ def main():
     gen_random_rays()
     gen_param_order()
     gen_c2_like()
+    gen_variants()
     shutil.rmtree(R["scratch"], ignore_errors=True)
 
 

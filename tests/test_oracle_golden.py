@@ -213,3 +213,27 @@ def test_c2_like_configuration(golden):
         _digest_close(model, g, "gdig_render.")
     finally:
         tcnn_ref.set_precision(prev)
+
+
+@pytest.mark.parametrize("tag", ["frames4", "active", "tres4"])
+def test_render_variant_configurations(golden, tag):
+    """Few frames / active sensor / another time resolution: oracle vs the reference's glue (gen_variants)."""
+    from oracle import tcnn_ref
+    from oracle.make_golden_next import VARIANTS
+    g = golden("render_variants")
+    kw, frame_t = VARIANTS[tag]
+    prev = tcnn_ref.get_precision()
+    tcnn_ref.set_precision("fp32")
+    try:
+        model = fill_model(fields_ref.LiDAR4D(**dict(SMALL_MODEL, density_scale=30.0, **kw)), seed=5)
+        out = model.render(T(g["rays_o"]), T(g["rays_d"]), torch.tensor([[frame_t]], dtype=torch.float32), staged=False,
+                           num_steps=64, perturb=True, noise=T(g["noise"]))
+        assert abs(float(out["z_vals"].double().sum()) - float(g[f"{tag}.z_vals_sum"])) == 0.0
+        close(out["depth_lidar"], g[f"{tag}.depth"], rtol=1e-4, atol=1e-7)
+        close(out["image_lidar"], g[f"{tag}.image"], rtol=1e-4, atol=1e-6)
+        close(out["weights_sum_lidar"], g[f"{tag}.wsum"], rtol=1e-4, atol=1e-6)
+        gd_, gi_ = det_uniform((1, 16), "vgd", -1, 1), det_uniform((1, 16, 2), "vgi", -1, 1)
+        ((out["depth_lidar"] * gd_).sum() + (out["image_lidar"] * gi_).sum()).backward()
+        _digest_close(model, g, f"{tag}.gdig.")
+    finally:
+        tcnn_ref.set_precision(prev)
