@@ -7,8 +7,9 @@
 //   pass 1  (one thread per (sample, level)): the 2^D corner contributions {entry, w * g[0..NV)} (fp16 payload) are
 //           partitioned inside the workgroup by bin = entry >> shift (LDS histogram + ranks) and written, sorted by
 //           bin, into the workgroup's own fixed slot of the record buffer together with its bin offsets -- no global
-//           atomics, no overflow, deterministic layout.  Coarse levels first merge runs of equal entries along the
-//           ray (wave_run_reduce).
+//           atomics, no overflow, deterministic layout.  Coarse levels first merge runs of samples in one cell along the
+//           ray (DPP row scan, wave_dev.h).  Blocks are ordered level-fast and XCD-aware so that the levels of a tile
+//           share the gradient rows in one L2.
 //   pass 2  (one workgroup per (level, bin)): walks every pass-1 workgroup's run for its bin (16 lanes per run),
 //           accumulates in LDS as int64 fixed point (ds_add_u64: 2.9 T lane-ops/s, exact and order independent), and
 //           adds the segment to the fp32 gradient table with plain stores -- each segment has exactly one owner.

@@ -9,9 +9,11 @@
 //
 //   0. static 3-D hash grid: sorted scatter (binscatter.hip).
 //   1. prep (one thread per sample): reads dX; writes the static planes' per-plane gradient factors
-//      gvs[scale][plane][p][8] (product rule already applied; plane-major so that a (scale, plane) pass reads it densely), the dynamic-hash upstream gradient transposed
-//      gdynT[col][p], and running maxima for the fixed-point scales.
-//   2. planes_dyn (one pass): all time planes of all scales fit in LDS as the 3 rows around t -> int32 accumulation;
+//      gvs[scale][plane][p][8] (product rule already applied; plane-major so that a (scale, plane) pass reads it
+//      densely), the dynamic-hash upstream gradient transposed gdynT[col][p], and running maxima for the fixed-point
+//      scales.
+//   2. planes_dyn (one pass): one LDS row per (scale, time plane, frame) -- the time rows and their weights are the
+//      same for every sample, so only the spatial axis is accumulated (int32) and the flush applies the row weights;
 //      also the coordinate adjoint of the two warped lookups = d(flow).
 //   3. planes_static (passes over <=128 KB row bands of each plane): int32 accumulation from gvs.
 //   4. dynhash (passes over (plane, level, entry range)): the 2 slices x 4 features of an entry all receive
