@@ -138,3 +138,24 @@ def write_kitti360_fixture(root, H=8, W=32, n_train=4, n_val=2):
         with open(os.path.join(root, f"transforms_{cfg['sequence_id']}_{split}.json"), "w") as fh:
             json.dump({"h_lidar": H, "w_lidar": W, "frames": frames}, fh)
     return cfg
+
+
+def write_scan_fixture(root, n_frames=3, n_points=4000):
+    """Raw-scan side of the preprocessing fixtures: ``<frame>.bin`` files (float32 x, y, z, intensity like KITTI-360's
+    velodyne_points) with deterministic contents, and a sensor-to-world pose per frame.  Returns (bin paths, poses)."""
+    import os
+
+    paths, poses = [], []
+    for k in range(n_frames):
+        az = det_uniform((n_points,), f"pp_az{k}", -np.pi, np.pi).numpy()
+        el = det_uniform((n_points,), f"pp_el{k}", np.deg2rad(-24.0), np.deg2rad(1.5)).numpy()
+        r = det_uniform((n_points,), f"pp_r{k}", 1.0, 90.0).numpy()
+        cloud = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el),
+                          det_uniform((n_points,), f"pp_i{k}", 0, 1).numpy()], -1).astype(np.float32)
+        path = os.path.join(root, f"{k:010d}.bin")
+        cloud.tofile(path)
+        paths.append(path)
+        a = 0.3 * k
+        c, s = np.cos(a), np.sin(a)
+        poses.append(np.array([[c, -s, 0, 100 + 5 * k], [s, c, 0, -40 + 2 * k], [0, 0, 1, 3 + 0.1 * k], [0, 0, 0, 1]], dtype=np.float32))
+    return paths, poses

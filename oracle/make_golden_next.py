@@ -182,6 +182,33 @@ def gen_variants():
     save("render_variants", **arrays)
 
 
+def gen_preprocess(scratch):
+    """The reference's preprocessing functions (raw scans -> range views; range views + poses -> scene scale / offset) on
+    the tiny deterministic sequence of oracle.detparams.write_scan_fixture."""
+    import os
+    import sys
+    import tempfile
+
+    from oracle.detparams import write_scan_fixture
+    sys.path.insert(0, os.path.join(scratch, "ref", "data", "preprocess"))
+    import cal_seq_config as ref_cfg
+    import generate_rangeview as ref_gen
+
+    H, W, K = 16, 64, (2.0, 26.9)
+    root = tempfile.mkdtemp(prefix="l4d_pre_")
+    bins, poses = write_scan_fixture(root)
+    views, view_paths = [], []
+    for p in bins:
+        cloud = np.fromfile(p, dtype=np.float32).reshape(-1, 4)
+        view = ref_gen.LiDAR_2_Pano_KITTI(cloud, H, W, K)
+        views.append(view)
+        view_paths.append(p.replace(".bin", ".npy"))
+        np.save(view_paths[-1], view)
+    scale, center = ref_cfg.cal_centerpose_bound_scale(view_paths, poses, list(K))
+    save("preprocess", H=H, W=W, K=np.array(K), views=np.stack(views), poses=np.stack(poses), scale=scale, centerpose=np.array(center))
+    shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     torch.set_num_threads(8)
     R = _import_reference()
@@ -192,6 +219,7 @@ def main():
     gen_param_order()
     gen_c2_like()
     gen_variants()
+    gen_preprocess(R["scratch"])
     shutil.rmtree(R["scratch"], ignore_errors=True)
 
 

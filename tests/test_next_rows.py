@@ -320,3 +320,31 @@ def test_training_step_with_all_loss_terms():
     finally:
         data.patch_size_lidar = 1
     assert np.isfinite(l_patch)
+
+
+def test_preprocess_glue_matches_reference_scripts(tmp_path):
+    """lidar4d_amd.preprocess (raw scans -> range views; range views + poses -> scene scale / offset / config file) against
+    the reference's data/preprocess functions run on the same files (gen_preprocess).  The conversions are injected from
+    the CPU restatement here -- the HIP versions have their own GPU parity tests -- so this pins the file handling and
+    the float64 reductions."""
+    from lidar4d_amd import preprocess
+    from oracle.detparams import write_scan_fixture
+    g = np.load(os.path.join(GOLD, "preprocess.npz"))
+    H, W, K = int(g["H"]), int(g["W"]), tuple(float(v) for v in g["K"])
+    bins, poses = write_scan_fixture(str(tmp_path))
+    assert np.array_equal(np.stack(poses), g["poses"])
+    to_pano = lambda pts, h, w, k, md: convert_ref.lidar_to_pano_with_intensities(pts.numpy(), h, w, k, md)
+    written = preprocess.generate_rangeview(bins, str(tmp_path / "train"), H, W, K, device="cpu", to_pano=to_pano)
+    assert [os.path.basename(p) for p in written] == [f"{k:010d}.npy" for k in range(3)]
+    for k, p in enumerate(written):
+        view = np.load(p)
+        assert view.dtype == np.float64 and view.shape == (H, W, 3) and np.array_equal(view, g["views"][k])
+    to_points = lambda depth, fov: convert_ref.pano_to_lidar_with_intensities(depth.numpy(), np.zeros_like(depth.numpy()), fov)[:, :3]
+    scale, center, near, far = preprocess.cal_centerpose_bound_scale(written, poses, list(K), device="cpu", to_points=to_points)
+    assert abs(scale - float(g["scale"])) <= 1e-12 * float(g["scale"])
+    np.testing.assert_allclose(center, g["centerpose"], rtol=1e-12)
+    assert 0 < near < far < 80.0
+    cfg = preprocess.write_seq_config(str(tmp_path / "configs" / "kitti360_4950.txt"), "kitti360", "data/kitti360", "4950", 51, K, scale, center)
+    lines = open(cfg).read().splitlines()
+    assert lines[0] == "dataloader = kitti360" and lines[3] == "num_frames = 51" and lines[5] == f"scale = {scale}"
+    assert lines[4] == "fov_lidar = [2.0, 26.9]" and lines[6].startswith("offset = [")
