@@ -110,7 +110,32 @@ def cpu_baseline(num_frames, scale, budget_s=20.0, timeout_s=240):
         return {"value": None, "unit": "rays/s", "cores": None, "kind": "port", "sample": f"cpu baseline timed out after {timeout_s} s"}
 
 
+class _QuietStdout:
+    """Everything written to file descriptor 1 inside the block goes to stderr instead -- including what native libraries
+    print on their own (RCCL announces itself on stdout when the process group comes up) -- so that the JSON line stays
+    the only thing this script ever writes to stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
+    with _QuietStdout():
+        line = _run()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+def _run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -255,9 +280,9 @@ def main():
                             "note": "random-init field vs synthetic ground truth: exercises the eval path, not a quality claim"}
         if world == 1 and not args.no_cpu_baseline and not inference:
             line["cpu_baseline"] = cpu_baseline(51, KITTI360_SCALE)
-        print(json.dumps(line))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    return line if rank == 0 else None
 
 
 if __name__ == "__main__":
