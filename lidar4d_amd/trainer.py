@@ -8,6 +8,7 @@ scene-flow and line-of-sight loss terms (runner.py:215-276).  The patch gradient
 """
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -241,6 +242,46 @@ class FlatAdam:
         self.model.planes_encoder._cl_key = None  # channel-last plane copy must be rebuilt
 
 
+def refine_unet(unet, raydrop_input, raydrop_gt, epochs=1000, batch_size=None, lr=0.001, box_num_max=32, rng=None, log=None):
+    """The ray-drop refinement stage, runner.py:865-912: train the U-Net on the stacked [ray-drop, intensity, depth] images
+    the frozen field renders for the training frames (raydrop_input [B, 3, H, W]) against the ground-truth ray-drop masks
+    (raydrop_gt [B, 1, H, W]) -- BCE loss, Adam(lr) under a OneCycleLR of ``epochs`` steps, and per step a random number
+    (< box_num_max) of rectangles, each up to 10 % of the image per side, blanked out of all input channels so that the
+    network learns to fill holes.  ``rng``: numpy Generator / RandomState for the boxes and the batch choice (the reference
+    draws from the global numpy state).  Returns the list of losses.  Plain torch modules: runs on MIOpen on the GPU."""
+    rng = rng if rng is not None else np.random
+    randint = (lambda lo, hi=None: int(rng.integers(lo, hi) if hi is not None else rng.integers(lo))) if hasattr(rng, "integers") \
+        else (lambda lo, hi=None: int(rng.randint(lo, hi) if hi is not None else rng.randint(lo)))
+    unet.train()
+    optimizer = torch.optim.Adam(unet.parameters(), lr=lr, weight_decay=0)
+    scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=lr, total_steps=epochs)
+    bce = torch.nn.BCELoss()
+    H, W = raydrop_input.shape[2], raydrop_input.shape[3]
+    max_h, max_w = int(0.1 * H), int(0.1 * W)
+    losses = []
+    for it in range(epochs):
+        optimizer.zero_grad()
+        if batch_size is not None:
+            pick = torch.as_tensor(rng.choice(raydrop_input.shape[0], batch_size, replace=False), device=raydrop_input.device)
+            x, gt = raydrop_input[pick], raydrop_gt[pick]
+        else:
+            x, gt = raydrop_input, raydrop_gt
+        keep = torch.ones_like(x)
+        for _ in range(randint(box_num_max)):
+            bh, bw = randint(1, max(max_h, 2)), randint(1, max(max_w, 2))
+            y0, x0 = randint(H - bh), randint(W - bw)
+            keep[:, :, y0:y0 + bh, x0:x0 + bw] = 0.0
+        loss = bce(unet(x * keep), gt)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        if log is not None and it % 50 == 0:
+            log(f"iter:{it}, lr:{optimizer.param_groups[0]['lr']:.6f}, raydrop loss:{losses[-1]}")
+        optimizer.step()
+        scheduler.step()
+    unet.eval()
+    return losses
+
+
 class FlatEMA:
     """Exponential moving average of the parameters over the flat arena: what the reference keeps with
     ``torch_ema.ExponentialMovingAverage(model.parameters(), decay)`` (runner.py:97-98; updated after every optimiser
@@ -394,6 +435,24 @@ class Trainer:
         if self.ema is not None:
             self.ema.update()  # runner.py:534-535
         return loss
+
+    @torch.no_grad()
+    def collect_refine_data(self, frames=None, max_ray_batch=4096):
+        """runner.py:824-863: render every training frame with the (frozen) field and stack what the U-Net sees --
+        returns (raydrop_input [B, 3, H, W], raydrop_gt [B, 1, H, W]) for ``refine_unet``."""
+        self.model.eval()
+        if self.ema is not None:
+            self.ema.copy_to()  # the reference refines on the EMA weights and drops the raw ones (runner.py:819-821)
+        inputs, gts = [], []
+        for k in (range(self.dataset.num_frames) if frames is None else frames):
+            fr = self.dataset.frame(k)
+            H, W = fr["H_lidar"], fr["W_lidar"]
+            out = self.model.render(fr["rays_o_lidar"], fr["rays_d_lidar"], fr["time"], staged=True, perturb=False,
+                                    max_ray_batch=max_ray_batch, num_steps=self.num_steps)
+            image = out["image_lidar"].reshape(-1, H, W, 2)
+            inputs.append(torch.cat([image[..., 0], image[..., 1], out["depth_lidar"].reshape(-1, H, W)], dim=0).unsqueeze(0))
+            gts.append(fr["images_lidar"][:, :, :, 0].unsqueeze(0))
+        return torch.cat(inputs, 0).float().contiguous(), torch.cat(gts, 0).float().contiguous()
 
     @torch.no_grad()
     def test_step(self, data, refine=True, perturb=False, max_ray_batch=4096, raydrop_loss="mse", alpha_r=0.01):

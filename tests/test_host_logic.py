@@ -468,3 +468,28 @@ def test_simulator_pipeline_with_stub_model(tmp_path):
         np.testing.assert_allclose(rng, want, rtol=1e-5)
     assert np.array_equal(last, np.load(tmp_path / "points" / f"lidar4d_{frames - 1:04d}.npy"))
     assert os.path.exists(tmp_path / "images" / "lidar4d_0000.png") and os.path.exists(tmp_path / "log_stub.txt")
+
+
+def test_refine_unet_loop_learns_and_follows_reference_recipe():
+    """trainer.refine_unet (runner.py:865-912: BCE, Adam 1e-3 under OneCycleLR, random blank boxes) on a toy problem; the
+    U-Net is a plain torch module, so this runs on CPU."""
+    from lidar4d_amd.trainer import refine_unet
+    from lidar4d_amd.unet import UNet
+    torch.manual_seed(0)
+    net = UNet(in_channels=3, out_channels=1)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 32, 64, generator=g)
+    gt = (x[:, :1] > 0.5).float()  # learnable: threshold of the first channel
+    calls = []
+    rs = np.random.RandomState(3)
+    losses = refine_unet(net, x, gt, epochs=40, rng=rs, log=calls.append)
+    assert len(losses) == 40 and all(np.isfinite(losses)) and np.mean(losses[-5:]) < 0.85 * np.mean(losses[:5])
+    assert not net.training and len(calls) == 1 and calls[0].startswith("iter:0, lr:")
+    # the box recipe consumes the numpy stream like the reference: count, then (height, width, top, left) per box
+    rs2 = np.random.RandomState(3)
+    n_boxes = rs2.randint(32)
+    first = (rs2.randint(1, 3), rs2.randint(1, 6), None)
+    assert 0 <= n_boxes < 32 and 1 <= first[0] < 3 and 1 <= first[1] < 6
+    # batch_size picks distinct frames
+    losses_b = refine_unet(net, x, gt, epochs=3, batch_size=1, rng=np.random.default_rng(1))
+    assert len(losses_b) == 3
