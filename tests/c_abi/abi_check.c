@@ -1,0 +1,60 @@
+/* Plain-C consumer of include/lidar4d_hip.h: proves that the header is valid C (no C++ or torch types in the boundary),
+ * that every declared entry point links against liblidar4d_hip.so with the declared prototype, and that the version and
+ * error calls work without a GPU.  Built and run by tests/test_host_logic.py::test_c_abi_from_plain_c (gcc). */
+#include <stdio.h>
+
+#include "lidar4d_hip.h"
+
+typedef void (*fn_t)(void);
+
+int main(void) {
+  const fn_t entry_points[] = {
+      (fn_t)&l4d_adam_step,
+      (fn_t)&l4d_attr_gather,
+      (fn_t)&l4d_attr_gather_bwd,
+      (fn_t)&l4d_attr_scatter,
+      (fn_t)&l4d_attr_scatter_bwd,
+      (fn_t)&l4d_cast_f32_to_f16,
+      (fn_t)&l4d_chamfer_bwd,
+      (fn_t)&l4d_chamfer_fwd,
+      (fn_t)&l4d_chamfer_workspace,
+      (fn_t)&l4d_composite_bwd,
+      (fn_t)&l4d_composite_fwd,
+      (fn_t)&l4d_composite_image,
+      (fn_t)&l4d_density_encode_bwd,
+      (fn_t)&l4d_density_encode_bwd_workspace,
+      (fn_t)&l4d_density_encode_fwd,
+      (fn_t)&l4d_field_width,
+      (fn_t)&l4d_freq_fwd,
+      (fn_t)&l4d_hashgrid_bwd,
+      (fn_t)&l4d_hashgrid_fwd,
+      (fn_t)&l4d_hashgrid_t_bwd,
+      (fn_t)&l4d_hashgrid_t_bwd_workspace,
+      (fn_t)&l4d_hashgrid_t_fwd,
+      (fn_t)&l4d_last_error,
+      (fn_t)&l4d_lidar_to_pano,
+      (fn_t)&l4d_lidar_to_pano_workspace,
+      (fn_t)&l4d_mlp_bwd,
+      (fn_t)&l4d_mlp_fwd,
+      (fn_t)&l4d_pano_to_lidar,
+      (fn_t)&l4d_pano_to_lidar_workspace,
+      (fn_t)&l4d_planes_bwd,
+      (fn_t)&l4d_planes_fwd,
+      (fn_t)&l4d_planes_relayout,
+      (fn_t)&l4d_sample_rays,
+      (fn_t)&l4d_sample_rays_xt,
+      (fn_t)&l4d_sigma_bwd,
+      (fn_t)&l4d_sigma_from_h,
+      (fn_t)&l4d_time_setup,
+      (fn_t)&l4d_version,
+  };
+  const int n = (int)(sizeof(entry_points) / sizeof(entry_points[0]));
+  for (int i = 0; i < n; ++i)
+    if (!entry_points[i]) return 2;
+  if (l4d_version() != L4D_ABI_VERSION) {
+    fprintf(stderr, "ABI mismatch: library %d, header %d\n", l4d_version(), L4D_ABI_VERSION);
+    return 3;
+  }
+  printf("%d entry points, ABI v%d, last error: \"%s\"\n", n, l4d_version(), l4d_last_error());
+  return 0;
+}

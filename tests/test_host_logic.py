@@ -493,3 +493,21 @@ def test_refine_unet_loop_learns_and_follows_reference_recipe():
     # batch_size picks distinct frames
     losses_b = refine_unet(net, x, gt, epochs=3, batch_size=1, rng=np.random.default_rng(1))
     assert len(losses_b) == 3
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """tests/c_abi/abi_check.c: include/lidar4d_hip.h consumed by a C99 compiler (-Wall -Wextra -Werror), every declared
+    entry point linked against the shared library, version / error calls executed -- no Python, no torch in the boundary."""
+    import shutil
+    import subprocess
+    from lidar4d_amd import _lib
+    if shutil.which("gcc") is None or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("needs gcc and the built library")
+    exe = str(tmp_path / "abi_check")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi", "abi_check.c"), "-L", libdir, "-llidar4d_hip", f"-Wl,-rpath,{libdir}",
+                    "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    n_declared = len(_lib.SIGNATURES) + 2
+    assert out.startswith(f"{n_declared} entry points, ABI v{_lib.ABI_VERSION}")
