@@ -1,16 +1,24 @@
 """Dataset preparation either side of the on-disk format the path trains on.  Mirrors of the
-reference's data/preprocess/generate_rangeview.py:28-70 (raw Velodyne scans -> range views) and
-data/preprocess/cal_seq_config.py:28-69,92-111 (scene scale / offset of a sequence -> configs/<dataset>_<seq>.txt), with
+reference's data/preprocess/generate_rangeview.py:28-70 (raw Velodyne scans -> range views),
+kitti360_loader.py:62-127 + kitti360_to_nerf.py:76-146 (raw poses and calibration -> transforms_<seq>_<split>.json) and
+cal_seq_config.py:28-69,92-111 (scene scale / offset of a sequence -> configs/<dataset>_<seq>.txt), with
 the point <-> range-image conversions on the device (lidar4d_amd.convert; the reference walks every point of every scan
 in a python loop).
 
 The conversion functions are parameters (``to_pano`` / ``to_points``) so that the file handling and the reductions can be
 exercised without a GPU; they default to the HIP kernels.
 """
+import json
 import os
 
 import numpy as np
 import torch
+
+from .kitti360 import SEQUENCE_FRAMES
+
+# held-out frames of each sequence (kitti360_to_nerf.py:32-73): four frames, every 13th of the 64-frame sequences and
+# every 10th of the 51-frame ones; "test" is the same set as "val"
+VAL_FRAMES = {seq: [lo + (13 if hi - lo == 63 else 10) * k for k in range(1, 5)] for seq, (lo, hi) in SEQUENCE_FRAMES.items()}
 
 
 def range_view_from_points(points, H, W, intrinsics, max_depth=80.0, to_pano=None):
@@ -76,3 +84,56 @@ def write_seq_config(config_path, dataset, root_path, sequence_id, num_frames, f
     with open(config_path, "w") as fh:
         fh.write("".join(f"{key} = {value}\n" for key, value in entries.items()))
     return config_path
+
+
+def load_lidar_poses(kitti_360_root, sequence_name, frame_ids):
+    """data/preprocess/kitti360_loader.py:62-127: sensor-to-world matrices of the Velodyne from KITTI-360's raw files --
+    ``data_poses/<seq>_sync/poses.txt`` (frame id + 3x4 IMU-to-world), ``calibration/calib_cam_to_pose.txt`` (``image_00:``
+    3x4 camera-to-IMU) and ``calibration/calib_cam_to_velo.txt`` (3x4 camera-to-Velodyne):
+    velo_to_world = imu_to_world @ cam00_to_imu @ inv(cam00_to_velo); frames without a pose reuse the previous one.
+    (Restated from the reference, which needs the ``camtools`` package that is not available here: unpinned.)"""
+    pad = lambda m: np.vstack([np.asarray(m, dtype=np.float64).reshape(3, 4), [0.0, 0.0, 0.0, 1.0]])
+    imu_to_world = {}
+    for row in np.loadtxt(os.path.join(kitti_360_root, "data_poses", f"{sequence_name}_sync", "poses.txt"), ndmin=2):
+        imu_to_world[int(row[0])] = row[1:].reshape(3, 4)
+    cam_to_imu = None
+    with open(os.path.join(kitti_360_root, "calibration", "calib_cam_to_pose.txt")) as fh:
+        for line in fh:
+            if line.startswith("image_00"):
+                cam_to_imu = pad([float(v) for v in line.split(":", 1)[1].split()])
+    if cam_to_imu is None:
+        raise ValueError("calib_cam_to_pose.txt has no image_00 entry")
+    with open(os.path.join(kitti_360_root, "calibration", "calib_cam_to_velo.txt")) as fh:
+        cam_to_velo = pad([float(v) for v in fh.readline().split()])
+    velo_to_cam = np.linalg.inv(cam_to_velo)
+    out, last = [], None
+    for fid in frame_ids:
+        if fid in imu_to_world:
+            last = pad(imu_to_world[fid] @ cam_to_imu @ velo_to_cam)
+        if last is None:
+            raise ValueError(f"no pose at or before frame {fid}")
+        out.append(last)
+    return np.stack(out)
+
+
+def write_transforms(root, sequence_id, lidar2world, range_view_dir="train"):
+    """data/preprocess/kitti360_to_nerf.py:76-146: the ``transforms_<seq>_{train,val,test}.json`` files the dataset reader
+    loads -- lidar2world [frames, 4, 4] for every frame of the sequence (first to last id inclusive), range views expected
+    as ``<root>/<range_view_dir>/<frame id, 10 digits>.npy``.  Returns the three paths."""
+    sequence_id = str(sequence_id)
+    first, last = SEQUENCE_FRAMES[sequence_id]
+    frame_ids = list(range(first, last + 1))
+    if len(lidar2world) != len(frame_ids):
+        raise ValueError(f"sequence {sequence_id} has {len(frame_ids)} frames, got {len(lidar2world)} poses")
+    h, w, _ = np.load(os.path.join(root, range_view_dir, f"{first:010d}.npy")).shape
+    held_out = VAL_FRAMES[sequence_id]
+    splits = {"train": [f for f in frame_ids if f not in held_out], "val": held_out, "test": held_out}
+    paths = []
+    for split, ids in splits.items():
+        doc = {"w_lidar": int(w), "h_lidar": int(h), "num_frames": len(frame_ids), "num_frames_split": len(ids),
+               "frames": [{"frame_id": f, "lidar_file_path": os.path.join(range_view_dir, f"{f:010d}.npy"),
+                           "lidar2world": np.asarray(lidar2world[f - first]).tolist()} for f in ids]}
+        paths.append(os.path.join(root, f"transforms_{sequence_id}_{split}.json"))
+        with open(paths[-1], "w") as fh:
+            json.dump(doc, fh, indent=2)
+    return paths

@@ -348,3 +348,51 @@ def test_preprocess_glue_matches_reference_scripts(tmp_path):
     lines = open(cfg).read().splitlines()
     assert lines[0] == "dataloader = kitti360" and lines[3] == "num_frames = 51" and lines[5] == f"scale = {scale}"
     assert lines[4] == "fov_lidar = [2.0, 26.9]" and lines[6].startswith("offset = [")
+
+
+def test_transforms_writer_roundtrips_through_the_reader(tmp_path):
+    """preprocess.load_lidar_poses + write_transforms (kitti360_loader.py:62-127, kitti360_to_nerf.py:76-146) produce files
+    the (reference-pinned) reader loads: schema, splits, pose algebra."""
+    import json
+    from lidar4d_amd import preprocess
+    from lidar4d_amd.kitti360 import KITTI360Dataset, SEQUENCE_FRAMES
+    root, seq = tmp_path / "kitti360", "4950"
+    first, last = SEQUENCE_FRAMES[seq]
+    k3 = root / "KITTI-360"
+    (k3 / "calibration").mkdir(parents=True)
+    (k3 / "data_poses" / "2013_05_28_drive_0000_sync").mkdir(parents=True)
+    cam_to_imu = np.array([[0.0, 0.0, 1.0, 1.5], [-1.0, 0.0, 0.0, 0.1], [0.0, -1.0, 0.0, 0.9]])
+    cam_to_velo = np.array([[0.0, -1.0, 0.0, 0.2], [0.0, 0.0, -1.0, -0.1], [1.0, 0.0, 0.0, -0.3]])
+    (k3 / "calibration" / "calib_cam_to_pose.txt").write_text(
+        "image_00: " + " ".join(f"{v:.6f}" for v in cam_to_imu.reshape(-1)) + "\nimage_01: " + " ".join(["0"] * 12) + "\n")
+    (k3 / "calibration" / "calib_cam_to_velo.txt").write_text(" ".join(f"{v:.6f}" for v in cam_to_velo.reshape(-1)) + "\n")
+    rows = []
+    for fid in range(first, last + 1):
+        if fid == first + 7:
+            continue  # a frame without a pose reuses the previous one
+        a = 0.01 * (fid - first)
+        imu = np.array([[np.cos(a), -np.sin(a), 0.0, 1000.0 + (fid - first)], [np.sin(a), np.cos(a), 0.0, 3700.0], [0.0, 0.0, 1.0, 115.0]])
+        rows.append([fid] + imu.reshape(-1).tolist())
+    np.savetxt(k3 / "data_poses" / "2013_05_28_drive_0000_sync" / "poses.txt", np.array(rows))
+    poses = preprocess.load_lidar_poses(str(k3), "2013_05_28_drive_0000", range(first, last + 1))
+    assert poses.shape == (51, 4, 4) and np.array_equal(poses[7], poses[6])
+    pad = lambda m: np.vstack([m, [0, 0, 0, 1]])
+    want = pad(np.array(rows[3][1:]).reshape(3, 4)) @ pad(cam_to_imu) @ np.linalg.inv(pad(cam_to_velo))
+    np.testing.assert_allclose(poses[3], want, atol=1e-9)
+    (root / "train").mkdir()
+    H, W = 4, 16
+    for fid in range(first, last + 1):
+        view = np.zeros((H, W, 3))
+        view[:, :, 1], view[:, :, 2] = 0.5, 10.0 + (fid - first)
+        np.save(root / "train" / f"{fid:010d}.npy", view)
+    paths = preprocess.write_transforms(str(root), seq, poses)
+    assert [os.path.basename(p) for p in paths] == [f"transforms_4950_{s}.json" for s in ("train", "val", "test")]
+    doc = json.load(open(paths[1]))
+    assert doc["num_frames"] == 51 and doc["num_frames_split"] == 4 and [f["frame_id"] for f in doc["frames"]] == [4960, 4970, 4980, 4990]
+    assert json.load(open(paths[0]))["num_frames_split"] == 47 and doc["h_lidar"] == H and doc["w_lidar"] == W
+    ds = KITTI360Dataset(device="cpu", split="val", root_path=str(root), sequence_id=seq, preload=False, scale=0.01,
+                         offset=[1000.0, 3700.0, 115.0], fp16=False, fov_lidar=[2.0, 26.9])
+    assert len(ds) == 4 and ds.H_lidar == H and ds.W_lidar == W
+    np.testing.assert_allclose(ds.times.numpy().reshape(-1), [0.2, 0.4, 0.6, 0.8], rtol=1e-6)
+    np.testing.assert_allclose(ds.images_lidar[0, 0, 0].numpy(), [1.0, 0.5, 20.0 * 0.01], rtol=1e-6)
+    np.testing.assert_allclose(ds.poses_lidar[0, :3, 3].numpy(), (poses[10, :3, 3] - np.array([1000.0, 3700.0, 115.0])) * 0.01, atol=1e-6)
