@@ -1,26 +1,47 @@
 """bench.py -- training rays/s of the LiDAR4D ray-rendering hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2-like ...]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c2|c5 ...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = forward + backward + Adam of ``render(staged=False, perturb=True)`` with the reference's three primary
-losses (runner.py:179-213) on one batch of synthetic KITTI-360-shaped rays (64 x 1024 panorama, T = 768 samples per
-ray).  Default workload = BASELINE.json configs[2] ("C3": full 4D field -- hash + hex-planes + flow --
-16,384 rays/batch/GPU), whose 8-GPU weak-scaled form is configs[3] (131,072 rays/step), the configuration the
-headline ">= 10 M training rays/s on 8 x MI355X" is quoted on.  Rank r draws its own ray indices (all ranks step through the same
-frame sequence, so that the per-step work is the same everywhere); the flat gradient buffer is SUM-all-reduced over RCCL
-once per step.  Inputs are resident in HBM before the timed region.
+``--gpus N`` (N > 1) without a torchrun environment re-launches this script under torch.distributed.run with N ranks on
+127.0.0.1 (and fails loudly if the node has fewer than N GPUs); it never reports fewer GPUs than it was asked for.
 
-The JSON line also carries `roofline` (dominant kernel: algorithmic bytes / measured launch time vs the 8 TB/s HBM
-peak; per-kernel times come from HIP events recorded around every launch on the launch stream in a separate
-profiling pass after the timed region) and, on rank 0 at N = 1, `cpu_baseline` (the oracle, i.e. a port, timed on
-the host cores over a bounded ray sample).
+A step = the reference's training step (model/runner.py:166-253,474-551): ``render(staged=False, perturb=True)`` of one
+batch of synthetic KITTI-360-shaped rays (64 x 1024 panorama, T = 768 samples per ray), the three primary losses (L1 depth,
+MSE ray-drop, MSE intensity: runner.py:179-213) + the ray-chamfer term (runner.py:215-220, always on in the reference)
++ the scene-flow consistency loss (runner.py:222-253, ``--flow_loss`` defaults to True there), backward, GradScaler
+check / skip / update, Adam.  The parameter EMA is updated once per epoch (runner.py:534-535).  ``--no-chamfer --no-flow``
+gives the bare three-loss step; the default run also times it and reports it under ``variants``.
+Default workload = BASELINE.json configs[2] ("C3": full 4D field, 16,384 rays/batch/GPU), whose 8-GPU weak-scaled form is
+configs[3] (131,072 rays/step), the configuration the headline ">= 10 M training rays/s on 8 x MI355X" is quoted on.
+Rank r draws its own ray indices (all ranks step through the same frame sequence, so that the per-step work is the same
+everywhere); the flat gradient buffer is SUM-all-reduced over RCCL once per step.  Inputs are resident in HBM before the
+timed region.
+
+Besides the contract's fields the JSON line carries (rank 0, N = 1):
+  roofline          the dominant single kernel against ITS roof (see ``kernel_models``): HBM-streaming kernels against the
+                    8 TB/s HBM peak with their compulsory bytes; gather kernels against the 34.5 TB/s L2 peak with the
+                    table-entry bytes the algorithm touches (the tables, 97 MB, sit in L2 / Infinity Cache, so dividing those
+                    bytes by the HBM peak is meaningless) plus their compulsory HBM rate; the LDS kernel against the LDS peak.
+                    Every duration is measured live: HIP events around every kernel launch on the launch stream
+                    (csrc/common.h L4D_LAUNCH), in a separate pass after the timed region.
+  roofline_kernels  the same for every modelled kernel, sorted by time per step
+  hash_encoder      the hash lookup alone (north_star: ">= 40 % HBM roofline for the hash encoder"): the static 3-D grid at
+                    L = 8 and L = 16 on the batch's ray-ordered samples, 64 B/level/sample of table entries / time / 8 TB/s
+  mfma              algorithmic TFLOP/s of the MLP kernels against the 2.5 PFLOP/s dense fp16 peak (+ the PMC busy figure
+                    from profiles/ when a rocprofv3 --pmc pass of this build has been committed)
+  parity            depth / intensity / ray-drop error and mask-set equality against the oracle on 64 rays (default model)
+  variants          the three-loss step and a trained-state measurement (after --trained-steps further steps)
+  cpu_baseline      the oracle (a port) timed on the host cores over a bounded ray sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -29,7 +50,11 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0     # HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
+L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth, 8 XCDs
+LDS_PEAK_GBS = 150000.0   # ds_read_b64/b128 streaming, 256 CUs
+MFMA_F16_PEAK_TFLOPS = 2500.0
 
 WORKLOADS = {
     # name: (model kwargs, rays per GPU per step, description)
@@ -47,33 +72,71 @@ WORKLOADS = {
 INFERENCE = {"c5"}
 
 
-def algorithmic_bytes_per_sample(model):
-    """SURVEY.md 8(d) per-sample table-entry traffic of the fused kernels at this model's configuration.
-    fwd: fp16 hash entries (8 B at F=4), fp32 channel-last plane texels (32 B);
-    bwd: plane values are re-read for the product rule, gradients are fp32 read-modify-write (x2)."""
+def kernel_models(model, P, M):
+    """Per-kernel roof and byte model: {kernel name: dict(bound, bytes, [alg], note)} per LAUNCH at P sample points and M
+    attribute rows (samples with weight > 1e-4).  ``bytes`` is what the roof is charged with:
+      bound "hbm": COMPULSORY HBM bytes (inputs read once + outputs written once; tables excluded: they are cache resident)
+      bound "l2" : table-entry bytes the algorithm gathers (SURVEY 8d: fp16 hash entries 8 / 16 B, fp32 plane texels 32 B);
+                   ``hbm`` then gives the kernel's compulsory HBM bytes for the secondary figure
+      bound "lds": table-entry bytes served from LDS
+    Kernel names are the launch sites' (csrc), the same rocprofv3's kernel trace shows."""
     he, pe = model.hash_encoder, model.planes_encoder
     L = he.hash_static.meta.n_levels
     nS = pe.layout.n_scales
-    static = L * 8 * 8
-    dyn_eval = 3 * 2 * L * 4 * 8
-    planes_full = 6 * nS * 4 * 32
-    planes_dyn = 3 * nS * 4 * 32
-    flow = model.flow_net.n_levels * 8 * 16
-    fwd = static + 3 * dyn_eval + planes_full + 2 * planes_dyn
-    bwd = (planes_full + 2 * planes_dyn) + 2 * ((L * 8 * 16) + (3 * 2 * L * 4 * 16) + (planes_full + 2 * planes_dyn))
-    return {"l4d_density_encode_fwd": fwd, "l4d_density_encode_bwd": bwd, "l4d_hashgrid_t_fwd": flow,
-            "l4d_hashgrid_t_bwd": 2 * model.flow_net.n_levels * 8 * 32, "hash_static_fwd_only": static}
+    in_pad = model.sigma_net.in_pad
+    a_pad = model.intensity_net.in_pad
+    n_dyn = 3 * L
+    Lf = model.flow_net.n_levels
+    nh_s, nh_a = model.sigma_net.n_hidden_layers, model.intensity_net.n_hidden_layers
+    planes_full, planes_dyn = 6 * nS * 4 * 32, 3 * nS * 4 * 32
+    enc_alg = L * 8 * 8 + 3 * (2 * L * 4 * 8) + planes_full + 2 * planes_dyn   # static + xy stack x 3 frames + planes
+    lds_alg = 2 * 3 * (2 * L * 4 * 8)                                            # xz, yz stacks x 3 frames
+    X = 2 * in_pad
+    m = {}
+    m["density_encode_fwd_kernel<true>"] = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P,
+                                                note="planes + static hash + xy dynamic hash gathers; row staged in LDS, written once")
+    m["density_encode_fwd_kernel<false>"] = dict(bound="l2", bytes=(enc_alg + lds_alg) * P, hbm=(16 + 32 + X) * P, note="all gathers direct")
+    m["dynhash_fwd_lds_kernel"] = dict(bound="lds", bytes=lds_alg * P, hbm=(2 * L * (16 + 16) + 2 * 2 * L) * P,
+                                       note="xz / yz HashGridT stacks from LDS-resident slice tables; one streaming pass of xt / flow per (plane, level)")
+    m[f"hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="l2", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, note="flow grid + interpT")
+    for name, pad, nh, rows in ((f"<{in_pad // 16}, {nh_s}>", in_pad, nh_s, P), (f"<{a_pad // 16}, {nh_a}>", a_pad, nh_a, M),
+                                (f"<1, {model.flow_net.n_hidden}>", 16, model.flow_net.n_hidden, P)):
+        fl = 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
+        m["mlp_fwd_kernel" + name] = dict(bound="hbm", bytes=(2 * pad + 32 + nh * 128) * rows, flops=fl * rows, note="x + y + saved activations")
+        it = pad // 16
+        m[f"mlp_bwd_kernel<{it}, {nh}, 0, {it}, true>"] = dict(bound="hbm", bytes=(2 * pad + nh * 128 + 32 + 2 * pad) * rows, flops=2 * fl * rows,
+                                                             note="x + activations + dy read, dx written (algorithmic flops: dX + dW)")
+    rec = 8 * 12  # one 12-byte record per corner (upper bound: equal-cell runs along a ray are merged first)
+    m["bin_pass1_kernel<3, 4>"] = dict(bound="hbm", bytes=(16 + 8 * L + L * rec) * P, note="static grid: xt + dX columns read, sorted records written (upper bound)")
+    m["bin_pass2_kernel<3, 4>"] = dict(bound="hbm", bytes=L * rec * P, note="static grid: records read, segments reduced in LDS")
+    rec2 = 8 * 8
+    m["bin_pass1_kernel<3, 2>"] = dict(bound="hbm", bytes=(16 + 4 * Lf + Lf * rec2) * P, note="flow grid records")
+    m["bin_pass2_kernel<3, 2>"] = dict(bound="hbm", bytes=Lf * rec2 * P, note="flow grid records")
+    m["field_bwd_prep_kernel"] = dict(bound="hbm", bytes=(16 + X + 3 * nS * 16 + 2 * n_dyn) * P, note="dX row read, plane factors + transposed dyn gradient written")
+    m["planes_dyn_lds_kernel"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
+    m["planes_static_lds_kernel"] = dict(bound="hbm", bytes=(3 * nS * 16 + 3 * nS * 8) * P, note="plane-major factors read once per (scale, plane)")
+    m["dynhash_lds_kernel"] = dict(bound="hbm", bytes=(2 * n_dyn + n_dyn * 8) * P, note="transposed gradient + 2 coordinates per (plane, level) pass")
+    m["composite_fwd_kernel"] = dict(bound="hbm", bytes=(4 + 4 + 4 + 4) * P, note="sigma, z in; weights, index out")
+    m["composite_bwd_kernel"] = dict(bound="hbm", bytes=(4 * 3 + 8 + 4 + 8) * P, note="")
+    m["sample_rays_xt_kernel"] = dict(bound="hbm", bytes=(4 + 4 + 16) * P, note="noise in; z, xt out")
+    m["attr_gather_kernel"] = dict(bound="hbm", bytes=(4 + 32 + 2 * a_pad) * M, note="")
+    n_par = model._store.numel
+    m["adam_ranges_kernel"] = dict(bound="hbm", bytes=30 * n_par, note="p, g, m, v read; p, m, v, fp16 copy written (gated-off time slices are skipped: upper bound)")
+    return m
 
 
 CPU_BASELINE_CODE = r"""
 import json, os, sys, time
+import numpy as np
 import torch
 sys.path.insert(0, {root!r})
 from oracle import fields_ref, tcnn_ref
+from oracle.detparams import det_uniform, fill_model
+from oracle.make_golden import test_rays
 tcnn_ref.set_precision("tcnn")
 cores = min(os.cpu_count() or 1, 32)          # oversubscribing a big host with tiny torch ops only thrashes
 torch.set_num_threads(cores)
-scale, num_frames, budget = {scale!r}, {num_frames!r}, {budget!r}
+scale, num_frames, budget, out_path = {scale!r}, {num_frames!r}, {budget!r}, {out_path!r}
 m = fields_ref.LiDAR4D(near_lidar=1.0 * scale, far_lidar=81.0 * scale, num_frames=num_frames)
 g = torch.Generator().manual_seed(0)
 rd = torch.nn.functional.normalize(torch.randn(1, 1024, 3, generator=g), dim=-1)
@@ -88,17 +151,26 @@ step(4)                                        # warm-up (allocator, thread pool
 probe = step(8)
 n = int(max(8, min(1024, budget / max(probe / 8, 1e-6))))
 dt = step(n)
-print(json.dumps(dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
+res = dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
       sample="oracle (torch CPU restatement of the reference path, tiny-cuda-nn rounding points) forward+backward of "
-             "render() on %d rays x 768 samples, full 4D default config, no optimizer step; %.1f s on %d threads" % (n, dt, cores))))
+             "render() on %d rays x 768 samples, full 4D default config, no optimizer step; %.1f s on %d threads" % (n, dt, cores))
+# parity reference (checker role): the default model with deterministic, visible parameters, 64 rays x 768 samples, frame 25
+m.density_scale = 30.0
+fill_model(m, seed=3)
+pro, prd = test_rays(64, 42)
+noise = det_uniform((64, 768), "benchpar", 0.0, 1.0)
+with torch.no_grad():
+    o = m.render(pro, prd, torch.tensor([[25 / 50]]), num_steps=768, perturb=True, noise=noise)
+np.savez(out_path, depth=o["depth_lidar"].numpy(), image=o["image_lidar"].numpy(), mask=o["mask"].numpy(),
+         weights=o["weights"].numpy())
+print(json.dumps(res))
 """
 
 
-def cpu_baseline(num_frames, scale, budget_s=20.0, timeout_s=240):
+def cpu_baseline(num_frames, scale, out_path, budget_s=20.0, timeout_s=300):
     """Oracle (CPU restatement = a port of the reference path) fwd+bwd on the host cores, in a subprocess with a hard
-    timeout so the bench line is always produced."""
-    import subprocess
-    code = CPU_BASELINE_CODE.format(root=ROOT, scale=scale, num_frames=num_frames, budget=budget_s)
+    timeout so the bench line is always produced; the same subprocess writes the parity reference outputs."""
+    code = CPU_BASELINE_CODE.format(root=ROOT, scale=scale, num_frames=num_frames, budget=budget_s, out_path=out_path)
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
@@ -108,6 +180,33 @@ def cpu_baseline(num_frames, scale, budget_s=20.0, timeout_s=240):
         return {"value": None, "unit": "rays/s", "cores": None, "kind": "port", "sample": "cpu baseline failed: " + r.stderr[-300:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "rays/s", "cores": None, "kind": "port", "sample": f"cpu baseline timed out after {timeout_s} s"}
+
+
+def parity_against(ref_path, dev, scale):
+    """HIP path vs the oracle outputs written by the cpu_baseline subprocess: same model / fill / rays / noise."""
+    import numpy as np
+    from lidar4d_amd import LiDAR4D
+    from oracle.detparams import det_uniform, fill_model          # deterministic fills + rays only (numpy); the oracle's
+    from oracle.make_golden import test_rays                        # model code ran in the cpu_baseline subprocess
+    ref = np.load(ref_path)
+    m = fill_model(LiDAR4D(near_lidar=1.0 * scale, far_lidar=81.0 * scale, num_frames=51, density_scale=30.0), seed=3).to(dev)
+    pro, prd = test_rays(64, 42)
+    noise = det_uniform((64, 768), "benchpar", 0.0, 1.0)
+    with torch.no_grad():
+        o = m.render(pro.to(dev), prd.to(dev), torch.tensor([[25 / 50]], device=dev), num_steps=768, perturb=True, noise=noise.to(dev))
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    depth, image = o["depth_lidar"].cpu().numpy(), o["image_lidar"].cpu().numpy()
+    cnt = int(o["mask_count"])
+    got = set(o["mask_idx"][:cnt].tolist())
+    want = set(np.nonzero(ref["mask"].reshape(-1))[0].tolist())
+    w = ref["weights"].reshape(-1)
+    off_threshold = [i for i in got ^ want if abs(float(w[i]) - 1e-4) >= 1e-7]
+    return {"rays": 64, "samples_per_ray": 768, "vs": "oracle/fields_ref (tiny-cuda-nn rounding points), default C3 model, frame 25",
+            "depth_rel_err": rel(depth, ref["depth"]), "raydrop_rel_err": rel(image[..., 0], ref["image"][..., 0]),
+            "intensity_rel_err": rel(image[..., 1], ref["image"][..., 1]),
+            "depth_rmse_vs_ref": float(np.sqrt(np.mean((depth - ref["depth"]) ** 2))),
+            "mask_size": len(want), "mask_symmetric_difference": len(got ^ want),
+            "mask_equal_outside_threshold_ulp": len(off_threshold) == 0, "tolerance": 1e-3}
 
 
 class _QuietStdout:
@@ -128,33 +227,69 @@ class _QuietStdout:
         return False
 
 
-def main():
-    with _QuietStdout():
-        line = _run()
-    if line is not None:
-        print(json.dumps(line), flush=True)
-
-
-def _run():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chamfer", action="store_true", help="add the reference's ray chamfer loss term (runner.py:215-220) to the step")
-    ap.add_argument("--flow", action="store_true", help="add the reference's scene-flow consistency loss (runner.py:222-253, opt.flow_loss)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity check that uses its reference outputs")
+    ap.add_argument("--no-chamfer", action="store_true", help="drop the ray chamfer loss term (runner.py:215-220; always on in the reference)")
+    ap.add_argument("--no-flow", action="store_true", help="drop the scene-flow consistency loss (runner.py:222-253; the reference's default is on)")
+    ap.add_argument("--chamfer", action="store_true", help=argparse.SUPPRESS)  # accepted for older command lines: now the default
+    ap.add_argument("--flow", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sort-rays", action="store_true", help="serve the random pixels of a batch in 8x8-pixel-block order (locality experiment; measured slower)")
     ap.add_argument("--urf", action="store_true", help="add the line-of-sight loss (runner.py:255-276, opt.urf_loss)")
-    ap.add_argument("--no-ema", action="store_true", help="skip the parameter EMA update the reference does after every step (--ema_decay 0.95 by default there)")
-    ap.add_argument("--profile-steps", type=int, default=2)
-    args = ap.parse_args()
+    ap.add_argument("--no-ema", action="store_true", help="no parameter EMA (the reference's default keeps one, --ema_decay 0.95, updated once per epoch)")
+    ap.add_argument("--profile-steps", type=int, default=2, help="steps of the per-kernel timing pass (0: no roofline block)")
+    ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of each secondary measurement (0: skip them)")
+    ap.add_argument("--trained-steps", type=int, default=200, help="further training steps before the trained-state measurement")
+    return ap.parse_args()
 
+
+def relaunch_distributed(args):
+    """--gpus N > 1 outside a torchrun environment: run N ranks of this script on this node."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but this node exposes {n_dev} GPU(s); refusing to report a "
+                         f"smaller run under that label")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env)
+    if r.returncode != 0:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank launch failed with exit code {r.returncode}")
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_distributed(args)  # rank 0 of the child job prints the JSON line on our stdout
+        return
+    with _QuietStdout():
+        line = _run(args)
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+def timed(step, n, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def _run(args):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # L4D_FORCE_DIST=1: take the multi-rank code path (RCCL init, barrier, gradient all-reduce) even with one rank --
@@ -164,7 +299,7 @@ def _run():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    from lidar4d_amd import LiDAR4D, _lib
+    from lidar4d_amd import LiDAR4D, _lib, ops
     from lidar4d_amd.data import KITTI360_SCALE, SyntheticKitti360
     from lidar4d_amd.trainer import Trainer
 
@@ -174,7 +309,9 @@ def _run():
     inference = args.workload in INFERENCE
     data = SyntheticKitti360(dev, W=2048 if inference else 1024, num_rays=n_rays, seed=1000 + rank, sort_pixels=args.sort_rays,
                              frame_seed=1000)  # every rank: its own rays, the same frame sequence (equal work per step)
-    trainer = Trainer(model, data, chamfer=args.chamfer, flow=args.flow, urf=args.urf, ema_decay=None if args.no_ema else 0.95)
+    use_chamfer, use_flow = not args.no_chamfer, not args.no_flow
+    trainer = Trainer(model, data, chamfer=use_chamfer and not inference, flow=use_flow and not inference, urf=args.urf,
+                      ema_decay=None if args.no_ema else 0.95)
     if inference:
         from lidar4d_amd.data import KITTI360_FOV
         from lidar4d_amd.metrics import PointsMeter
@@ -199,62 +336,122 @@ def _run():
 
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(step, args.steps, barrier)
     if world > 1 or force_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
+    scale_after = trainer.scaler.get_scale() if (not inference and trainer.scaler is not None) else None
 
-    # ---- per-kernel timing pass (HIP events on the launch stream), outside the timed region ----
-    roofline = None
-    kernels = {}
+    # ---- per-kernel timing pass (HIP events around every kernel launch, on the launch stream), outside the timed region ----
+    roofline, roofline_kernels, mfma, per_step = None, None, None, {}
     if args.profile_steps > 0:
         # every rank runs the extra steps (they contain the gradient all-reduce); only rank 0 records events
         if rank == 0:
-            _lib.PROFILE = []
+            _lib.profile_start()
         for _ in range(args.profile_steps):
             step()
         barrier()
     if rank == 0 and args.profile_steps > 0:
-        for name, s, e in _lib.PROFILE:
+        kernels = {}
+        for name, ms in _lib.profile_stop():
             k = kernels.setdefault(name, [0, 0.0])
             k[0] += 1
-            k[1] += s.elapsed_time(e)
-        _lib.PROFILE = None
+            k[1] += ms
         per_step = {k: v[1] / args.profile_steps for k, v in kernels.items()}
-        # entry points that launch several kernels (the adjoints) are aggregates; the roofline is quoted for the
-        # dominant SINGLE kernel, whose name rocprofv3 reports the same way (profiles/)
-        aggregates = {"l4d_density_encode_bwd", "l4d_hashgrid_t_bwd", "l4d_planes_relayout"}
-        dominant = max((k for k in per_step if k not in aggregates), key=per_step.get)
-        launches = kernels[dominant][0] / args.profile_steps
-        avg_ms = kernels[dominant][1] / kernels[dominant][0]
         P = min(n_rays, 4096) * 768 if inference else n_rays * 768  # staged inference launches per 4096-ray chunk
-        bps = algorithmic_bytes_per_sample(model)
-        alg = bps.get(dominant)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and args.workload == "c3":  # PMC passes were collected on the default workload
-            traffic = json.load(open(tpath)).get(dominant)
-        if alg is not None:
-            achieved = alg * P / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": alg * P, "avg_launch_ms": round(avg_ms, 4),
-                        "launches_per_step": launches,
-                        "rocprof_kernels": "dynhash_fwd_lds_kernel + density_encode_fwd_kernel<true>" if dominant == "l4d_density_encode_fwd" else dominant,
-                        "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
-        else:
-            roofline = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": None, "traffic": traffic,
-                        "kernel_ms_per_step": {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
+        with torch.no_grad():  # attribute rows = samples with weight > 1e-4 in the current state (one read-back, outside timing)
+            b = data.batch_for(25) if not inference else None
+            M = P if inference else int(model.render(b["rays_o_lidar"], b["rays_d_lidar"], b["time"], staged=False, perturb=True, num_steps=768)["mask_count"])
+        models = kernel_models(model, P, M)
+        peaks = {"hbm": HBM_PEAK_GBS, "l2": L2_PEAK_GBS, "lds": LDS_PEAK_GBS}
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_r02.json")
+        traffic = json.load(open(tpath)) if os.path.exists(tpath) and args.workload == "c3" else {}
+        rows, mf = [], []
+        for name, (count, total) in kernels.items():
+            avg_ms = total / count
+            row = {"kernel": name, "ms_per_step": round(per_step[name], 3), "launches_per_step": count / args.profile_steps,
+                   "avg_launch_ms": round(avg_ms, 4)}
+            mod = models.get(name)
+            if mod is not None:
+                ach = mod["bytes"] / (avg_ms * 1e-3) / 1e9
+                row.update(bound=mod["bound"], bytes_per_launch=mod["bytes"], achieved=round(ach, 1), peak=peaks[mod["bound"]], unit="GB/s",
+                           frac=round(ach / peaks[mod["bound"]], 4), traffic=traffic.get(name), note=mod["note"])
+                if "hbm" in mod:
+                    row["compulsory_hbm_GBps"] = round(mod["hbm"] / (avg_ms * 1e-3) / 1e9, 1)
+                    row["compulsory_hbm_frac"] = round(row["compulsory_hbm_GBps"] / HBM_PEAK_GBS, 4)
+                if "flops" in mod:
+                    tf = mod["flops"] / (avg_ms * 1e-3) / 1e12
+                    mf.append({"kernel": name, "algorithmic_tflops": round(tf, 1), "frac_of_dense_f16_peak": round(tf / MFMA_F16_PEAK_TFLOPS, 4)})
+            rows.append(row)
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        roofline_kernels = rows
+        modelled = [r for r in rows if "bound" in r]
+        if modelled:
+            d = modelled[0]  # the dominant modelled kernel
+            roofline = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": d["peak"], "unit": "GB/s",
+                        "frac": d["frac"], "traffic": d["traffic"], "bytes_per_launch": d["bytes_per_launch"],
+                        "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
+                        "bytes_are": {"hbm": "compulsory HBM bytes", "l2": "table-entry bytes gathered through L1/L2 (tables are cache resident)",
+                                      "lds": "table-entry bytes served from LDS"}[d["bound"]],
+                        "compulsory_hbm_GBps": d.get("compulsory_hbm_GBps"), "compulsory_hbm_frac": d.get("compulsory_hbm_frac"),
+                        "samples_per_launch": P, "attribute_rows": M}
+        pmc_path = os.path.join(ROOT, "profiles", "r02_mfma_pmc.json")
+        mfma = {"kernels": mf, "peak_tflops": MFMA_F16_PEAK_TFLOPS,
+                "pmc": json.load(open(pmc_path)) if os.path.exists(pmc_path) else None,
+                "note": "MLPs are 18-55 kFLOP per sample (SURVEY 8d): the matrix cores are a few % busy at HBM-streaming speed; the binding roof of these kernels is HBM"}
 
+    # ---- secondary measurements (single GPU): hash encoder alone, three-loss step, trained state ----
+    hash_enc, variants = None, None
+    if rank == 0 and world == 1 and not inference and args.variant_steps > 0:
+        import numpy as np
+        from lidar4d_amd.gridmeta import GridMeta
+        b = data.batch_for(25)
+        lin = torch.linspace(0.0, 1.0, 768, device=dev)
+        noise = torch.rand(n_rays, 768, device=dev)
+        _, xt = ops.sample_rays_xt(b["rays_o_lidar"].view(-1, 3).contiguous(), b["rays_d_lidar"].view(-1, 3).contiguous(), lin, noise,
+                                   b["time"].view(-1), float(np.float32(model.near_lidar)), float(np.float32(model.far_lidar)), model.bound)
+        hash_enc = {"what": "static 3-D hash grid forward alone (l4d_hashgrid_fwd), ray-ordered samples of one batch, F = 4, 2^19-entry tables, fp16",
+                    "samples": xt.shape[0], "peak": HBM_PEAK_GBS, "unit": "GB/s", "target_frac": 0.40}
+        for Lh in (8, 16):
+            meta = GridMeta(3, Lh, 4, 19, 512, np.exp2(np.log2(32768 / 512) / (Lh - 1)))
+            table = ((torch.rand(meta.n_params, device=dev) - 0.5)).half()
+            out = ops.hashgrid_fwd(meta, xt, (0, 1, 2), table)
+            torch.cuda.synchronize()
+            _lib.profile_start()
+            for _ in range(5):
+                ops.hashgrid_fwd(meta, xt, (0, 1, 2), table, out=out)
+            recs = _lib.profile_stop()
+            ms = sum(v for _, v in recs) / 5
+            gbs = Lh * 64 * xt.shape[0] / (ms * 1e-3) / 1e9
+            hash_enc[f"L{Lh}"] = {"ms": round(ms, 4), "algorithmic_bytes_per_sample": Lh * 64, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            del table, out
+        variants = {}
+        if use_chamfer or use_flow:
+            trainer.chamfer = trainer.flow = False
+            for _ in range(2):
+                step()
+            dtv = timed(step, args.variant_steps, barrier)
+            variants["three_loss_step"] = {"step": "L1 depth + MSE raydrop + MSE intensity only (no ray chamfer, no scene-flow loss)", "steps": args.variant_steps,
+                                           "ms_per_step": dtv / args.variant_steps * 1e3, "rays_per_s": n_rays * args.variant_steps / dtv}
+            trainer.chamfer, trainer.flow = use_chamfer, use_flow
+        if args.trained_steps > 0:
+            for _ in range(args.trained_steps):
+                step()
+            dtv = timed(step, args.variant_steps, barrier)
+            with torch.no_grad():
+                bb = data.batch_for(25)
+                frac = float(model.render(bb["rays_o_lidar"], bb["rays_d_lidar"], bb["time"], staged=False, perturb=True, num_steps=768)["mask_count"]) / (n_rays * 768)
+            variants["trained_state"] = {"what": f"the headline step after {args.warmup + args.steps + args.profile_steps + args.trained_steps + 2 * args.variant_steps} training "
+                                                 "steps on the synthetic scene: fewer samples pass the weights > 1e-4 mask (attribute networks run on those only), flow gradients are no longer tiny",
+                                         "steps": args.variant_steps, "ms_per_step": dtv / args.variant_steps * 1e3, "rays_per_s": n_rays * args.variant_steps / dtv,
+                                         "mask_fraction": round(frac, 4), "loss_scale": trainer.scaler.get_scale() if trainer.scaler is not None else None}
+
+    line = None
     if rank == 0:
         total_rays = n_rays * world * args.steps
+        losses = "L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if use_chamfer else "") + \
+                 (" + scene-flow consistency" if use_flow else "") + (" + line-of-sight" if args.urf else "")
         line = {
             "metric": "inference rays/sec (64x2048 novel-view frame)" if inference else "training rays/sec (64x1024 LiDAR panorama)",
             "value": total_rays / dt,
@@ -272,17 +469,30 @@ def _run():
                        "global_rays_per_step": n_rays * world,
                        "parallelism": f"frame-sharded x{world}, no collective" if inference else f"ray-sharded dp{world}, one RCCL gradient all-reduce per step in two phases, overlapped with the tail of the backward pass",
                        "step": "no_grad render(staged=True, max_ray_batch=4096) + U-Net + pano_to_lidar + chamfer/F-score" if inference else
-                               "forward + backward + Adam" + ("" if args.no_ema else " + parameter EMA") + ", losses L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if args.chamfer else "") + (" + scene-flow consistency" if args.flow else "") + (" + line-of-sight" if args.urf else "") + ("" if args.chamfer or args.flow or args.urf else " (no chamfer/flow loss)")},
+                               f"the reference's training step (runner.py:166-253,474-551): forward + backward + GradScaler check/skip/update + Adam; losses {losses}; "
+                               + ("no parameter EMA" if args.no_ema else "parameter EMA once per epoch of 51 steps (runner.py:534-535)"),
+                       "state": "random init (tiny-cuda-nn default U(-1e-4, 1e-4) tables): every sample passes the weights > 1e-4 mask, the attribute networks run on all of them",
+                       "loss_scale_after_timed_region": scale_after},
             "roofline": roofline,
+            "roofline_kernels": roofline_kernels,
+            "mfma": mfma,
+            "hash_encoder": hash_enc,
+            "variants": variants,
         }
         if inference:
             line["eval"] = {"chamfer_distance_m2, f_score@0.05": [float(v) for v in meter.measure()], "frames": meter.N,
                             "note": "random-init field vs synthetic ground truth: exercises the eval path, not a quality claim"}
         if world == 1 and not args.no_cpu_baseline and not inference:
-            line["cpu_baseline"] = cpu_baseline(51, KITTI360_SCALE)
+            with tempfile.TemporaryDirectory() as td:
+                ref_path = os.path.join(td, "parity_ref.npz")
+                line["cpu_baseline"] = cpu_baseline(51, KITTI360_SCALE, ref_path)
+                try:
+                    line["parity"] = parity_against(ref_path, dev, KITTI360_SCALE) if os.path.exists(ref_path) else None
+                except Exception as e:  # the bench line must still be produced
+                    line["parity"] = {"error": repr(e)[:300]}
     if world > 1 or force_dist:
         dist.destroy_process_group()
-    return line if rank == 0 else None
+    return line
 
 
 if __name__ == "__main__":

@@ -47,6 +47,14 @@ typedef struct {
 int l4d_version(void);
 const char* l4d_last_error(void);
 
+/* Per-kernel timing for benchmarks: while enabled, every kernel the library launches is bracketed by a pair of HIP events
+ * on its launch stream.  enable(1) clears earlier records and starts recording, enable(0) stops and clears;
+ * l4d_profile_get(i, &name, &ms) waits for record i and returns the kernel's name (as at the launch site, template
+ * arguments included) and duration.  Single host thread. */
+int l4d_profile_enable(int32_t on);
+int l4d_profile_count(void);
+int l4d_profile_get(int32_t i, const char** name /*host out*/, float* ms /*host out*/);
+
 /* ---- tcnn.Encoding(HashGrid) : model/hash_field.py:107-117, model/flow_field.py:67-77 -------
  * x        [P, x_stride] fp32; the grid's n_dims coordinates are columns cols[0..n_dims-1] (host)
  * table    [n_entries, F] fp16 (level-major)
@@ -248,6 +256,28 @@ int l4d_cast_f32_to_f16(const float* src, void* dst, int64_t n, void* stream);
 int l4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16 /*or null*/,
                   int64_t n, float lr, float beta1, float beta2, float eps, float bias_c1, float bias_c2,
                   float grad_scale, void* stream);
+/* The same update over n_ranges (<= 40) ranges [off[r], off[r] + len[r]) of the flat arenas in ONE launch, with the
+ * optimiser's bookkeeping on the device so that the step never waits on the host (torch.optim.Adam keeps a step count per
+ * parameter tensor and skips tensors whose .grad is None; torch.cuda.amp.GradScaler skips the whole step on a non-finite
+ * gradient: runner.py:506-508).  off / len / lr / gate_idx: host arrays; off[r] a multiple of 4 elements.
+ *   gates   device fp32 array or null; range r is updated only if gate_idx[r] < 0 or gates[gate_idx[r]] != 0
+ *   scaler  device fp32[4] or null: [0] loss scale, [1] growth tracker, [2] != 0 -> skip every range, [3] 1 / loss scale
+ *           (multiplied into the gradient together with grad_scale)
+ *   steps   device int32[n_ranges]: per-range step counts, incremented here for the ranges that are updated; the bias
+ *           corrections 1 - beta^t are derived from them on the device. */
+int l4d_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16 /*or null*/,
+                         int32_t n_ranges, const int64_t* off /*host*/, const int64_t* len /*host*/, const float* lr /*host*/,
+                         const int32_t* gate_idx /*host, or null*/, const float* gates, const float* scaler, int32_t* steps,
+                         float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* GradScaler pieces (torch.cuda.amp.GradScaler as the reference uses it, runner.py:102,506-508), device-resident state
+ * scaler_state fp32[4] as above.  check: sets state[2] = 1 if any of grad[0..n) is inf / nan (call after the gradient
+ * all-reduce, before the Adam step).  update: halve the scale after a non-finite step, multiply it by growth_factor after
+ * growth_interval consecutive clean steps, clear state[2], refresh state[3] (call after the Adam step). */
+int l4d_grad_nonfinite_check(const float* grad, int64_t n, float* scaler_state, void* stream);
+int l4d_scaler_update(float* scaler_state, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream);
+/* gates[i1] = gates[i2] = 1 for the pair of time slices HashGridT.forward blends at time tinfo[0] (hash_field.py:79-85):
+ * the slices whose tables receive a gradient in this step (tinfo: l4d_time_setup). */
+int l4d_mark_time_slices(const float* tinfo, int32_t n_slices, float* gates, void* stream);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,13 @@ SIGNATURES = {
     "l4d_lidar_to_pano": [P, I64, I32, I32, F64, F64, F32, P, P, P, P],
     "l4d_cast_f32_to_f16": [P, P, I64, P],
     "l4d_adam_step": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, F32, F32, P],
+    "l4d_adam_step_ranges": [P, P, P, P, P, I32, PI64, PI64, P, PI32, P, P, P, F32, F32, F32, F32, P],
+    "l4d_grad_nonfinite_check": [P, I64, P, P],
+    "l4d_scaler_update": [P, F32, F32, I32, P],
+    "l4d_mark_time_slices": [P, I32, P, P],
+    "l4d_profile_enable": [I32],
+    "l4d_profile_count": [],
+    "l4d_profile_get": [I32, P, P],
 }
 
 _lib = None
@@ -131,16 +138,23 @@ def check(status, name):
         raise HipExtensionError(f"{name} failed: {lib().l4d_last_error().decode()}")
 
 
-PROFILE = None  # set to a list to record (name, start_event, end_event) around every launch (bench.py)
-
-
 def call(name, *args):
-    if PROFILE is None:
-        check(getattr(lib(), name)(*args), name)
-        return
-    import torch
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
     check(getattr(lib(), name)(*args), name)
-    e.record()
-    PROFILE.append((name, s, e))
+
+
+def profile_start():
+    """Per-kernel HIP-event timing inside the library (csrc/common.h L4D_LAUNCH): from now on every kernel launch is
+    bracketed by events on its launch stream.  bench.py's per-kernel pass."""
+    check(lib().l4d_profile_enable(1), "l4d_profile_enable")
+
+
+def profile_stop():
+    """-> [(kernel name, ms)] in launch order; switches the recording off."""
+    l = lib()
+    out = []
+    name, ms = C.c_char_p(), C.c_float()
+    for i in range(l.l4d_profile_count()):
+        check(l.l4d_profile_get(i, C.byref(name), C.byref(ms)), "l4d_profile_get")
+        out.append((name.value.decode().strip("()"), ms.value))
+    check(l.l4d_profile_enable(0), "l4d_profile_enable")
+    return out

@@ -21,6 +21,15 @@ class chamfer_3DFunction(Function):
         dist2 = torch.empty(batchsize, m, device=dev)
         idx1 = torch.empty(batchsize, n, dtype=torch.int32, device=dev)
         idx2 = torch.empty(batchsize, m, dtype=torch.int32, device=dev)
+        ctx.degenerate = n == 0 or m == 0
+        if ctx.degenerate:
+            # One cloud is empty (early in training every predicted ray-drop can be <= 0.5 -> no predicted points): the
+            # reference kernel has nothing to index; report "infinitely far" for the non-empty side so that the caller's
+            # metrics degrade (chamfer inf, F-score 0) instead of the evaluation aborting.  No gradient flows.
+            dist1.fill_(float("inf")), dist2.fill_(float("inf")), idx1.zero_(), idx2.zero_()
+            ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+            ctx.mark_non_differentiable(idx1, idx2)
+            return dist1, dist2, idx1, idx2
         ws = torch.empty(_lib.lib().l4d_chamfer_workspace(batchsize, n, m), dtype=torch.uint8, device=dev)
         ops.call("l4d_chamfer_fwd", ops._p(xyz1), ops._p(xyz2), batchsize, n, m, ops._p(dist1), ops._p(dist2), ops._p(idx1),
                  ops._p(idx2), ops._p(ws), ops._stream())
@@ -37,6 +46,8 @@ class chamfer_3DFunction(Function):
         graddist2 = graddist2.float().contiguous()
         gradxyz1 = torch.zeros_like(xyz1)
         gradxyz2 = torch.zeros_like(xyz2)
+        if ctx.degenerate:
+            return gradxyz1, gradxyz2
         ops.call("l4d_chamfer_bwd", ops._p(xyz1), ops._p(xyz2), b, n, m, ops._p(graddist1), ops._p(graddist2), ops._p(idx1),
                  ops._p(idx2), ops._p(gradxyz1), ops._p(gradxyz2), ops._stream())
         return gradxyz1, gradxyz2

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   for (int j = 0; j < NV; ++j) {
     gv[j] = valid ? h2f(g[p * g_stride + g_col + lvl * NV + j]) * pre_scale : 0.0f;
     any |= gv[j] != 0.0f;
-    amax = fmaxf(amax, fabsf(gv[j]));
+    amax = amax_nf(amax, gv[j]);
   }
   for (int i = threadIdx.x; i < NWAVES * BS_MAX_BINS; i += BS_THREADS) (&hist[0][0])[i] = 0;
   __syncthreads();
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
       stage[r * NW] = keys[k];
       half_t hv[2 * (NW - 1)];
 #pragma unroll
-      for (int j = 0; j < 2 * (NW - 1); ++j) hv[j] = j < NV ? f2h(fminf(fmaxf(vals[k][j], -65504.f), 65504.f)) : (half_t)0.0f;
+      for (int j = 0; j < 2 * (NW - 1); ++j) hv[j] = j < NV ? f2h_grad(vals[k][j]) : (half_t)0.0f;
 #pragma unroll
       for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = reinterpret_cast<uint32_t*>(hv)[q];
     }
@@ -209,6 +209,10 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   const float gmax = lvl_max[lvl];
   if (!(gmax > 0.0f)) return;
   const uint32_t lo = (uint32_t)b << shift;
+  if (nonfinite(gmax)) {  // overflowed upstream gradient (inf / nan in g): hand it on to the table gradient
+    if (threadIdx.x == 0) out[((size_t)desc.offset[lvl] + lo) * NV] = __builtin_nanf("");
+    return;
+  }
   const int n_el = (int)min(1u << shift, size - lo) * NV;
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) acc[i] = 0;
   __syncthreads();
@@ -280,10 +284,10 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   const int lds2 = (1 << pl.shift) * NV * 8;
 #define BS_LAUNCH(D, V)                                                                                                      \
   {                                                                                                                          \
-    hipLaunchKernelGGL((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
+    L4D_LAUNCH((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
                        g_col, pre_scale, pl.shift, (int64_t)pl.n_wg, offs, bins, lvl_max, out, out_scale);                                     \
     (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);              \
-    hipLaunchKernelGGL((bin_pass2_kernel<D, V>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
+    L4D_LAUNCH((bin_pass2_kernel<D, V>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
                        lvl_max, out, out_scale);                                                                            \
   }
   if (n_dims == 3 && NV == 4) BS_LAUNCH(3, 4)

@@ -98,17 +98,17 @@ extern "C" int l4d_chamfer_fwd(const float* xyz1, const float* xyz2, int32_t b, 
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_chamfer_fwd memset"); return (int)e; }
   {
     const int segs = seg_for(n, m, b), seg_len = (m + segs - 1) / segs;
-    hipLaunchKernelGGL(chamfer_nn_kernel, dim3((n + CH_THREADS - 1) / CH_THREADS, (m + seg_len - 1) / seg_len, b), dim3(CH_THREADS), 0,
+    L4D_LAUNCH(chamfer_nn_kernel, dim3((n + CH_THREADS - 1) / CH_THREADS, (m + seg_len - 1) / seg_len, b), dim3(CH_THREADS), 0,
                        stream, xyz1, n, xyz2, m, seg_len, best1);
   }
   {
     const int segs = seg_for(m, n, b), seg_len = (n + segs - 1) / segs;
-    hipLaunchKernelGGL(chamfer_nn_kernel, dim3((m + CH_THREADS - 1) / CH_THREADS, (n + seg_len - 1) / seg_len, b), dim3(CH_THREADS), 0,
+    L4D_LAUNCH(chamfer_nn_kernel, dim3((m + CH_THREADS - 1) / CH_THREADS, (n + seg_len - 1) / seg_len, b), dim3(CH_THREADS), 0,
                        stream, xyz2, m, xyz1, n, seg_len, best2);
   }
-  hipLaunchKernelGGL(chamfer_unpack_kernel, dim3((unsigned)ceil_div64((int64_t)b * n, 256)), dim3(256), 0, stream, best1, (int64_t)b * n,
+  L4D_LAUNCH(chamfer_unpack_kernel, dim3((unsigned)ceil_div64((int64_t)b * n, 256)), dim3(256), 0, stream, best1, (int64_t)b * n,
                      dist1, idx1);
-  hipLaunchKernelGGL(chamfer_unpack_kernel, dim3((unsigned)ceil_div64((int64_t)b * m, 256)), dim3(256), 0, stream, best2, (int64_t)b * m,
+  L4D_LAUNCH(chamfer_unpack_kernel, dim3((unsigned)ceil_div64((int64_t)b * m, 256)), dim3(256), 0, stream, best2, (int64_t)b * m,
                      dist2, idx2);
   L4D_LAUNCH_CHECK("l4d_chamfer_fwd");
   return 0;
@@ -119,9 +119,9 @@ extern "C" int l4d_chamfer_bwd(const float* xyz1, const float* xyz2, int32_t b, 
                                void* stream_) {
   if (b == 0 || n == 0 || m == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(chamfer_grad_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, xyz1, n, xyz2, m, grad_dist1, idx1, grad_xyz1,
+  L4D_LAUNCH(chamfer_grad_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, xyz1, n, xyz2, m, grad_dist1, idx1, grad_xyz1,
                      grad_xyz2);
-  hipLaunchKernelGGL(chamfer_grad_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, xyz2, m, xyz1, n, grad_dist2, idx2, grad_xyz2,
+  L4D_LAUNCH(chamfer_grad_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, xyz2, m, xyz1, n, grad_dist2, idx2, grad_xyz2,
                      grad_xyz1);
   L4D_LAUNCH_CHECK("l4d_chamfer_bwd");
   return 0;

@@ -21,6 +21,18 @@ extern "C" void l4d_set_error(int code, const char* where);
     }                                                   \
   } while (0)
 
+// Every kernel launch of the library goes through this macro: when profiling is switched on (l4d_profile_enable, used by
+// bench.py's per-kernel pass) a pair of HIP events is recorded around the launch ON THE LAUNCH STREAM, so the durations
+// bench.py reports are per KERNEL (same names as rocprofv3's kernel trace), also for entry points that launch several.
+extern "C" int l4d_prof_begin(const char* kernel, void* stream);
+extern "C" void l4d_prof_end(int idx, void* stream);
+#define L4D_LAUNCH(kernel, grid, block, lds, stream, ...)                    \
+  do {                                                                       \
+    const int prof_idx__ = l4d_prof_begin(#kernel, (void*)(stream));         \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);       \
+    if (prof_idx__ >= 0) l4d_prof_end(prof_idx__, (void*)(stream));          \
+  } while (0)
+
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -30,6 +42,13 @@ typedef float float2_t __attribute__((ext_vector_type(2)));  // arithmetic on it
 
 __device__ __forceinline__ float h2f(half_t h) { return (float)h; }
 __device__ __forceinline__ half_t f2h(float f) { return (half_t)f; }  // round-to-nearest-even
+// fp16 narrowing of BACKWARD quantities.  Not saturated on purpose: a gradient that leaves the fp16 range becomes inf
+// (and inf * 0 = nan further down), every kernel of the adjoint chain hands non-finite values on to the parameter
+// gradients it produces, and the optimiser side (l4d_grad_nonfinite_check, or torch's GradScaler.unscale_ in the
+// reference's own loop, runner.py:506-508) then skips the step and lowers the loss scale -- tiny-cuda-nn / autocast
+// semantics.  A saturating clamp here would hide the overflow and let a growing loss scale corrupt gradients silently.
+__device__ __forceinline__ half_t f2h_grad(float f) { return (half_t)f; }
+__device__ __forceinline__ bool nonfinite(float x) { return !(fabsf(x) <= 3.402823466e38f); }  // inf or nan
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

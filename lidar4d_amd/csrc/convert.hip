@@ -93,8 +93,8 @@ extern "C" int l4d_pano_to_lidar(const float* pano, const float* intensities, in
   if (n == 0) return (int)hipMemsetAsync(count, 0, 4, stream);
   const unsigned blocks = (unsigned)ceil_div64(n, CV_THREADS);
   int32_t* counts = (int32_t*)workspace;
-  hipLaunchKernelGGL(pano_count_kernel, dim3(blocks), dim3(CV_THREADS), 0, stream, pano, n, counts);
-  hipLaunchKernelGGL(pano_emit_kernel, dim3(blocks), dim3(CV_THREADS), 0, stream, pano, intensities, (int)H, (int)W, (float)fov_up,
+  L4D_LAUNCH(pano_count_kernel, dim3(blocks), dim3(CV_THREADS), 0, stream, pano, n, counts);
+  L4D_LAUNCH(pano_emit_kernel, dim3(blocks), dim3(CV_THREADS), 0, stream, pano, intensities, (int)H, (int)W, (float)fov_up,
                      (float)fov, (const int32_t*)counts, points, count);
   L4D_LAUNCH_CHECK("l4d_pano_to_lidar");
   return 0;
@@ -148,9 +148,9 @@ extern "C" int l4d_lidar_to_pano(const float* points, int64_t n, int32_t H, int3
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_lidar_to_pano memset"); return (int)e; }
   unsigned long long* best = (unsigned long long*)workspace;
   if (n > 0)
-    hipLaunchKernelGGL(lidar_bin_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, stream, points, n, (int)H, (int)W,
+    L4D_LAUNCH(lidar_bin_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, stream, points, n, (int)H, (int)W,
                        (float)((fov - fov_up) / 180 * CV_PI), (float)(2 * CV_PI / W), (float)(fov / 180 * CV_PI / H), max_depth, best);
-  hipLaunchKernelGGL(lidar_unpack_kernel, dim3((unsigned)ceil_div64(npix, 256)), dim3(256), 0, stream,
+  L4D_LAUNCH(lidar_unpack_kernel, dim3((unsigned)ceil_div64(npix, 256)), dim3(256), 0, stream,
                      (const unsigned long long*)best, points, npix, pano, intensities);
   L4D_LAUNCH_CHECK("l4d_lidar_to_pano");
   return 0;

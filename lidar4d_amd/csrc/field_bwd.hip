@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
 #pragma unroll
       for (int k = 0; k < C; ++k) {
         gd[k] = valid ? h2f(h[k]) : 0.0f;
-        gd_max = fmaxf(gd_max, fabsf(gd[k]));
+        gd_max = amax_nf(gd_max, gd[k]);
       }
     }
     Tap taps[3];
@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
         const float2_t gv = g2 * va * vb;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          hv[k + u] = f2h(fminf(fmaxf(gv[u], -65504.f), 65504.f));
-          smax = fmaxf(smax, fabsf(h2f(hv[k + u])));
+          hv[k + u] = f2h_grad(gv[u]);
+          smax = amax_nf(smax, h2f(hv[k + u]));
         }
       }
       if (valid) *reinterpret_cast<uint4*>(gvs + ((int64_t)(s * 3 + j) * P + p) * C) = *reinterpret_cast<uint4*>(hv);
@@ -127,8 +127,8 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
     for (int plane = 0; plane < 3; ++plane) {
       const int L = fd.hd[plane].n_levels;
       for (int lvl = 0; lvl < L; ++lvl, ++cidx) {
-        const half_t hv = f2h(fminf(fmaxf(h2f(row[col + lvl]) * c0, -65504.f), 65504.f));
-        const float a = valid ? fabsf(h2f(hv)) : 0.0f;
+        const half_t hv = f2h_grad(h2f(row[col + lvl]) * c0);
+        const float a = valid ? amax_nf(0.0f, h2f(hv)) : 0.0f;
         if (valid) gdynT[(int64_t)cidx * P + p] = hv;
         const float m = wave_max(a);
         if (lane == ST_DYN_MAX + cidx) my_stat = m;
@@ -254,13 +254,16 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
     if (active) {  // d(flow), in dX's (loss-scaled) domain
       half_t out[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) out[k] = k < 6 ? f2h(fminf(fmaxf(gflow[k], -65504.f), 65504.f)) : (half_t)0.0f;
+      for (int k = 0; k < 16; ++k) out[k] = k < 6 ? f2h_grad(gflow[k]) : (half_t)0.0f;
       uint4* dst = reinterpret_cast<uint4*>(dflow16 + p * 16);
       dst[0] = reinterpret_cast<uint4*>(out)[0];
       dst[1] = reinterpret_cast<uint4*>(out)[1];
     }
   }
   __syncthreads();
+  // an upstream gradient that left the fp16 range (inf / nan in dX) must reach the parameter gradients: the step is
+  // then skipped and the loss scale lowered (common.h, f2h_grad)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nonfinite(stats[ST_GD_MAX])) garena[fd.planes.off[0][group_ci(true, 0)]] = __builtin_nanf("");
   // flush: row S of (scale, plane, frame e) goes to the time rows y0(e), y1(e) of the gradient plane
   const float inv = pscale / fxs;
   for (int s = 0; s < nS; ++s) {
@@ -384,6 +387,7 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
   __syncthreads();
   const float inv = pscale / fxs;
   float* g = garena + fd.planes.off[s][ci] + (size_t)row0 * W * C;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nonfinite(stats[ST_GVS_MAX + s])) g[0] = __builtin_nanf("");  // overflowed upstream gradient
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
     const int v = lds_i[i];
     if (v != 0) atomicAdd(g + i, (float)v * inv);
@@ -411,6 +415,10 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
   for (int q = 0; q < plane; ++q) cidx += fd.hd[q].n_levels;
   const float gmax = stats[ST_DYN_MAX + cidx];
   if (!(gmax > 0.0f)) return;  // no gradient reaches this level at all
+  if (nonfinite(gmax)) {       // overflowed upstream gradient: hand it on (expanded into both slices' gradients)
+    if (blockIdx.x == 0 && threadIdx.x == 0) Hbuf[tasks.hoff[task] + lo] = __builtin_nanf("");
+    return;
+  }
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) lds_l[i] = 0;
   __syncthreads();
   const float fxs = fx_scale((float)chunk * gmax * 1.01f, 61);
@@ -518,7 +526,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   if (e == hipSuccess) e = hipMemcpyAsync(stats + ST_VMAX, plane_abs_max, sizeof(float), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
 
-  hipLaunchKernelGGL(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, stream, d, xt,
+  L4D_LAUNCH(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, stream, d, xt,
                      tinfo, P, (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats);
 
   // static 3-D hash grid: sorted scatter of dX[:, 2*nS*8 + lvl*4 ..] (binscatter.hip)
@@ -543,7 +551,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       for (int j = 0; j < 3; ++j) lds += TFRAMES * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
     (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
+    L4D_LAUNCH(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
                        tinfo, P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16);
   }
   // static planes
@@ -565,7 +573,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
         }
       }
     (void)hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    hipLaunchKernelGGL(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
+    L4D_LAUNCH(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
                        wave_skip, gvs, param_scale, stats);
   }
   // dynamic hash
@@ -588,11 +596,11 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
     (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipLaunchKernelGGL(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xt, P, chunk, gdynT, stats, Hbuf);
+    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xt, P, chunk, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);
-      hipLaunchKernelGGL(dynhash_expand_kernel, dim3((max_size + 255) / 256, d.hd[p].n_levels), dim3(256), 0, stream, d, fg, tinfo,
+      L4D_LAUNCH(dynhash_expand_kernel, dim3((max_size + 255) / 256, d.hd[p].n_levels), dim3(256), 0, stream, d, fg, tinfo,
                          Hbuf, p, hoff_plane[p], param_scale);
     }
   }

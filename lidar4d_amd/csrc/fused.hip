@@ -309,7 +309,7 @@ extern "C" int l4d_field_width(const l4d_field_desc* f) {
 }
 
 extern "C" int l4d_time_setup(const float* t, int32_t num_frames, float* tinfo, void* stream) {
-  hipLaunchKernelGGL(time_setup_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, num_frames, tinfo);
+  L4D_LAUNCH(time_setup_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, num_frames, tinfo);
   L4D_LAUNCH_CHECK("l4d_time_setup");
   return 0;
 }
@@ -318,7 +318,7 @@ extern "C" int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, cons
                                   const float* t, int64_t N, int32_t T, float near, float far, float bound, float* z_vals,
                                   float* xt, void* stream) {
   if (N == 0) return 0;
-  hipLaunchKernelGGL(sample_rays_xt_kernel, dim3((unsigned)ceil_div64(N * T, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+  L4D_LAUNCH(sample_rays_xt_kernel, dim3((unsigned)ceil_div64(N * T, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
                      rays_d, lin, noise, t, N, T, near, far, bound, z_vals, xt);
   L4D_LAUNCH_CHECK("l4d_sample_rays_xt");
   return 0;
@@ -342,17 +342,17 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     const int64_t chunk = ceil_div64(P, n_chunks);
     n_chunks = (int)ceil_div64(P, chunk);
     (void)hipFuncSetAttribute((const void*)dynhash_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DH_MAX_ENTRIES * 8);
-    hipLaunchKernelGGL(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
+    L4D_LAUNCH(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
                        2 * DH_MAX_ENTRIES * 8, (hipStream_t)stream, d, xt, (const half_t*)flow16, tinfo, P, chunk, (half_t*)hd_scratch);
   }
   const dim3 egrid((unsigned)xcd_grid(ceil_div64(P, ENC_THREADS)));
   const int colsA = 2 * d.planes.n_scales * 8;
   const int enc_lds = ENC_THREADS * (std::max(colsA, in_pad - colsA) + 8) * 2;
   if (hd_scratch)
-    hipLaunchKernelGGL((density_encode_fwd_kernel<true>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
+    L4D_LAUNCH((density_encode_fwd_kernel<true>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
                        (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);
   else
-    hipLaunchKernelGGL((density_encode_fwd_kernel<false>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
+    L4D_LAUNCH((density_encode_fwd_kernel<false>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
                        (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);
   L4D_LAUNCH_CHECK("l4d_density_encode_fwd");
   return 0;

@@ -231,7 +231,7 @@ extern "C" int l4d_hashgrid_fwd(const l4d_grid_desc* desc, const float* x, int64
   Cols c = make_cols(cols, desc->n_dims);
   dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels), block(256);
 #define CALL(D, F)                                                                                          \
-  hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, \
+  L4D_LAUNCH((hashgrid_fwd_kernel<D, F>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, \
                      (const half_t*)table, (half_t*)out, out_stride);
   DISPATCH_DF(desc->n_dims, desc->n_features, CALL)
 #undef CALL
@@ -248,10 +248,10 @@ extern "C" int l4d_hashgrid_bwd(const l4d_grid_desc* desc, const float* x, int64
   dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels), block(256);
 #define CALL(D, F)                                                                                                  \
   if (dout_is_half)                                                                                                 \
-    hipLaunchKernelGGL((hashgrid_bwd_kernel<D, F, true>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, \
+    L4D_LAUNCH((hashgrid_bwd_kernel<D, F, true>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, \
                        dout, dout_stride, grad_scale, grad_table);                                                  \
   else                                                                                                              \
-    hipLaunchKernelGGL((hashgrid_bwd_kernel<D, F, false>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride,  \
+    L4D_LAUNCH((hashgrid_bwd_kernel<D, F, false>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride,  \
                        c, dout, dout_stride, grad_scale, grad_table);
   DISPATCH_DF(desc->n_dims, desc->n_features, CALL)
 #undef CALL
@@ -289,7 +289,7 @@ extern "C" int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc, const float* x, int
   for (int i = 0; i < L4D_MAX_SLICES; ++i) tabs.t[i] = i < n_slices ? (const half_t*)tables[i] : nullptr;
   dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels), block(256);
 #define CALL(D, F, B)                                                                                                \
-  hipLaunchKernelGGL((hashgrid_t_fwd_kernel<D, F, B>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, tabs, \
+  L4D_LAUNCH((hashgrid_t_fwd_kernel<D, F, B>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, tabs, \
                      n_slices, t, out, out_stride);
   DISPATCH_T(desc->n_dims, desc->n_features, out_is_half, CALL)
 #undef CALL
@@ -325,16 +325,16 @@ extern "C" int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc, const float* x, int
   } else {
     dim3 grid((unsigned)ceil_div64(P, 256), desc->n_levels);
 #define CALL(D, F, B)                                                                                                \
-  hipLaunchKernelGGL((hashgrid_t_bwd_kernel<D, F, B>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c,    \
+  L4D_LAUNCH((hashgrid_t_bwd_kernel<D, F, B>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c,    \
                      dout, dout_stride, grad_scale, scratch);
     DISPATCH_T(desc->n_dims, desc->n_features, dout_is_half, CALL)
 #undef CALL
   }
   dim3 egrid((unsigned)ceil_div64(n_entries, 256));
   if (desc->n_features == 4)
-    hipLaunchKernelGGL((hashgrid_t_expand_kernel<4>), egrid, block, 0, (hipStream_t)stream, n_entries, n_slices, t, scratch, gr);
+    L4D_LAUNCH((hashgrid_t_expand_kernel<4>), egrid, block, 0, (hipStream_t)stream, n_entries, n_slices, t, scratch, gr);
   else
-    hipLaunchKernelGGL((hashgrid_t_expand_kernel<8>), egrid, block, 0, (hipStream_t)stream, n_entries, n_slices, t, scratch, gr);
+    L4D_LAUNCH((hashgrid_t_expand_kernel<8>), egrid, block, 0, (hipStream_t)stream, n_entries, n_slices, t, scratch, gr);
   L4D_LAUNCH_CHECK("l4d_hashgrid_t_bwd");
   return 0;
 }

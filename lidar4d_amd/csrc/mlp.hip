@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            nz[a][ks][r] = f2h(clamp_h(c[2 * ks][r]));
-            nz[a][ks][4 + r] = f2h(clamp_h(c[2 * ks + 1][r]));
+            nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
+            nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
           }
       }
 #pragma unroll
@@ -329,8 +329,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
         f4 t1 = MFMA(dzf[1][0], FR(L::WOT_N + nt), (f4{0, 0, 0, 0}));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h(clamp_h(t0[r])) : (half_t)0.0f;
-          dzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h(clamp_h(t1[r])) : (half_t)0.0f;
+          dzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h_grad(t0[r]) : (half_t)0.0f;
+          dzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h_grad(t1[r]) : (half_t)0.0f;
         }
       }
 #pragma unroll
@@ -385,8 +385,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            nz[a][ks][r] = f2h(clamp_h(c[2 * ks][r]));
-            nz[a][ks][4 + r] = f2h(clamp_h(c[2 * ks + 1][r]));
+            nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
+            nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
           }
       }
 #pragma unroll
@@ -397,8 +397,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
         t1 = MFMA(dzf[1][1], FR(fb + 8 + nt * 2 + 1), t1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          nzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h(clamp_h(t0[r])) : (half_t)0.0f;
-          nzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h(clamp_h(t1[r])) : (half_t)0.0f;
+          nzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h_grad(t0[r]) : (half_t)0.0f;
+          nzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h_grad(t1[r]) : (half_t)0.0f;
         }
       }
 #pragma unroll
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
             if (ok[a]) {
               h4 ov;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) ov[r] = f2h(clamp_h(c[r]));
+              for (int r = 0; r < 4; ++r) ov[r] = f2h_grad(c[r]);
               *reinterpret_cast<h4*>(dx + rows[a] * IN_PAD + 16 * mt + 4 * g) = ov;
             }
           }
@@ -508,7 +508,7 @@ extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int3
   bool done = false;
 #define X(IT, NHH)                                                                                                   \
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
-    hipLaunchKernelGGL((mlp_fwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, P, \
+    L4D_LAUNCH((mlp_fwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, P, \
                        n_rows, (const half_t*)weights, (half_t*)y, (half_t*)act);                                           \
     done = true;                                                                                                     \
   }
@@ -533,7 +533,7 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   bool done = false;
 #define X(IT, NHH)                                                                                                   \
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
-    hipLaunchKernelGGL((mlp_bwd_kernel<IT, NHH, 0, IT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,         \
+    L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,         \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
                        (half_t*)dx, grad_w, inv_loss_scale);                                                         \
     done = true;                                                                                                     \
@@ -542,10 +542,10 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
 #undef X
 #define X(IT, NHH)                                                                                                   \
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
-    hipLaunchKernelGGL((mlp_bwd_kernel<IT, NHH, 0, 6, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
+    L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, 6, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
                        (half_t*)dx, grad_w, inv_loss_scale);                                                         \
-    hipLaunchKernelGGL((mlp_bwd_kernel<IT, NHH, 6, IT, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
+    L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 6, IT, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
                        (half_t*)dx, grad_w, inv_loss_scale);                                                         \
     done = true;                                                                                                     \

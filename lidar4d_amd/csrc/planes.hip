@@ -160,7 +160,7 @@ extern "C" int l4d_planes_relayout(const float* const* planes, const int32_t* re
       const int64_t n = (int64_t)C * H * W;
       float* cl = planes_cl + plane_off[s * NPLANES + c];
       float* nchw = const_cast<float*>(planes[s * NPLANES + c]);
-      hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
+      L4D_LAUNCH(relayout_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
                          to_channel_last ? nchw : cl, to_channel_last ? cl : nchw, C, H, W, to_channel_last);
     }
   L4D_LAUNCH_CHECK("l4d_planes_relayout");
@@ -177,7 +177,7 @@ extern "C" int l4d_planes_fwd(const float* planes_cl, const int64_t* plane_off, 
   }
   PlaneDesc d;
   if (fill_desc(d, plane_off, res, n_scales)) return 1;
-  hipLaunchKernelGGL((planes_fwd_kernel<8>), dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, d,
+  L4D_LAUNCH((planes_fwd_kernel<8>), dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, d,
                      planes_cl, xt, P, which, out_s, out_d);
   L4D_LAUNCH_CHECK("l4d_planes_fwd");
   return 0;
@@ -193,7 +193,7 @@ extern "C" int l4d_planes_bwd(const float* planes_cl, const int64_t* plane_off, 
   }
   PlaneDesc d;
   if (fill_desc(d, plane_off, res, n_scales)) return 1;
-  hipLaunchKernelGGL((planes_bwd_kernel<8>), dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, d,
+  L4D_LAUNCH((planes_bwd_kernel<8>), dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, d,
                      planes_cl, xt, P, which, dout_s, dout_d, grad_cl, dxt);
   L4D_LAUNCH_CHECK("l4d_planes_bwd");
   return 0;

@@ -344,8 +344,8 @@ __global__ void __launch_bounds__(256) attr_scatter_bwd_kernel(const int32_t* __
   half_t vr[16], vi[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) { vr[e] = (half_t)0.0f; vi[e] = (half_t)0.0f; }
-  vr[0] = f2h(fminf(fmaxf(d_attr[p * 2 + 0] * sr * (1.0f - sr) * loss_scale, -65504.f), 65504.f));
-  vi[0] = f2h(fminf(fmaxf(d_attr[p * 2 + 1] * si * (1.0f - si) * loss_scale, -65504.f), 65504.f));
+  vr[0] = f2h_grad(d_attr[p * 2 + 0] * sr * (1.0f - sr) * loss_scale);
+  vi[0] = f2h_grad(d_attr[p * 2 + 1] * si * (1.0f - si) * loss_scale);
   uint4* dr = reinterpret_cast<uint4*>(dy_raydrop + j * 16);
   uint4* di = reinterpret_cast<uint4*>(dy_intensity + j * 16);
   dr[0] = reinterpret_cast<uint4*>(vr)[0]; dr[1] = reinterpret_cast<uint4*>(vr)[1];
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256) attr_gather_bwd_kernel(const int32_t* __r
   if (j >= M) return;
   const int64_t p = idx ? idx[j] : j;
   const float v = h2f(dxa_r[j * in_pad + n_enc + k]) + h2f(dxa_i[j * in_pad + n_enc + k]);
-  dh[p * 16 + 1 + k] = f2h(fminf(fmaxf(v, -65504.f), 65504.f));
+  dh[p * 16 + 1 + k] = f2h_grad(v);
 }
 
 // Same, one thread per row with 16-byte accesses, for the usual layout (n_enc a multiple of 8, 16 columns available):
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256) attr_gather_bwd_rows_kernel(const int32_t
 #pragma unroll
   for (int k = 0; k < 15; ++k) {
     const float v = h2f(r[k]) + h2f(q[k]);
-    o[1 + k] = k < n_geo ? f2h(fminf(fmaxf(v, -65504.f), 65504.f)) : (half_t)0.0f;
+    o[1 + k] = k < n_geo ? f2h_grad(v) : (half_t)0.0f;
   }
   *reinterpret_cast<uint4*>(dh + p * 16) = *reinterpret_cast<uint4*>(o);
   *reinterpret_cast<uint4*>(dh + p * 16 + 8) = *reinterpret_cast<uint4*>(o + 8);
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256) sigma_bwd_kernel(const half_t* __restrict
   if (p >= P) return;
   const float x = fminf(fmaxf(h2f(h[p * 16]), -15.0f), 15.0f);
   const float g = d_sigma[p] * expf(x) * loss_scale;
-  dh[p * 16] = f2h(fminf(fmaxf(g, -65504.f), 65504.f));
+  dh[p * 16] = f2h_grad(g);
 }
 
 // ================================================================================================
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) sigma_bwd_kernel(const half_t* __restrict
 extern "C" int l4d_sample_rays(const float* rays_o, const float* rays_d, const float* lin, const float* noise, int64_t N,
                                int32_t T, float near, float far, float bound, float* z_vals, float* xyz, void* stream) {
   if (N == 0) return 0;
-  hipLaunchKernelGGL(sample_rays_kernel, dim3((unsigned)ceil_div64(N * T, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+  L4D_LAUNCH(sample_rays_kernel, dim3((unsigned)ceil_div64(N * T, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
                      rays_d, lin, noise, N, T, near, far, bound, z_vals, xyz);
   L4D_LAUNCH_CHECK("l4d_sample_rays");
   return 0;
@@ -429,7 +429,7 @@ extern "C" int l4d_composite_fwd(const float* sigma, const float* z_vals, int64_
     hipError_t e = hipMemsetAsync(mask_count, 0, sizeof(int32_t), (hipStream_t)stream);
     if (e != hipSuccess) { l4d_set_error((int)e, "l4d_composite_fwd memset"); return (int)e; }
   }
-  hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, z_vals,
+  L4D_LAUNCH(composite_fwd_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, z_vals,
                      N, T, sample_dist, density_scale, active_sensor, weights, weights_sum, depth, mask, mask_idx, mask_count);
   L4D_LAUNCH_CHECK("l4d_composite_fwd");
   return 0;
@@ -438,7 +438,7 @@ extern "C" int l4d_composite_fwd(const float* sigma, const float* z_vals, int64_
 extern "C" int l4d_composite_image(const float* weights, const float* attr, int64_t N, int32_t T, int32_t C, float* image,
                                    void* stream) {
   if (N == 0) return 0;
-  hipLaunchKernelGGL(composite_image_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, (hipStream_t)stream, weights, attr,
+  L4D_LAUNCH(composite_image_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, (hipStream_t)stream, weights, attr,
                      N, T, C, image);
   L4D_LAUNCH_CHECK("l4d_composite_image");
   return 0;
@@ -450,7 +450,7 @@ extern "C" int l4d_composite_bwd(const float* sigma, const float* z_vals, const 
                                  float* d_sigma, float* d_attr, void* stream) {
   if (N == 0) return 0;
   if (C > 4 || T > 8 * 64 * MAXC) { l4d_set_error(1, "l4d_composite_bwd: C <= 4 and T <= 8192"); return 1; }
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, z_vals,
+  L4D_LAUNCH(composite_bwd_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, z_vals,
                      weights, attr, N, T, C, sample_dist, density_scale, active_sensor, d_depth, d_wsum, d_image, d_weights,
                      d_sigma, d_attr);
   L4D_LAUNCH_CHECK("l4d_composite_bwd");
@@ -460,7 +460,7 @@ extern "C" int l4d_composite_bwd(const float* sigma, const float* z_vals, const 
 extern "C" int l4d_freq_fwd(const float* x, int64_t P, int32_t n_dims, int32_t n_freq, void* out, int32_t out_stride,
                             void* stream) {
   if (P == 0) return 0;
-  hipLaunchKernelGGL(freq_kernel, dim3((unsigned)ceil_div64(P * n_dims * n_freq, 256)), dim3(256), 0, (hipStream_t)stream, x, P,
+  L4D_LAUNCH(freq_kernel, dim3((unsigned)ceil_div64(P * n_dims * n_freq, 256)), dim3(256), 0, (hipStream_t)stream, x, P,
                      n_dims, n_freq, (half_t*)out, out_stride);
   L4D_LAUNCH_CHECK("l4d_freq_fwd");
   return 0;
@@ -470,7 +470,7 @@ extern "C" int l4d_attr_gather(const int32_t* idx, const int32_t* count, int64_t
                                int32_t n_enc, const void* h, int32_t n_geo, void* xa, int32_t in_pad, void* stream) {
   if (cap == 0) return 0;
   if (in_pad % 8 || n_enc + n_geo > in_pad || n_geo > 15) { l4d_set_error(1, "l4d_attr_gather: bad widths"); return 1; }
-  hipLaunchKernelGGL(attr_gather_kernel, dim3((unsigned)ceil_div64(cap * (in_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+  L4D_LAUNCH(attr_gather_kernel, dim3((unsigned)ceil_div64(cap * (in_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                      idx, count, cap, T, (const half_t*)dir_enc, n_enc, (const half_t*)h, n_geo, (half_t*)xa, in_pad);
   L4D_LAUNCH_CHECK("l4d_attr_gather");
   return 0;
@@ -479,7 +479,7 @@ extern "C" int l4d_attr_gather(const int32_t* idx, const int32_t* count, int64_t
 extern "C" int l4d_attr_scatter(const int32_t* idx, const int32_t* count, int64_t cap, const void* y_raydrop,
                                 const void* y_intensity, float* attr, float* attr_compact, void* stream) {
   if (cap == 0) return 0;
-  hipLaunchKernelGGL(attr_scatter_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream, idx, count,
+  L4D_LAUNCH(attr_scatter_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream, idx, count,
                      cap, (const half_t*)y_raydrop, (const half_t*)y_intensity, attr, attr_compact);
   L4D_LAUNCH_CHECK("l4d_attr_scatter");
   return 0;
@@ -489,7 +489,7 @@ extern "C" int l4d_attr_scatter_bwd(const int32_t* idx, const int32_t* count, in
                                     const float* attr_compact, float loss_scale, void* dy_raydrop, void* dy_intensity,
                                     void* stream) {
   if (cap == 0) return 0;
-  hipLaunchKernelGGL(attr_scatter_bwd_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream, idx,
+  L4D_LAUNCH(attr_scatter_bwd_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream, idx,
                      count, cap, d_attr, attr_compact, loss_scale, (half_t*)dy_raydrop, (half_t*)dy_intensity);
   L4D_LAUNCH_CHECK("l4d_attr_scatter_bwd");
   return 0;
@@ -500,11 +500,11 @@ extern "C" int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int
                                    void* stream) {
   if (cap == 0) return 0;
   if ((n_enc & 7) == 0 && n_enc + 16 <= in_pad && n_geo <= 15)
-    hipLaunchKernelGGL(attr_gather_bwd_rows_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream,
+    L4D_LAUNCH(attr_gather_bwd_rows_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream,
                        idx, count, cap, (const half_t*)dxa_raydrop, (const half_t*)dxa_intensity, in_pad, n_enc, n_geo,
                        (half_t*)dh);
   else
-    hipLaunchKernelGGL(attr_gather_bwd_kernel, dim3((unsigned)ceil_div64(cap * n_geo, 256)), dim3(256), 0, (hipStream_t)stream,
+    L4D_LAUNCH(attr_gather_bwd_kernel, dim3((unsigned)ceil_div64(cap * n_geo, 256)), dim3(256), 0, (hipStream_t)stream,
                        idx, count, cap, (const half_t*)dxa_raydrop, (const half_t*)dxa_intensity, in_pad, n_enc, n_geo,
                        (half_t*)dh);
   L4D_LAUNCH_CHECK("l4d_attr_gather_bwd");
@@ -513,7 +513,7 @@ extern "C" int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int
 
 extern "C" int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* stream) {
   if (P == 0) return 0;
-  hipLaunchKernelGGL(sigma_from_h_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream,
+  L4D_LAUNCH(sigma_from_h_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)h, P, sigma);
   L4D_LAUNCH_CHECK("l4d_sigma_from_h");
   return 0;
@@ -521,7 +521,7 @@ extern "C" int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* st
 
 extern "C" int l4d_sigma_bwd(const void* h, const float* d_sigma, int64_t P, float loss_scale, void* dh, void* stream) {
   if (P == 0) return 0;
-  hipLaunchKernelGGL(sigma_bwd_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)h,
+  L4D_LAUNCH(sigma_bwd_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)h,
                      d_sigma, P, loss_scale, (half_t*)dh);
   L4D_LAUNCH_CHECK("l4d_sigma_bwd");
   return 0;

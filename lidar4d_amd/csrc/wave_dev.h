@@ -84,6 +84,10 @@ __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
 #undef L4D_FMAC_DPP
 }
 
+// running maximum of |v| that turns into +inf as soon as a non-finite value is seen (fmaxf alone drops nan): the
+// fixed-point statistics double as the "gradient overflowed" signal of the adjoint chain (common.h, f2h_grad)
+__device__ __forceinline__ float amax_nf(float m, float v) { return nonfinite(v) ? __builtin_inff() : fmaxf(m, fabsf(v)); }
+
 // fixed-point scale: largest power of two s with bound * s < 2^bits (bound > 0)
 __device__ __forceinline__ float fx_scale(float bound, int bits) {
   if (!(bound > 0.0f)) return 1.0f;

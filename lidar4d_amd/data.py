@@ -154,4 +154,5 @@ class SyntheticKitti360:
         images = torch.gather(self.images[frame].view(1, -1, 3), 1, inds[..., None].expand(-1, -1, 3))
         t = torch.tensor([[frame / (self.num_frames - 1)]], dtype=torch.float32, device=self.device)
         return {"rays_o_lidar": rays["rays_o"], "rays_d_lidar": rays["rays_d"], "time": t, "images_lidar": images,
-                "poses_lidar": pose, "H_lidar": self.H, "W_lidar": self.W, "index": [frame]}
+                "poses_lidar": pose, "H_lidar": self.H, "W_lidar": self.W, "index": [frame],
+                "time_host": frame / (self.num_frames - 1)}  # the same number on the host: no read-back for host-side decisions

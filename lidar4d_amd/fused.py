@@ -72,7 +72,11 @@ def _flow_wgrad(model):
 
 
 class RenderFn(torch.autograd.Function):
+    # The reference calls render() inside torch.cuda.amp.autocast (runner.py:497).  The node fixes its own precisions
+    # (fp16 tables / MFMA operands, fp32 accumulation and compositing), so autocast is switched off inside it and
+    # floating-point inputs arrive as fp32.
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, model, rays_o, rays_d, t_dev, noise, num_steps, train, *params):
         store = model._store
         N, T = rays_o.shape[0], int(num_steps)
@@ -119,12 +123,16 @@ class RenderFn(torch.autograd.Function):
         return depth, image, wsum, weights, z_vals, idx, count
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, d_depth, d_image, d_wsum, d_weights, _dz, _di, _dc):
         model, T, sample_dist = ctx.model, ctx.T, ctx.sample_dist
         (t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count, XA, actR, actI, attr,
          attr_c) = ctx.saved_tensors
         store = model._store
         store.prepare_grads()
+        # the current frame's time-slice pair is what receives dynamic-hash gradients (hash_field.py:79-85): raise its
+        # gates for the optimiser (trainer.FlatAdam leaves ungated slices alone, like torch.optim.Adam with grad = None)
+        ops.mark_time_slices(tinfo, model.hash_encoder.hash_dynamic[0].time_resolution, store.gates)
         ls = float(model.loss_scale)
         inv = 1.0 / ls
         P = xt.shape[0]
@@ -171,4 +179,10 @@ class RenderFn(torch.autograd.Function):
         fn = model.flow_net
         dxf = ops.mlp_bwd(xf, act_f, dflow16, _flow_w16(model), fn.n_hidden, _flow_wgrad(model), inv)
         ops.hashgrid_t_bwd(fn.grid_enc.meta, xt, (0, 1, 2), 1, t_dev, dxf, [store.grad_view(fn.grid_enc.params)], inv)
+        pair = getattr(model, "_host_slice_pair", None)
+        if pair is not None:  # reference semantics for a torch optimiser: untouched slices keep .grad = None (LiDAR4D.run)
+            for hd in model.hash_encoder.hash_dynamic:
+                for s, enc in enumerate(hd.hash_t):
+                    if s not in pair:
+                        enc.params.grad = None
         return (None,) * 7 + (None,) * (len(ctx.needs_input_grad) - 7)

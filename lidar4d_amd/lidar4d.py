@@ -37,6 +37,12 @@ class LiDAR4D(LiDAR_Renderer):
         self.num_frames = num_frames
         self.geo_feat_dim = geo_feat_dim
         self.loss_scale = 128.0  # scale of the fp16 adjoints inside the fused backward (tiny-cuda-nn's default)
+        # True (for the reference's own loop: torch.optim.Adam + GradScaler, runner.py:474-551): after backward, the
+        # HashGridT time slices the step did not use keep ``.grad = None`` as in the reference, so that torch's Adam skips
+        # them (no moment decay, no step count).  Costs one host read of ``time`` per call -- the reference pays the same
+        # in ``int(t * (num_frames - 1))`` (lidar4d.py:143).  lidar4d_amd.trainer.Trainer switches it off and gates those
+        # ranges on the device instead.
+        self.reference_grad_none = True
 
         self.planes_encoder = Planes4D(grid_dimensions=2, input_dim=4, output_dim=n_features_per_level_plane,
                                        resolution=[min_resolution] * 3 + [time_resolution],
@@ -103,6 +109,11 @@ class LiDAR4D(LiDAR_Renderer):
         field_params = [p for _, p, _, n, _ in self._store.entries if n > 0]
         train = torch.is_grad_enabled() and any(p.requires_grad for p in field_params)
         params = [p for p in field_params if p.requires_grad] if train else []
+        self._host_slice_pair = None
+        if train and self.reference_grad_none:  # hash_field.py:79-85 on the host, fp32 like the reference's tensor math
+            n_slices = self.hash_encoder.hash_dynamic[0].time_resolution
+            idx = np.float32(float(time.reshape(-1)[0]) if torch.is_tensor(time) else float(time)) * np.float32(n_slices - 1)
+            self._host_slice_pair = (int(np.floor(idx)), int(np.ceil(idx)))
         depth, image, wsum, weights, z_vals, idx, count = RenderFn.apply(self, rays_o, rays_d, t_dev, noise, num_steps,
                                                                         train, *params)
         return {

@@ -40,6 +40,12 @@ class PointsMeter:
         pred_lidar = pano_to_lidar(preds[0], self.intrinsics)
         gt_lidar = pano_to_lidar(truths[0], self.intrinsics)
         dist1, dist2, _, _ = chamfer_3DDist()(pred_lidar[None], gt_lidar[None])
+        if pred_lidar.shape[0] == 0 or gt_lidar.shape[0] == 0:
+            # a degenerate frame (e.g. every predicted ray-drop <= 0.5 early in training): record the worst value of both
+            # metrics instead of aborting the evaluation (the mean over an empty cloud would be nan)
+            self.V.append(torch.tensor([float("inf"), 0.0], device=preds.device))
+            self.N += 1
+            return
         chamfer_dis = dist1.mean() + dist2.mean()
         f_score, _, _ = fscore(dist1, dist2, 0.05)
         self.V.append(torch.stack([chamfer_dis, f_score[0]]))  # stays on the device

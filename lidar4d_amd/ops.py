@@ -342,3 +342,42 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, param16, lr, beta1, beta2, eps, 
     _chk(param16, torch.float16, "param16")
     call("l4d_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param16), param.numel(), float(lr),
          float(beta1), float(beta2), float(eps), 1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), _stream())
+
+
+class AdamRanges:
+    """Host-side description of the ranges one l4d_adam_step_ranges launch walks (built once)."""
+
+    def __init__(self, offs, lens, lr_mults, gate_idx):
+        self.n = len(offs)
+        self.offs, self.lens, self.lr_mults, self.gate_idx = list(offs), list(lens), list(lr_mults), list(gate_idx)
+        self._off = _i64s(self.offs)
+        self._len = _i64s(self.lens)
+        self._gate = _i32s(self.gate_idx)
+
+
+def adam_step_ranges(param, grad, exp_avg, exp_avg_sq, param16, ranges, lr, gates, scaler_state, steps, beta1, beta2, eps,
+                     grad_scale=1.0):
+    """One launch over all ranges; per-range step counters / gates / the scaler's skip flag live on the device."""
+    for nm, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _chk(t, torch.float32, nm)
+    _chk(param16, torch.float16, "param16"), _chk(gates, torch.float32, "gates"), _chk(scaler_state, torch.float32, "scaler")
+    _chk(steps, torch.int32, "steps")
+    lrs = (C.c_float * ranges.n)(*[lr * m for m in ranges.lr_mults])
+    call("l4d_adam_step_ranges", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param16), ranges.n, ranges._off,
+         ranges._len, C.cast(lrs, C.c_void_p), ranges._gate, _p(gates), _p(scaler_state), _p(steps), float(beta1), float(beta2),
+         float(eps), float(grad_scale), _stream())
+
+
+def grad_nonfinite_check(grad, scaler_state):
+    _chk(grad, torch.float32, "grad"), _chk(scaler_state, torch.float32, "scaler")
+    call("l4d_grad_nonfinite_check", _p(grad), grad.numel(), _p(scaler_state), _stream())
+
+
+def scaler_update(scaler_state, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+    _chk(scaler_state, torch.float32, "scaler")
+    call("l4d_scaler_update", _p(scaler_state), float(growth_factor), float(backoff_factor), int(growth_interval), _stream())
+
+
+def mark_time_slices(tinfo, n_slices, gates):
+    _chk(tinfo, torch.float32, "tinfo"), _chk(gates, torch.float32, "gates")
+    call("l4d_mark_time_slices", _p(tinfo), int(n_slices), _p(gates), _stream())

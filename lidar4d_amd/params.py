@@ -13,6 +13,7 @@ import torch
 from . import ops
 
 ALIGN = 8  # elements: 32-byte fp32 / 16-byte fp16 alignment for vector loads
+GATE_TAIL = 32  # floats after the last parameter's slot in the GRADIENT arena: "this range received a gradient" gates
 
 _EPOCH = [0]
 
@@ -42,6 +43,7 @@ class ParamStore:
             self.group_ranges.append((start, off))
         self.numel = off
         self.by_param = {id(p): (o, n) for _, p, o, n, _ in self.entries}
+        self.grad_numel = off + GATE_TAIL  # the gradient arena carries the optimiser's gates behind the parameters' slots
         self.flat = None
         self.flat_grad = None
         self.flat16 = None
@@ -91,11 +93,18 @@ class ParamStore:
         off, n = self.by_param[id(param)]
         return self.flat_grad[off:off + n]
 
+    @property
+    def gates(self):
+        """[GATE_TAIL] fp32 view behind the gradients: gates[s] != 0 <=> HashGridT time slice s received a gradient since
+        the last zero_grad (the reference leaves the other slices' .grad at None and torch.optim.Adam skips them).  Being
+        part of the gradient arena they are zeroed with it and merged across ranks by the same SUM all-reduce."""
+        return self.flat_grad[self.numel:self.numel + GATE_TAIL]
+
     def prepare_grads(self):
         """Make every parameter's .grad a view into the flat gradient arena; zero it if no gradient was held.
         Returns the arena.  Foreign .grad tensors (not our views) are folded in and replaced."""
         if self.flat_grad is None or self.flat_grad.device != self.flat.device:
-            self.flat_grad = torch.zeros(self.numel, dtype=torch.float32, device=self.flat.device)
+            self.flat_grad = torch.zeros(self.grad_numel, dtype=torch.float32, device=self.flat.device)
             fresh = True
         else:
             fresh = False

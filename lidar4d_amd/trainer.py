@@ -4,7 +4,9 @@ schedule, and ray-sharded data parallelism with one RCCL all-reduce of the flat 
 Restates only what `training rays/s` needs from the reference's Trainer (model/runner.py:166-213,474-551;
 optimizer main_lidar4d.py:298-305) plus the inference step of the evaluation / simulation loops
 (runner.py:438-470: staged render of a whole frame, U-Net ray-drop refinement, masking) and the optional ray-chamfer and
-scene-flow and line-of-sight loss terms (runner.py:215-276).  The patch gradient loss, EMA, checkpoints and logging are out of scope.
+scene-flow and line-of-sight loss terms (runner.py:215-276), the patch depth-gradient terms (runner.py:277-367), the
+optimiser-side semantics of the reference's AMP loop (GradScaler skip / backoff / growth, per-parameter Adam state:
+runner.py:102,506-508) and the per-epoch parameter EMA (runner.py:534-535).  Logging is out of scope.
 """
 import os
 
@@ -16,18 +18,45 @@ from . import ops
 from .params import bump_epoch
 
 
-def lidar_loss(outputs, images_lidar, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, smooth=0.2):
-    """runner.py:179-213: L1 depth + MSE ray-drop (label-smoothed) + MSE intensity, masked by the GT ray-drop, summed."""
+def criterion(kind, scale=1.0):
+    """The element-wise loss the reference selects with --depth_loss / --intensity_loss / --raydrop_loss
+    (main_lidar4d.py:63-66,183-196): l1, mse, bce (with logits) or huber (delta = 0.2 * scene scale), reduction none."""
+    if kind == "l1":
+        return lambda a, b: (a - b).abs()
+    if kind == "mse":
+        return lambda a, b: (a - b) ** 2
+    if kind == "bce":
+        return lambda a, b: torch.nn.functional.binary_cross_entropy_with_logits(a, b, reduction="none")
+    if kind == "huber":
+        return lambda a, b: torch.nn.functional.huber_loss(a, b, reduction="none", delta=0.2 * scale)
+    raise ValueError(f"unknown loss criterion {kind!r} (l1, mse, bce, huber)")
+
+
+def lidar_loss(outputs, images_lidar, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, smooth=0.2, depth_loss="l1",
+               raydrop_loss="mse", intensity_loss="mse", scale=1.0):
+    """runner.py:179-213: depth + ray-drop (label-smoothed) + intensity terms, masked by the GT ray-drop, summed.  Defaults =
+    the reference's: L1 depth, MSE ray-drop, MSE intensity (main_lidar4d.py:63-66); with ``raydrop_loss='bce'`` the
+    prediction goes through a sigmoid first and then BCE-with-logits, exactly as the reference does (runner.py:196-197)."""
     gt_raydrop = images_lidar[:, :, 0]
     gt_intensity = images_lidar[:, :, 1] * gt_raydrop
     gt_depth = images_lidar[:, :, 2] * gt_raydrop
     pred_raydrop = outputs["image_lidar"][:, :, 0]
     pred_intensity = outputs["image_lidar"][:, :, 1] * gt_raydrop
     pred_depth = outputs["depth_lidar"] * gt_raydrop
+    if raydrop_loss == "bce":
+        pred_raydrop = torch.sigmoid(pred_raydrop)
     gt_smooth = gt_raydrop.clamp(smooth, 1 - smooth)
-    loss = (alpha_d * (pred_depth - gt_depth).abs() + alpha_r * (pred_raydrop - gt_smooth) ** 2 +
-            alpha_i * (pred_intensity - gt_intensity) ** 2)
+    loss = (alpha_d * criterion(depth_loss, scale)(pred_depth, gt_depth) +
+            alpha_r * criterion(raydrop_loss, scale)(pred_raydrop, gt_smooth) +
+            alpha_i * criterion(intensity_loss, scale)(pred_intensity, gt_intensity))
     return loss.sum()
+
+
+def frame_index(time_lidar, num_frames):
+    """``int(time_lidar * (num_frames - 1))`` as the reference evaluates it (runner.py:228, lidar4d.py:143): the product is
+    an fp32 TENSOR product, truncated.  (In float64 the same expression lands just below k for 26 of the 51 default frame
+    times k / 50 and truncates to k - 1.)"""
+    return int(np.float32(float(time_lidar)) * np.float32(num_frames - 1))
 
 
 def ray_chamfer_loss(outputs, data, scale):
@@ -143,13 +172,16 @@ def process_pointcloud(dataset, ground_split=None):
     return pc_list, pc_ground_list
 
 
-def flow_loss(model, pc_list, pc_ground_list, time_lidar, num_frames, t_ground=None):
+def flow_loss(model, pc_list, pc_ground_list, time_lidar, num_frames, t_ground=None, frame_idx=None):
     """runner.py:222-253: two-step forward / backward chamfer consistency of the scene flow between neighbouring frames'
     point clouds (sum, not mean, of the squared distances) + 0.001 * L1 of the flow on ground points at a random time.
-    ``t_ground`` replaces the reference's ``torch.rand(1)`` when given (tests)."""
+    ``t_ground`` replaces the reference's ``torch.rand(1)`` when given (tests).  ``frame_idx``: the value of
+    ``frame_index(time_lidar, num_frames)`` if the caller already knows it on the host (spares the device read-back the
+    reference pays in ``int(time_lidar * ...)``)."""
     from .chamfer import chamfer_3DDist
     cham = chamfer_3DDist()
-    frame_idx = int(float(time_lidar) * (num_frames - 1))
+    if frame_idx is None:
+        frame_idx = frame_index(time_lidar, num_frames)
     pc = pc_list[f"{frame_idx}"]
     pred = model.flow(pc, time_lidar)
     loss = pc.new_zeros(())
@@ -170,18 +202,78 @@ def flow_loss(model, pc_list, pc_ground_list, time_lidar, num_frames, t_ground=N
     return loss
 
 
+class DynamicLossScaler:
+    """torch.cuda.amp.GradScaler as the reference's Trainer uses it (runner.py:102,506-508: default init_scale 65536,
+    growth 2 every 2000 clean steps, backoff 0.5) with its state ON THE DEVICE -- [scale, growth tracker, found non-finite,
+    1 / scale] -- so that scaling the loss, checking the reduced gradient arena (one reduction), gating the Adam launch
+    and updating the scale never make the host wait (torch's GradScaler.step reads found_inf back every step).
+    The scale multiplies the loss outside the fused backward, on top of ``model.loss_scale`` (= tiny-cuda-nn's constant
+    internal 128); the backward kernels do not saturate fp16 adjoints, they let inf / nan travel to the
+    parameter gradients (csrc/common.h f2h_grad), where ``check`` finds them."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 1.0 / init_scale], dtype=torch.float32, device=device)
+
+    def scale(self, loss):
+        return loss * self.state[0]
+
+    def check(self, flat_grad):
+        ops.grad_nonfinite_check(flat_grad, self.state)
+
+    def update(self):
+        ops.scaler_update(self.state, self.growth_factor, self.backoff_factor, self.growth_interval)
+
+    def get_scale(self):  # host read-back (synchronises): logging / tests only
+        return float(self.state[0])
+
+    def state_dict(self):
+        st = self.state.tolist()
+        return {"scale": st[0], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(st[1])}
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor = sd["growth_factor"], sd["backoff_factor"]
+        self.growth_interval = sd["growth_interval"]
+        self.state.copy_(torch.tensor([sd["scale"], float(sd["_growth_tracker"]), 0.0, 1.0 / sd["scale"]]))
+
+
 class FlatAdam:
-    """torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) over the model's flat arenas: one l4d_adam_step launch per lr
-    group (encoders at lr, networks at 0.1 lr: lidar4d.py:226-237), which also refreshes the fp16 compute copies.
-    lr follows the reference's LambdaLR: lr0 * 0.1 ** min(it / iters, 1) (main_lidar4d.py:303-305)."""
+    """torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) over the model's flat arenas in ONE l4d_adam_step_ranges launch
+    (which also refreshes the fp16 compute copies); encoders at lr, networks at 0.1 lr (lidar4d.py:226-237).
+    lr follows the reference's LambdaLR: lr0 * 0.1 ** min(it / iters, 1) (main_lidar4d.py:303-305).
+
+    torch.optim.Adam keeps its state per parameter TENSOR and skips tensors whose .grad is None.  With the reference's
+    ``zero_grad(set_to_none)`` that is what happens to the 6-7 of 8 HashGridT time slices a step does not touch
+    (hash_field.py:79-85): no moment decay, no step increment, no movement.  Here the arena is cut into ranges -- every
+    time slice table its own range, gated by the gate the backward pass sets for the slice pair it used
+    (ParamStore.gates), the rest merged per lr group -- each with its own step counter on the device; a range whose gate
+    is zero is left alone, and with a DynamicLossScaler the whole step is skipped when a gradient is non-finite."""
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, iters=30000):
         self.model, self.store = model, model._store
         self.lr0, self.betas, self.eps, self.iters = lr, betas, eps, iters
         self.group_lr = [1.0, 0.1]
-        self.step_count = 0
+        self.step_count = 0  # scheduler iterations (the reference steps its LambdaLR every iteration, skipped or not)
         self.exp_avg = torch.zeros_like(self.store.flat)
         self.exp_avg_sq = torch.zeros_like(self.store.flat)
+        self._build_ranges()
+        self.steps = torch.zeros(self.ranges.n, dtype=torch.int32, device=self.store.flat.device)
+
+    def _build_ranges(self):
+        import re
+        st = self.store
+        keyed = []  # (offset, group, gate) per entry in arena order
+        for name, p, off, n, gi in st.entries:
+            m = re.fullmatch(r"hash_encoder\.hash_dynamic\.\d+\.hash_t\.(\d+)\.params", name)
+            keyed.append((off, gi, int(m.group(1)) if m else -1))
+        starts = [k for i, k in enumerate(keyed) if i == 0 or k[2] >= 0 or keyed[i - 1][1:] != k[1:]]
+        ends = [k[0] for k in starts[1:]] + [st.numel]
+        self.ranges = ops.AdamRanges([k[0] for k in starts], [e - k[0] for k, e in zip(starts, ends)],
+                                     [self.group_lr[k[1]] for k in starts], [k[2] for k in starts])
+        self._range_of = {}
+        for name, p, off, n, gi in st.entries:
+            self._range_of[id(p)] = max(i for i, o in enumerate(self.ranges.offs) if o <= off)
 
     def lr(self):
         return self.lr0 * 0.1 ** min(self.step_count / self.iters, 1.0)
@@ -196,7 +288,8 @@ class FlatAdam:
 
     def state_dict(self):
         """A state dict a ``torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)`` can load: per-parameter
-        ``step`` / ``exp_avg`` / ``exp_avg_sq`` cut out of the flat moment buffers."""
+        ``step`` / ``exp_avg`` / ``exp_avg_sq`` cut out of the flat buffers (parameters that never received a gradient have
+        no entry, as in torch)."""
         layout = self._torch_layout()
         groups, state, lr_now = [], {}, self.lr()
         for gi, g in enumerate(self.model.get_params(self.lr0)):
@@ -204,19 +297,24 @@ class FlatAdam:
             groups.append({"lr": lr_now * (g["lr"] / self.lr0), "initial_lr": g["lr"], "betas": tuple(self.betas), "eps": self.eps,
                            "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
                            "differentiable": False, "fused": None, "params": ids})
-        if self.step_count > 0:
-            for k, (_, p) in enumerate(layout):
-                if p.numel() == 0 or id(p) not in self.store.by_param:
-                    continue
-                off, n = self.store.by_param[id(p)]
-                state[k] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
-                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        steps = self.steps.tolist()
+        for k, (_, p) in enumerate(layout):
+            if p.numel() == 0 or id(p) not in self.store.by_param:
+                continue
+            t = steps[self._range_of[id(p)]]
+            if t == 0:
+                continue
+            off, n = self.store.by_param[id(p)]
+            state[k] = {"step": torch.tensor(float(t)), "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        """Accepts the optimiser state of a checkpoint written by the reference's Trainer (or by ``state_dict`` above)."""
+        """Accepts the optimiser state of a checkpoint written by the reference's Trainer (or by ``state_dict`` above).
+        Per-parameter step counts are kept per range; tensors that share a range (planes + static grid, the networks)
+        always stepped together in the reference too -- the range takes their largest count."""
         layout = self._torch_layout()
-        steps = set()
+        steps = [0] * self.ranges.n
         for k, st in sd["state"].items():
             _, p = layout[int(k)]
             if p.numel() == 0 or id(p) not in self.store.by_param:
@@ -224,19 +322,21 @@ class FlatAdam:
             off, n = self.store.by_param[id(p)]
             self.exp_avg[off:off + n].copy_(st["exp_avg"].to(self.exp_avg).reshape(-1))
             self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].to(self.exp_avg_sq).reshape(-1))
-            steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise ValueError(f"FlatAdam: parameters with different step counts {sorted(steps)} cannot share one flat state")
-        self.step_count = steps.pop() if steps else 0
+            r = self._range_of[id(p)]
+            steps[r] = max(steps[r], int(float(st["step"])))
+        self.steps.copy_(torch.tensor(steps, dtype=torch.int32))
+        self.step_count = max(steps) if steps else 0  # checkpoint.load_checkpoint overrides it with the scheduler's count
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, scaler=None):
         st = self.store
         lr = self.lr()
         self.step_count += 1
         f16 = st.flat16 if st.flat16 is not None else st.refresh16()
-        for (a, b), mult in zip(st.group_ranges, self.group_lr):
-            ops.adam_step(st.flat[a:b], st.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], f16[a:b], lr * mult,
-                          self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale)
+        if self.steps.device != st.flat.device:
+            self.steps = self.steps.to(st.flat.device)
+        ops.adam_step_ranges(st.flat, st.flat_grad, self.exp_avg, self.exp_avg_sq, f16, self.ranges, lr, st.gates,
+                             None if scaler is None else scaler.state, self.steps, self.betas[0], self.betas[1], self.eps,
+                             grad_scale)
         bump_epoch()          # parameters changed behind torch's version counters ...
         st.mark16_current()   # ... and the fp16 copies were refreshed by the same kernel
         self.model.planes_encoder._cl_key = None  # channel-last plane copy must be rebuilt
@@ -284,8 +384,8 @@ def refine_unet(unet, raydrop_input, raydrop_gt, epochs=1000, batch_size=None, l
 
 class FlatEMA:
     """Exponential moving average of the parameters over the flat arena: what the reference keeps with
-    ``torch_ema.ExponentialMovingAverage(model.parameters(), decay)`` (runner.py:97-98; updated after every optimiser
-    step, :534-535; swapped in for evaluation with store / copy_to / restore, :565-567,679-680; ``--ema_decay`` 0.95 by
+    ``torch_ema.ExponentialMovingAverage(model.parameters(), decay)`` (runner.py:97-98; updated ONCE PER EPOCH, after the
+    loop over the loader, :534-535; swapped in for evaluation with store / copy_to / restore, :565-567,679-680; ``--ema_decay`` 0.95 by
     default).  One fused elementwise launch over one buffer instead of a python loop over ~70 tensors.
     Update rule (torch_ema): decay_t = min(decay, (1 + t) / (10 + t)) for the t-th update; shadow -= (1 - decay_t) *
     (shadow - param).  The U-Net is not part of the arena and is left alone (the reference trains it after the field)."""
@@ -369,7 +469,7 @@ class GradReducer:
     def early(self):
         g = self.store.flat_grad
         self.works = [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True)
-                      for a, b in ((0, self.flow_lo), (self.flow_hi, self.store.numel)) if b > a]
+                      for a, b in ((0, self.flow_lo), (self.flow_hi, self.store.grad_numel)) if b > a]  # incl. the gates
 
     def finish(self):
         g = self.store.flat_grad
@@ -387,18 +487,27 @@ class Trainer:
     indices -- parameters are replicated and the flat gradient buffer is SUM-all-reduced once per step (the primary
     loss is a sum over rays, so the result equals one big batch)."""
 
-    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=False, flow=False, urf=False,
-                 ema_decay=None):
-        """chamfer=True adds the reference's ray chamfer term (runner.py:215-220); it is a mean over the rank's own
-        rays, so under data parallelism it is scaled by 1/world before the SUM all-reduce.
-        flow=True adds the scene-flow consistency term (runner.py:222-253, ``opt.flow_loss``): a per-frame sum, so under
-        data parallelism it enters each rank's loss as it is (every rank works on its own frame)."""
+    def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=True, flow=True, urf=False,
+                 ema_decay=None, loss_scaler=True, init_scale=65536.0, depth_loss="l1", raydrop_loss="mse",
+                 intensity_loss="mse", epoch_steps=None):
+        """Defaults follow the reference's default run: the ray chamfer term is always part of its step
+        (runner.py:215-220) and ``--flow_loss`` defaults to True (main_lidar4d.py:67).
+        chamfer: a mean over the rank's own rays, so under data parallelism it is scaled by 1/world before the SUM
+        all-reduce.  flow: the scene-flow consistency term (runner.py:222-253), a per-frame sum, enters each
+        rank's loss as it is (every rank works on its own frame).  loss_scaler: GradScaler semantics on the device
+        (DynamicLossScaler).  ema_decay: parameter EMA, updated once per epoch like the reference's (runner.py:534-535);
+        an epoch = ``epoch_steps`` steps (default: one per training frame, the reference's loader length)."""
         self.model, self.dataset, self.num_steps, self.chamfer = model, dataset, num_steps, chamfer
         self.flow, self.urf, self.iters = flow, urf, iters
+        self.loss_kinds = dict(depth_loss=depth_loss, raydrop_loss=raydrop_loss, intensity_loss=intensity_loss)
         self.ema = FlatEMA(model, ema_decay) if ema_decay is not None else None  # runner.py:97-98
+        self.epoch_steps = epoch_steps if epoch_steps is not None else getattr(dataset, "num_frames", 1)
+        self.local_step = 0
         if flow:
             self.pc_list, self.pc_ground_list = process_pointcloud(dataset)
         self.opt = FlatAdam(model, lr=lr, iters=iters)
+        self.scaler = DynamicLossScaler(model._store.flat.device, init_scale=init_scale) if loss_scaler else None
+        model.reference_grad_none = False  # untouched time slices are gated on the device (FlatAdam), no host read-back
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # a one-rank process group still runs the collective when asked to (bench.py L4D_FORCE_DIST: exercises RCCL on one GPU)
         self.force_allreduce = dist.is_available() and dist.is_initialized() and os.environ.get("L4D_FORCE_DIST") == "1"
@@ -408,16 +517,15 @@ class Trainer:
             if os.environ.get("L4D_NO_OVERLAP") != "1":
                 model._grads_ready_hook = self.reducer.early
 
-    def train_step(self, data=None):
-        data = data if data is not None else self.dataset.batch()
-        self.opt.zero_grad()
-        out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
-                                num_steps=self.num_steps)
-        loss = lidar_loss(out, data["images_lidar"])
+    def compute_loss(self, data, out):
+        """The reference's training loss (runner.py:179-276,277-367) for one batch and its render outputs."""
+        loss = lidar_loss(out, data["images_lidar"], scale=self.dataset.scale, **self.loss_kinds)
         if self.chamfer:
             loss = loss + ray_chamfer_loss(out, data, self.dataset.scale) / self.world
         if self.flow:
-            loss = loss + flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames)
+            known = frame_index(data["time_host"], self.dataset.num_frames) if "time_host" in data else None
+            loss = loss + flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames,
+                                    frame_idx=known)
         patch = getattr(self.dataset, "patch_size_lidar", 1)
         if patch != 1:  # rays were drawn as pixel patches (runner.py:277-367); a sum over this rank's patches
             gt = data["images_lidar"]
@@ -426,15 +534,34 @@ class Trainer:
         if self.urf:  # a per-ray mean like the chamfer term
             gt = data["images_lidar"]
             loss = loss + urf_loss(out, gt[:, :, 2] * gt[:, :, 0], self.opt.step_count, self.iters) / self.world
-        loss.backward()
+        return loss
+
+    def train_step(self, data=None):
+        data = data if data is not None else self.dataset.batch()
+        self.opt.zero_grad()
+        out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
+                                num_steps=self.num_steps)
+        loss = self.compute_loss(data, out)
+        (self.scaler.scale(loss) if self.scaler is not None else loss).backward()  # runner.py:506
+        st = self.model._store
         if self.flow:
-            self.model._store.prepare_grads()  # fold gradients autograd produced outside the fused node into the arena
+            st.prepare_grads()  # fold gradients autograd produced outside the fused node into the arena
         if self.reducer is not None:
             self.reducer.finish()
-        self.opt.step()
-        if self.ema is not None:
-            self.ema.update()  # runner.py:534-535
+        if self.scaler is not None:
+            self.scaler.check(st.flat_grad)      # after the all-reduce: every rank takes the same decision
+        self.opt.step(scaler=self.scaler)        # runner.py:507 (skipped on the device if a gradient was non-finite)
+        if self.scaler is not None:
+            self.scaler.update()                 # runner.py:508
+        self.local_step += 1
+        if self.local_step % self.epoch_steps == 0:
+            self.end_epoch()
         return loss
+
+    def end_epoch(self):
+        """runner.py:534-535: the parameter EMA is updated once per epoch, after the loop over the loader."""
+        if self.ema is not None:
+            self.ema.update()
 
     @torch.no_grad()
     def collect_refine_data(self, frames=None, max_ray_batch=4096):

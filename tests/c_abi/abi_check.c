@@ -10,6 +10,7 @@ typedef void (*fn_t)(void);
 int main(void) {
   const fn_t entry_points[] = {
       (fn_t)&l4d_adam_step,
+      (fn_t)&l4d_adam_step_ranges,
       (fn_t)&l4d_attr_gather,
       (fn_t)&l4d_attr_gather_bwd,
       (fn_t)&l4d_attr_scatter,
@@ -26,6 +27,7 @@ int main(void) {
       (fn_t)&l4d_density_encode_fwd,
       (fn_t)&l4d_field_width,
       (fn_t)&l4d_freq_fwd,
+      (fn_t)&l4d_grad_nonfinite_check,
       (fn_t)&l4d_hashgrid_bwd,
       (fn_t)&l4d_hashgrid_fwd,
       (fn_t)&l4d_hashgrid_t_bwd,
@@ -34,6 +36,7 @@ int main(void) {
       (fn_t)&l4d_last_error,
       (fn_t)&l4d_lidar_to_pano,
       (fn_t)&l4d_lidar_to_pano_workspace,
+      (fn_t)&l4d_mark_time_slices,
       (fn_t)&l4d_mlp_bwd,
       (fn_t)&l4d_mlp_fwd,
       (fn_t)&l4d_pano_to_lidar,
@@ -41,8 +44,12 @@ int main(void) {
       (fn_t)&l4d_planes_bwd,
       (fn_t)&l4d_planes_fwd,
       (fn_t)&l4d_planes_relayout,
+      (fn_t)&l4d_profile_count,
+      (fn_t)&l4d_profile_enable,
+      (fn_t)&l4d_profile_get,
       (fn_t)&l4d_sample_rays,
       (fn_t)&l4d_sample_rays_xt,
+      (fn_t)&l4d_scaler_update,
       (fn_t)&l4d_sigma_bwd,
       (fn_t)&l4d_sigma_from_h,
       (fn_t)&l4d_time_setup,

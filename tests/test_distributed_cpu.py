@@ -38,6 +38,7 @@ def _worker(rank, world, port, out):
         lidar_loss(o, images[:, lo:hi]).backward()
         g = store.prepare_grads()
         g.zero_()
+        store.gates[rank + 1] = 1.0  # "this rank's step used time slice rank + 1": the gates ride in the arena's tail
         pr = dict(ref.named_parameters())
         for name, p, off, n, _ in store.entries:
             if n and pr[name].grad is not None:
@@ -60,9 +61,10 @@ def _worker(rank, world, port, out):
     fallback_equal = bool(torch.equal(store.flat_grad, g))
     if rank == 0:
         full = grads_for(0, n_total)
-        err = float((g - full).abs().max() / full.abs().max())
-        out.put(("err", err, int(full.numel()), [list(r) for r in store.group_ranges], two_phase_equal, fallback_equal,
-                 [red.flow_lo, red.flow_hi]))
+        n = store.numel  # parameter gradients only (the tail behind them holds the gates)
+        err = float((g[:n] - full[:n]).abs().max() / full[:n].abs().max())
+        out.put(("err", err, int(store.numel), [list(r) for r in store.group_ranges], two_phase_equal, fallback_equal,
+                 [red.flow_lo, red.flow_hi], g[store.numel:store.numel + 4].tolist(), int(full.numel())))
     dist.destroy_process_group()
 
 
@@ -76,7 +78,8 @@ def test_ray_sharded_allreduce_equals_single_batch():
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    tag, err, numel, ranges, two_phase_equal, fallback_equal, flow_range = out.get(timeout=10)
+    tag, err, numel, ranges, two_phase_equal, fallback_equal, flow_range, gates, grad_numel = out.get(timeout=10)
+    assert gates == [0.0, 1.0, 1.0, 0.0] and grad_numel == numel + 32  # the SUM all-reduce merges the ranks' slice gates
     assert tag == "err" and err < 1e-5, err
     assert two_phase_equal and fallback_equal
     assert ranges[1][0] == flow_range[0] < flow_range[1] < numel  # the flow field opens lr group 1

@@ -334,6 +334,13 @@ def test_checkpoint_roundtrip_and_reference_style_file(tmp_path):
     m = fill_model(LiDAR4D(**SMALL_MODEL), seed=4)
     opt, ema = FlatAdam(m, lr=1e-2, iters=100), FlatEMA(m, 0.95)
     opt.step_count = 7
+    # per-range step counts as a real run leaves them: time-slice tables that were rarely selected lag behind (the reference's
+    # torch.optim.Adam skips tensors whose .grad is None), one was never touched at all
+    opt.steps.fill_(7)
+    gated = [r for r, g in enumerate(opt.ranges.gate_idx) if g >= 0]
+    assert len(gated) == 3 * 8
+    opt.steps[gated[1]] = 3
+    opt.steps[gated[2]] = 0
     opt.exp_avg.normal_(generator=torch.Generator().manual_seed(1))
     opt.exp_avg_sq.uniform_(generator=torch.Generator().manual_seed(2))
     ema.shadow.mul_(0.5)
@@ -356,7 +363,12 @@ def test_checkpoint_roundtrip_and_reference_style_file(tmp_path):
     assert info["epoch"] == 3 and info["global_step"] == 7 and not info["missing_keys"] and not info["unexpected_keys"]
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
     assert opt2.step_count == 7 and ema2.decay == 0.95 and ema2.num_updates == 7
+    assert torch.equal(opt2.steps, opt.steps)  # differing per-parameter step counts survive the round trip
+    steps_written = sorted({int(v["step"]) for v in raw["optimizer"]["state"].values()})
+    assert steps_written == [3, 7]
     for (_, p, off, n, _), (_, p2, off2, _, _) in zip(m._store.entries, m2._store.entries):
+        if int(opt.steps[opt._range_of[id(p)]]) == 0:
+            continue  # never stepped: no optimiser state is written for it, as in torch
         assert torch.equal(opt.exp_avg[off:off + n], opt2.exp_avg[off2:off2 + n])
         assert torch.equal(ema.shadow[off:off + n], ema2.shadow[off2:off2 + n])
     # bare state dict (runner.py:1027-1030) and model_only
@@ -511,3 +523,62 @@ def test_c_abi_from_plain_c(tmp_path):
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     n_declared = len(_lib.SIGNATURES) + 2
     assert out.startswith(f"{n_declared} entry points, ABI v{_lib.ABI_VERSION}")
+
+
+def test_frame_index_is_the_fp32_product_of_the_reference():
+    """runner.py:228 / lidar4d.py:143: ``int(time * (num_frames - 1))`` with ``time`` an fp32 tensor.  The float64 product of
+    the same numbers truncates to k - 1 for about half of the default frame times k / 50."""
+    from lidar4d_amd.trainer import frame_index
+    wrong64 = 0
+    for F in (51, 5, 2, 17, 100, 201):
+        for k in range(F):
+            t = torch.tensor([[k / (F - 1)]], dtype=torch.float32)
+            want = int(t * (F - 1))
+            assert frame_index(t, F) == want == int(np.float32(float(t)) * np.float32(F - 1)), (F, k)
+            assert frame_index(float(t), F) == want
+            if F == 51:
+                assert want == k
+                wrong64 += int(float(t) * (F - 1)) != k
+    assert wrong64 > 20  # what the float64 evaluation would have got wrong
+
+
+def test_lidar_loss_criteria_match_the_reference_table():
+    """main_lidar4d.py:183-196: the criterion dict {l1, mse, bce (with logits), huber (delta 0.2 * scale)}, reduction none, as
+    runner.py:199-213 combines them (ray-drop prediction through a sigmoid first when its loss is bce)."""
+    from lidar4d_amd.trainer import lidar_loss
+    g = torch.Generator().manual_seed(5)
+    n, scale = 64, 0.0105
+    img = torch.rand(1, n, 3, generator=g)
+    img[..., 0] = (img[..., 0] > 0.3).float()
+    out = {"image_lidar": torch.rand(1, n, 2, generator=g), "depth_lidar": torch.rand(1, n, generator=g)}
+    table = {"l1": torch.nn.L1Loss(reduction="none"), "mse": torch.nn.MSELoss(reduction="none"),
+             "bce": torch.nn.BCEWithLogitsLoss(reduction="none"), "huber": torch.nn.HuberLoss(reduction="none", delta=0.2 * scale)}
+    for kd, kr, ki in (("l1", "mse", "mse"), ("huber", "bce", "l1"), ("mse", "l1", "huber"), ("bce", "huber", "bce")):
+        gt_r = img[:, :, 0]
+        pr = torch.sigmoid(out["image_lidar"][:, :, 0]) if kr == "bce" else out["image_lidar"][:, :, 0]
+        want = (1.0 * table[kd](out["depth_lidar"] * gt_r, img[:, :, 2] * gt_r) + 0.01 * table[kr](pr, gt_r.clamp(0.2, 0.8)) +
+                0.1 * table[ki](out["image_lidar"][:, :, 1] * gt_r, img[:, :, 1] * gt_r)).sum()
+        got = lidar_loss(out, img, depth_loss=kd, raydrop_loss=kr, intensity_loss=ki, scale=scale)
+        assert torch.allclose(got, want, rtol=1e-6), (kd, kr, ki)
+    with pytest.raises(ValueError):
+        lidar_loss(out, img, depth_loss="l3")
+
+
+def test_flat_adam_ranges_partition_the_arena():
+    """FlatAdam cuts the arena into one range per HashGridT time-slice table (gated by its slice index) and one merged range
+    per remaining run of an lr group: disjoint, ordered, covering every parameter."""
+    from lidar4d_amd import LiDAR4D
+    from lidar4d_amd.trainer import FlatAdam
+    from oracle.make_golden import SMALL_MODEL
+    m = LiDAR4D(**SMALL_MODEL)
+    opt = FlatAdam(m)
+    R, st = opt.ranges, m._store
+    assert R.offs[0] == 0 and all(o % 8 == 0 for o in R.offs)
+    assert all(R.offs[i] + R.lens[i] == R.offs[i + 1] for i in range(R.n - 1)) and R.offs[-1] + R.lens[-1] == st.numel
+    assert sorted(g for g in R.gate_idx if g >= 0) == sorted(list(range(8)) * 3) and R.gate_idx.count(-1) == R.n - 24
+    for name, p, off, n, gi in st.entries:
+        r = opt._range_of[id(p)]
+        assert R.offs[r] <= off and off + n <= R.offs[r] + R.lens[r]
+        assert R.lr_mults[r] == (1.0, 0.1)[gi]
+        assert (R.gate_idx[r] >= 0) == (".hash_t." in name)
+    assert st.grad_numel == st.numel + 32

@@ -230,7 +230,7 @@ def test_flow_loss_vs_oracle():
             scale = max(abs(v[1]), 1e-12)
             assert max(abs(dig[n][k] - v[k]) for k in range(3)) / scale < 3e-2, (n, dig[n], v)
         # a training step with all optional terms runs and changes the flow parameters
-        tr = Trainer(hip, data, num_steps=64, chamfer=True, flow=True)
+        tr = Trainer(hip, data, num_steps=64, chamfer=True, flow=True, init_scale=1.0)
         before = hip.flow_net.grid_enc.params.detach().clone()
         l0 = float(tr.train_step(data.batch_for(2)))
         assert np.isfinite(l0) and not torch.equal(before, hip.flow_net.grid_enc.params.detach())
@@ -299,9 +299,10 @@ def test_training_step_with_all_loss_terms():
     cfg = dict(SMALL_MODEL, num_frames=5, near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE, density_scale=20.0)
     data = SyntheticKitti360("cuda", H=16, W=64, num_frames=5, num_rays=128)
     losses = {}
-    for name, kw in (("plain", {}), ("urf", dict(urf=True)), ("all", dict(chamfer=True, flow=True, urf=True))):
+    off = dict(chamfer=False, flow=False)  # the Trainer's defaults are the reference's: chamfer and scene-flow terms on
+    for name, kw in (("plain", off), ("urf", dict(off, urf=True)), ("all", dict(urf=True))):
         m = fill_model(LiDAR4D(**cfg), seed=3, flow_out_amp=0.002).cuda()
-        tr = Trainer(m, data, num_steps=64, iters=10, **kw)
+        tr = Trainer(m, data, num_steps=64, iters=10, init_scale=1.0, **kw)  # scale 1: no skipped first steps
         before = m._store.flat.clone()
         data.gen.manual_seed(0)
         torch.manual_seed(0)
@@ -310,7 +311,7 @@ def test_training_step_with_all_loss_terms():
     assert losses["urf"][0] > losses["plain"][0] and losses["all"][0] > losses["urf"][0]  # the terms are non-negative
     # rays drawn as 2 x 8 pixel patches switch the depth-gradient term on (runner.py:277-367, 700-705)
     m = fill_model(LiDAR4D(**cfg), seed=3, flow_out_amp=0.002).cuda()
-    tr = Trainer(m, data, num_steps=64, iters=10)
+    tr = Trainer(m, data, num_steps=64, iters=10, init_scale=1.0)
     data.patch_size_lidar = [2, 8]
     try:
         b = data.batch_for(2)
