@@ -9,7 +9,7 @@ echo "pytest rc=$?" >> $O/pytest.log
 tail -n 25 $O/pytest.log
 python bench.py > $O/bench.json 2> $O/bench.err
 echo "bench rc=$?"; head -c 1500 $O/bench.json
-B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --variant-steps 0 --profile-steps 0"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --variant-steps 0 --profile-steps 0"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/kt -o kt -- $B > $GRAFT_REPO_ROOT/$O/kt.log 2>&1 )
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) 60 > $O/kernel_stats.txt 2>&1
 rocprofv3 -L 2>/dev/null | grep -i -E "mfma|SQ_BUSY_CYCLES|SQ_WAVE_CYCLES|GRBM_GUI_ACTIVE|SQ_ACTIVE_INST_VALU|SQ_INSTS_VALU " | head -60 > $O/counters.txt

@@ -20,7 +20,7 @@ def main(path):
          f"from {pe} e join {ip} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id "
          f"group by s.kernel_name, p.{name_col} order by 4 desc")
     print(f"{'kernel':64s} {'counter':12s} {'launches':>8s} {'sum':>14s} {'per_launch':>14s}")
-    for r in cur.execute(q).fetchall()[:40]:
+    for r in cur.execute(q).fetchall()[:200]:
         print(f"{r[0][:64]:64s} {str(r[1]):12s} {r[2]:8d} {r[3]:14.4e} {r[3] / max(r[2], 1):14.4e}")
 
 
