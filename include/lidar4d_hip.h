@@ -127,7 +127,10 @@ int l4d_freq_fwd(const float* x, int64_t P, int32_t n_dims, int32_t n_freq, void
 int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad, int32_t n_hidden,
                 const void* weights, void* y, void* act, void* stream);
 /* dy [P,16] fp16 (already multiplied by the caller's loss scale); dx [P, in_pad] fp16 or null;
- * grad_w fp32, same layout as weights, ACCUMULATED with 1/loss_scale applied. */
+ * grad_w fp32, same layout as weights, ACCUMULATED with 1/loss_scale applied.
+ * act: the forward's saved activations, or null = recompute them from x inside the kernel (saves 128 B/row/layer of HBM
+ * traffic twice; built for in_pad <= 32 with 1-3 hidden layers and for in_pad 128 with one hidden layer -- wider / deeper
+ * shapes would spill registers and return an error). */
 int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64_t P, const int32_t* n_rows, int32_t in_pad,
                 int32_t n_hidden, const void* weights, void* dx, float* grad_w, float inv_loss_scale, void* stream);
 
@@ -188,6 +191,7 @@ typedef struct {
   const void* hash_static_table;                               /* fp16 */
   l4d_grid_desc hash_dynamic[3];                               /* xy, xz, yz: 2-D, F = 4 */
   const void* hash_dynamic_tables[3][L4D_MAX_TIME_SLICES];     /* fp16, one table per time slice */
+  const void* hash_dynamic_pairs[3];                           /* null, or l4d_dyn_pairs_build() of the plane's slice tables */
   int32_t n_slices;
   int32_t n_scales;                                            /* hex-plane scales */
   int32_t plane_channels;                                      /* 8 */
@@ -202,6 +206,11 @@ typedef struct {                                               /* fp32 gradient 
 } l4d_field_grads;
 
 int l4d_field_width(const l4d_field_desc* f /*host*/);         /* feature columns before padding */
+/* Pair-interleaved copy of one plane's time-slice tables for the fused forward: pairs [n_slices - 1][n_entries][2][4] fp16,
+ * pairs[q][e] = {slice q entry e, slice q + 1 entry e}.  HashGridT blends two adjacent slices (hash_field.py:79-85): with
+ * this copy both come in ONE 16-byte load per corner.  slice_tables: host array of n_slices device pointers ([n_entries, 4]
+ * fp16 each, all levels).  Rebuild whenever the fp16 tables change (one pass over ~50 MB per plane set: microseconds). */
+int l4d_dyn_pairs_build(const void* const* slice_tables /*host*/, int32_t n_slices, int64_t n_entries, void* pairs, void* stream);
 /* tinfo [8] fp32 (device) <- t: [t, t1=(f+1)/num_frames, t2=(f-1)/num_frames, has_fwd, has_bwd, f] */
 int l4d_time_setup(const float* t, int32_t num_frames, float* tinfo, void* stream);
 /* l4d_sample_rays variant that writes xt [N*T,4] = ((clip(o+d z)+bound)/(2 bound), t) (lidar4d.py:141,148-149) */
@@ -210,9 +219,14 @@ int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, const float* li
                        float* xt, void* stream);
 /* flow16 [P,16] fp16: flow network output (cols 0-2 forward, 3-5 backward); X [P,in_pad] fp16.
  * hd_scratch: null, or (levels of the 3 dynamic grids) * P fp16 of device scratch -> the 2-D x time hash stacks are
- * evaluated by a separate kernel from LDS-resident slice tables (faster from ~1e5 samples). */
+ * evaluated by a separate kernel from LDS-resident slice tables (faster from ~1e5 samples).
+ * plane_rows: null, or l4d_plane_rows_workspace() bytes of device scratch -> the time planes are first reduced to the
+ * 1-D rows of the call's three frame times (their time coordinate is the same for every sample) and sampled with two
+ * taps instead of four. */
+int64_t l4d_plane_rows_workspace(const l4d_field_desc* f /*host*/);
 int l4d_density_encode_fwd(const l4d_field_desc* f /*host*/, const float* xt, const void* flow16,
-                           const float* tinfo, int64_t P, void* X, int32_t in_pad, void* hd_scratch, void* stream);
+                           const float* tinfo, int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows,
+                           void* stream);
 /* Adjoint.  dX [P,in_pad] fp16 (loss-scaled); parameter gradients are accumulated multiplied by param_scale
  * (= 1/loss_scale); dflow16 [P,16] fp16 stays in dX's scaled domain.  plane_abs_max: device fp32 = max |plane
  * parameter| (bounds the fixed-point LDS accumulators); samples_per_ray: T when the P rows are rays x T samples in

@@ -34,6 +34,7 @@ class FieldDesc(C.Structure):
         ("hash_static_table", C.c_void_p),
         ("hash_dynamic", GridDesc * 3),
         ("hash_dynamic_tables", (C.c_void_p * L4D_MAX_TIME_SLICES) * 3),
+        ("hash_dynamic_pairs", C.c_void_p * 3),
         ("n_slices", C.c_int32),
         ("n_scales", C.c_int32),
         ("plane_channels", C.c_int32),
@@ -82,10 +83,12 @@ SIGNATURES = {
     "l4d_sigma_from_h": [P, I64, P, P],
     "l4d_sigma_bwd": [P, P, I64, F32, P, P],
     "l4d_time_setup": [P, I32, P, P],
-    "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P, P],
+    "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P, P, P],
+    "l4d_plane_rows_workspace": [FD],
     "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P],
     "l4d_density_encode_bwd_workspace": [FD, I64],
     "l4d_field_width": [FD],
+    "l4d_dyn_pairs_build": [PP, I32, I64, P, P],
     "l4d_chamfer_workspace": [I32, I32, I32],
     "l4d_chamfer_fwd": [P, P, I32, I32, I32, P, P, P, P, P, P],
     "l4d_chamfer_bwd": [P, P, I32, I32, I32, P, P, P, P, P, P, P],

@@ -49,6 +49,54 @@ __device__ __forceinline__ void planes_group(const FieldDesc& fd, int s, const f
 #endif
 }
 
+// ---- time planes as 1-D rows ------------------------------------------------------------------------------------
+// The time coordinate of a frame is the same for every sample of a call, so the two time rows a time-plane tap touches and
+// their weights are launch-uniform: rows[s][j][e][x][c] = wy0(e) * plane[y0(e)][x][c] + wy1(e) * plane[y1(e)][x][c] is built
+// once per call (35 k floats at the default sizes) and a time-plane sample becomes a 1-D interpolation -- two 32-byte
+// texels instead of four.  The kernel is bound by L1 bandwidth on exactly these fp32 texel reads (12 KB per sample), and
+// 3/4 of the plane taps belong to time planes (3 planes at x, 3 + 3 at the two warped points).
+struct PlaneRows {
+  const float* base;  // null: sample the planes directly
+  int off[MAX_SCALES][3];
+};
+#define TROWS_FRAMES 3
+__global__ void __launch_bounds__(256) plane_time_rows_kernel(FieldDesc fd, PlaneRows pr, const float* __restrict__ tinfo, float* __restrict__ rows) {
+  constexpr int C = 8;
+  const int s = blockIdx.y / 3, j = blockIdx.y % 3, e = blockIdx.z;
+  const int W = fd.planes.res[s][j], Ht = fd.planes.res[s][3];
+  int y0, y1;
+  float wy0, wy1, my;
+  axis_tap(tinfo[e], Ht, y0, y1, wy0, wy1, my);
+  const float* plane = fd.planes_cl + fd.planes.off[s][j == 0 ? 2 : j == 1 ? 4 : 5];
+  float* dst = rows + pr.off[s][j] + e * W * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * C; i += gridDim.x * blockDim.x)
+    dst[i] = plane[(size_t)y0 * W * C + i] * wy0 + plane[(size_t)y1 * W * C + i] * wy1;
+}
+
+// product over the three time planes of scale s at frame e, from the 1-D rows
+template <int C>
+__device__ __forceinline__ void planes_time_group(const FieldDesc& fd, const PlaneRows& pr, int s, int e, const float coord[4], float out[C]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int W = fd.planes.res[s][j];
+    int x0, x1;
+    float wx0, wx1, mx;
+    axis_tap(coord[j], W, x0, x1, wx0, wx1, mx);
+    const char* b = reinterpret_cast<const char*>(pr.base + pr.off[s][j] + e * W * C);
+    const float4_t* p0 = reinterpret_cast<const float4_t*>(b + (uint32_t)x0 * (C * 4u));
+    const float4_t* p1 = reinterpret_cast<const float4_t*>(b + (uint32_t)x1 * (C * 4u));
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      const float4_t a = p0[q], c = p1[q];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = a[k] * wx0 + c[k] * wx1;
+        out[q * 4 + k] = j == 0 ? v : out[q * 4 + k] * v;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
   half_t h[8];
 #pragma unroll
@@ -67,12 +115,12 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 #ifndef ENC_WAVES_PER_EU
 #define ENC_WAVES_PER_EU 2
 #endif
-template <bool USE_HDT>
+template <bool USE_HDT, bool ROWS>
 __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
                                                                         const float* __restrict__ tinfo, int64_t P,
                                                                         const half_t* __restrict__ hdT,
-                                                                        half_t* __restrict__ X, int in_pad) {
+                                                                        half_t* __restrict__ X, int in_pad, PlaneRows prows) {
   constexpr int C = 8;
   // the row is staged and written out in two parts (planes | everything else) so that the staging buffer is half as
   // large: LDS is what limits this kernel's occupancy (gather latency needs waves in flight)
@@ -105,9 +153,15 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
   for (int s = 0; s < nS; ++s) {
     float ps[C], d0[C], d1[C], d2[C];
     planes_group<C>(fd, s, x0, false, ps);
-    planes_group<C>(fd, s, x0, true, d0);
-    if (has_fwd) planes_group<C>(fd, s, x1, true, d1);
-    if (has_bwd) planes_group<C>(fd, s, x2, true, d2);
+    if (ROWS) {
+      planes_time_group<C>(fd, prows, s, 0, x0, d0);
+      if (has_fwd) planes_time_group<C>(fd, prows, s, 1, x1, d1);
+      if (has_bwd) planes_time_group<C>(fd, prows, s, 2, x2, d2);
+    } else {
+      planes_group<C>(fd, s, x0, true, d0);
+      if (has_fwd) planes_group<C>(fd, s, x1, true, d1);
+      if (has_bwd) planes_group<C>(fd, s, x2, true, d2);
+    }
     float pd[C];
 #pragma unroll
     for (int k = 0; k < C; ++k) pd[k] = 0.5f * d0[k] + 0.25f * ((has_fwd ? d1[k] : d0[k]) + (has_bwd ? d2[k] : d0[k]));
@@ -205,8 +259,16 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
 #pragma unroll
   for (int e = 0; e < 3; ++e) in_lds[e] = has_e[e] && tc[e].sp.i1 == tc[0].sp.i1 && tc[e].sp.i2 == tc[0].sp.i2;
   const bool two = tc[0].sp.i1 != tc[0].sp.i2;
-  // stage the current frame's slice pair of this (plane, level): slice i1 at [0, size), slice i2 at [size, 2 size)
-  {
+  // stage the current frame's slice pair of this (plane, level): lds_tab[entry] = {slice i1, slice i2}
+  if (fd.hd_pairs[plane]) {  // pair-interleaved copy: already in the LDS layout, 16 bytes per lane, coalesced
+    const PairSel ps = pair_sel(tc[0].sp, fd.n_slices);
+    const uint4* src = reinterpret_cast<const uint4*>(fd.hd_pairs[plane]) + (size_t)ps.q * fd.hd_entries[plane] + g.offset[lvl];
+    for (uint32_t i = threadIdx.x; i < size; i += DH_THREADS) {
+      uint4 v = src[i];
+      if (!two && ps.hi) v = make_uint4(v.z, v.w, v.z, v.w);  // single slice in the pair's high half: serve it as "slice i1"
+      lds_tab[i] = v;
+    }
+  } else {
     const uint2* t1p = reinterpret_cast<const uint2*>(fd.hd_tables[plane][tc[0].sp.i1] + (size_t)g.offset[lvl] * 4);
     const uint2* t2p = reinterpret_cast<const uint2*>(fd.hd_tables[plane][tc[0].sp.i2] + (size_t)g.offset[lvl] * 4);
     for (uint32_t i = threadIdx.x * 2; i < size; i += DH_THREADS * 2) {  // sizes are multiples of 8 entries
@@ -220,9 +282,8 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
   __syncthreads();
   half_t* out = hdT + (int64_t)col * P;
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += DH_THREADS) {
-    const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
-    const uint4 u = *reinterpret_cast<const uint4*>(flow16 + p * 16);
+  // one sample: the three frames' lookups from the staged table, blended
+  auto eval = [&](const float4_t& c4, const uint4& u) -> half_t {
     const half_t* fh = reinterpret_cast<const half_t*>(&u);
     const float xa[3] = {c4[ca], c4[ca] + h2f(fh[ca]), c4[ca] + h2f(fh[3 + ca])};
     const float xb[3] = {c4[cb], c4[cb] + h2f(fh[cb]), c4[cb] + h2f(fh[3 + cb])};
@@ -269,7 +330,20 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
       }
     }
     const float r1 = has_e[1] ? r[1] : r[0], r2 = has_e[2] ? r[2] : r[0];
-    out[p] = f2h(0.5f * r[0] + 0.25f * (r1 + r2));
+    return f2h(0.5f * r[0] + 0.25f * (r1 + r2));
+  };
+  // two samples per iteration: both samples' global loads are in flight before the first LDS lookup (the loop is bound by
+  // the latency of these loads at one 1024-thread workgroup per CU)
+  for (int64_t p0 = lo_p + threadIdx.x; p0 < hi_p; p0 += 2 * DH_THREADS) {
+    const int64_t p1 = p0 + DH_THREADS;
+    const bool ok1 = p1 < hi_p;
+    const int64_t q1 = ok1 ? p1 : p0;
+    const float4_t c4a = *reinterpret_cast<const float4_t*>(xt + p0 * 4);
+    const uint4 ua = *reinterpret_cast<const uint4*>(flow16 + p0 * 16);
+    const float4_t c4b = *reinterpret_cast<const float4_t*>(xt + q1 * 4);
+    const uint4 ub = *reinterpret_cast<const uint4*>(flow16 + q1 * 16);
+    out[p0] = eval(c4a, ua);
+    if (ok1) out[p1] = eval(c4b, ub);
   }
 }
 
@@ -324,8 +398,39 @@ extern "C" int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, cons
   return 0;
 }
 
+// pairs[q][e] = {slice q entry e, slice q + 1 entry e}: one thread per (pair, entry)
+struct PairSrc {
+  const half_t* t[MAX_SLICES];
+};
+__global__ void __launch_bounds__(256) dyn_pairs_kernel(PairSrc tabs, int n_pairs, int64_t n_entries, uint4* __restrict__ pairs) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = blockIdx.y;
+  if (e >= n_entries) return;
+  const uint2 lo = reinterpret_cast<const uint2*>(tabs.t[q])[e];
+  const uint2 hi = reinterpret_cast<const uint2*>(tabs.t[q + 1])[e];
+  pairs[(int64_t)q * n_entries + e] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+extern "C" int l4d_dyn_pairs_build(const void* const* slice_tables, int32_t n_slices, int64_t n_entries, void* pairs, void* stream) {
+  if (n_slices < 2 || n_entries == 0) return 0;
+  if (n_slices > MAX_SLICES) { l4d_set_error(1, "l4d_dyn_pairs_build: too many slices"); return 1; }
+  PairSrc tabs;
+  for (int i = 0; i < MAX_SLICES; ++i) tabs.t[i] = i < n_slices ? (const half_t*)slice_tables[i] : nullptr;
+  L4D_LAUNCH(dyn_pairs_kernel, dim3((unsigned)ceil_div64(n_entries, 256), n_slices - 1), dim3(256), 0, (hipStream_t)stream, tabs,
+             n_slices - 1, n_entries, (uint4*)pairs);
+  L4D_LAUNCH_CHECK("l4d_dyn_pairs_build");
+  return 0;
+}
+
+extern "C" int64_t l4d_plane_rows_workspace(const l4d_field_desc* f) {
+  int64_t n = 0;
+  for (int s = 0; s < f->n_scales; ++s)
+    for (int j = 0; j < 3; ++j) n += (int64_t)TROWS_FRAMES * f->plane_res[s * 4 + j] * f->plane_channels;
+  return n * (int64_t)sizeof(float);
+}
+
 extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, const void* flow16, const float* tinfo,
-                                      int64_t P, void* X, int32_t in_pad, void* hd_scratch, void* stream) {
+                                      int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows, void* stream) {
   if (P == 0) return 0;
   FieldDesc d;
   if (make_field(f, d)) return 1;
@@ -345,15 +450,29 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     L4D_LAUNCH(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
                        2 * DH_MAX_ENTRIES * 8, (hipStream_t)stream, d, xt, (const half_t*)flow16, tinfo, P, chunk, (half_t*)hd_scratch);
   }
+  PlaneRows pr;
+  pr.base = plane_rows;
+  {
+    int o = 0;
+    for (int s = 0; s < MAX_SCALES; ++s)
+      for (int j = 0; j < 3; ++j) {
+        pr.off[s][j] = o;
+        if (s < d.planes.n_scales) o += TROWS_FRAMES * d.planes.res[s][j] * 8;
+      }
+  }
+  if (plane_rows)  // tinfo[0..2] = t, t1, t2: frames without a neighbour get a row nobody reads
+    L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, (hipStream_t)stream, d, pr, tinfo, plane_rows);
   const dim3 egrid((unsigned)xcd_grid(ceil_div64(P, ENC_THREADS)));
   const int colsA = 2 * d.planes.n_scales * 8;
   const int enc_lds = ENC_THREADS * (std::max(colsA, in_pad - colsA) + 8) * 2;
-  if (hd_scratch)
-    L4D_LAUNCH((density_encode_fwd_kernel<true>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
-                       (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);
-  else
-    L4D_LAUNCH((density_encode_fwd_kernel<false>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,
-                       (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad);
+#define ENC_LAUNCH(HDT, ROWS)                                                                                               \
+  L4D_LAUNCH((density_encode_fwd_kernel<HDT, ROWS>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,         \
+             (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr)
+  if (hd_scratch && plane_rows) ENC_LAUNCH(true, true);
+  else if (hd_scratch) ENC_LAUNCH(true, false);
+  else if (plane_rows) ENC_LAUNCH(false, true);
+  else ENC_LAUNCH(false, false);
+#undef ENC_LAUNCH
   L4D_LAUNCH_CHECK("l4d_density_encode_fwd");
   return 0;
 }

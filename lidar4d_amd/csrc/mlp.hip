@@ -190,7 +190,10 @@ struct BwdFrags {
 // COL_LO..COL_HI: range of 16-wide input-column tiles whose dW1 / dX this launch produces; REST: also accumulate the
 // hidden/output layers' dW.  Inputs wider than 128 columns are handled by two launches (the dW1 accumulators of all
 // columns do not fit the register file next to the other layers'); the chain is recomputed, which is cheap.
-template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST>
+// RECOMP: the hidden activations are not read from `act` but recomputed from x with the forward chain (forward weight
+// fragments in LDS as well): trades 128 B/row/layer of HBM traffic (written by the forward, read here) for 4 KS_IN + 8 (NH-1)
+// MFMAs per 16 rows.  Used where the activations dominate the traffic (the flow network: 32-byte rows, 256 B of activations).
+template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST, bool RECOMP = false>
 __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
                                                      const half_t* __restrict__ dy, int64_t cap,
                                                      const int32_t* __restrict__ n_rows,
@@ -200,7 +203,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
   using L = BwdFrags<IN_TILES, NH>;
   constexpr int IN_PAD = IN_TILES * 16;
   constexpr int KS_IN = L::KS_IN;
-  __shared__ uint4 frags[L::NF][64];
+  constexpr int NF_FWD = RECOMP ? 4 * KS_IN + (NH - 1) * 8 : 0;  // forward chain fragments (layers 1 .. NH), as in mlp_fwd_kernel
+  __shared__ uint4 frags[L::NF + NF_FWD][64];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -225,6 +229,19 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       v = build_frag(W1, HID, IN_PAD, 1, 16 * mt + i, 32 * ks + 8 * g);
     }
     frags[f][lane] = *reinterpret_cast<uint4*>(&v);
+  }
+  if (RECOMP) {
+    for (int f = wave; f < NF_FWD; f += 4) {
+      h8 v;
+      if (f < 4 * KS_IN) {
+        const int mt = f / KS_IN, ks = f % KS_IN;
+        v = build_frag(weights, HID, IN_PAD, 0, perm_row(mt, i), 32 * ks + 8 * g);
+      } else {
+        const int q = f - 4 * KS_IN, layer = q / 8, mt = (q % 8) / 2, ks = q % 2;
+        v = build_frag(weights + HID * IN_PAD + layer * HID * HID, HID, HID, 0, perm_row(mt, i), 32 * ks + 8 * g);
+      }
+      frags[L::NF + f][lane] = *reinterpret_cast<uint4*>(&v);
+    }
   }
   __syncthreads();
   auto FR = [&](int f) -> h8 { uint4 u = frags[f][lane]; return *reinterpret_cast<h8*>(&u); };
@@ -257,6 +274,42 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       rows[a] = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
       ok[a] = rows[a] < P;
     }
+    // ---- (RECOMP) forward chain from x: hidden activations of every layer, chain layout [layer][a][ks] ----
+    h8 xf[2][KS_IN];
+    h8 hrec[RECOMP ? NH : 1][2][2];
+    if (RECOMP) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int ks = 0; ks < KS_IN; ++ks) {
+          const int k0 = 32 * ks + 8 * g;
+          uint4 u = make_uint4(0, 0, 0, 0);
+          if (ok[a] && k0 < IN_PAD) u = *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
+          xf[a][ks] = *reinterpret_cast<h8*>(&u);
+        }
+        f4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          acc[mt] = f4{0, 0, 0, 0};
+#pragma unroll
+          for (int ks = 0; ks < KS_IN; ++ks) acc[mt] = MFMA(FR(L::NF + mt * KS_IN + ks), xf[a][ks], acc[mt]);
+        }
+        hrec[0][a][0] = relu_pack(acc[0], acc[1]);
+        hrec[0][a][1] = relu_pack(acc[2], acc[3]);
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+          const int base = L::NF + 4 * KS_IN + (l - 1) * 8;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            acc[mt] = f4{0, 0, 0, 0};
+            acc[mt] = MFMA(FR(base + mt * 2 + 0), hrec[l - 1][a][0], acc[mt]);
+            acc[mt] = MFMA(FR(base + mt * 2 + 1), hrec[l - 1][a][1], acc[mt]);
+          }
+          hrec[l][a][0] = relu_pack(acc[0], acc[1]);
+          hrec[l][a][1] = relu_pack(acc[2], acc[3]);
+        }
+      }
+    }
     // ---- output layer ----------------------------------------------------------------------
     h8 dzf[2][2];  // chain B fragments of the current layer's dZ: [a][ks]
     h8 dzT[4];     // orientation-2: lane = feature 16*nt + i, 8 rows
@@ -278,7 +331,12 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
     }
     // activations of the last hidden layer, chain layout [a][ks]
     h8 hf[2][2];
-    {
+    if (RECOMP) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) hf[a][ks] = hrec[NH - 1][a][ks];
+    } else {
       const half_t* a_l = act + (int64_t)(NH - 1) * cap * HID;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -347,9 +405,13 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          uint4 u = make_uint4(0, 0, 0, 0);
-          if (ok[a]) u = *reinterpret_cast<const uint4*>(a_l + rows[a] * HID + 32 * ks + 8 * g);
-          hf[a][ks] = *reinterpret_cast<h8*>(&u);
+          if (RECOMP) {
+            hf[a][ks] = hrec[RECOMP ? layer - 2 : 0][a][ks];
+          } else {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (ok[a]) u = *reinterpret_cast<const uint4*>(a_l + rows[a] * HID + 32 * ks + 8 * g);
+            hf[a][ks] = *reinterpret_cast<h8*>(&u);
+          }
         }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -410,16 +472,17 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
     }
     // ---- first layer: dW1 = dZ1^T X, dX = dZ1 W1 ---------------------------------------------
     {
-      h8 xf[2][KS_IN];
+      if (!RECOMP) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int ks = 0; ks < KS_IN; ++ks) {
-          const int k0 = 32 * ks + 8 * g;
-          uint4 u = make_uint4(0, 0, 0, 0);
-          if (ok[a] && k0 < IN_PAD) u = *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
-          xf[a][ks] = *reinterpret_cast<h8*>(&u);
-        }
+          for (int ks = 0; ks < KS_IN; ++ks) {
+            const int k0 = 32 * ks + 8 * g;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (ok[a] && k0 < IN_PAD) u = *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
+            xf[a][ks] = *reinterpret_cast<h8*>(&u);
+          }
+      }
 #pragma unroll
       for (int nt = COL_LO; nt < COL_HI; ++nt) {
         const h8 sel = (nt & 1) ? I1 : I0;
@@ -531,6 +594,20 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   int grid = grid_for((P + 31) / 32);
   if (grid > 512) grid = 512;  // each wave flushes a full dW with atomics: keep the wave count bounded
   bool done = false;
+  // act == null: the hidden activations are recomputed from x inside the kernel (narrow inputs only: the flow network)
+#define X(IT, NHH)                                                                                                   \
+  if (!done && !act && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                      \
+    L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
+               (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,           \
+               (half_t*)dx, grad_w, inv_loss_scale);                                                                 \
+    done = true;                                                                                                     \
+  }
+  X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3) X(8, 1)  // <6, 2> and wider / deeper spill registers: those keep their saved activations
+#undef X
+  if (!done && !act) {
+    l4d_set_error(1, "l4d_mlp_bwd: act == null (recompute the activations) is only built for in_pad <= 32 and (in_pad 128, 1 hidden layer)");
+    return 1;
+  }
 #define X(IT, NHH)                                                                                                   \
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,         \

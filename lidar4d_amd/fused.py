@@ -24,6 +24,7 @@ def _field_desc(model):
     arena = model.planes_encoder._arena()
     key = (f16.data_ptr(), arena.data_ptr())
     if getattr(model, "_fd_key", None) == key:
+        _refresh_pairs(model)
         return model._fd
     he, pe = model.hash_encoder, model.planes_encoder
     fd = FieldDesc()
@@ -41,8 +42,27 @@ def _field_desc(model):
     for i, v in enumerate(lay.off):
         fd.plane_off[i] = v
     fd.planes_cl = arena.data_ptr()
+    # pair-interleaved copies of the time-slice tables (both slices of a corner in one 16-byte load)
+    model._dyn_pairs, model._pairs_version = [], None
+    if fd.n_slices >= 2:
+        for p in range(3):
+            n_entries = he.hash_dynamic[p].hash_t[0].params.numel() // 4
+            buf = torch.empty(fd.n_slices - 1, n_entries, 8, dtype=torch.float16, device=f16.device)
+            model._dyn_pairs.append(buf)
+            fd.hash_dynamic_pairs[p] = buf.data_ptr()
     model._fd, model._fd_key = fd, key
+    _refresh_pairs(model)
     return fd
+
+
+def _refresh_pairs(model):
+    store = model._store
+    if not model._dyn_pairs or model._pairs_version == store.version16:
+        return
+    for p, buf in enumerate(model._dyn_pairs):
+        hd = model.hash_encoder.hash_dynamic[p]
+        ops.dyn_pairs_build([store.half(enc.params) for enc in hd.hash_t], buf)
+    model._pairs_version = store.version16
 
 
 def _field_grads(model, planes_grad_cl):
@@ -92,12 +112,14 @@ class RenderFn(torch.autograd.Function):
         # flow field (flow_field.py:113-130)
         fn = model.flow_net
         xf = ops.hashgrid_t_fwd(fn.grid_enc.meta, xt, (0, 1, 2), [store.half(fn.grid_enc.params)], t_dev, half_out=True)
-        flow16, act_f = ops.mlp_fwd(xf, _flow_w16(model), fn.n_hidden, save_act=train)
+        # hidden activations are only stored where the backward cannot recompute them from the input rows (ops.mlp_recompute_supported)
+        flow16, act_f = ops.mlp_fwd(xf, _flow_w16(model), fn.n_hidden, save_act=train and not ops.mlp_recompute_supported(xf.shape[1], fn.n_hidden))
 
         # density (lidar4d.py:139-188)
         fd = _field_desc(model)
         X = ops.density_encode_fwd(fd, xt, flow16, tinfo, model.sigma_net.in_pad)
-        h, act_s = ops.mlp_fwd(X, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers, save_act=train)
+        h, act_s = ops.mlp_fwd(X, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,
+                               save_act=train and not ops.mlp_recompute_supported(X.shape[1], model.sigma_net.n_hidden_layers))
         sigma = ops.sigma_from_h(h)
 
         # compositing + mask compaction (renderer.py:98-110)

@@ -14,6 +14,7 @@ def call(name, *args):
     _lib.call(name, *args)
 
 
+PLANE_ROWS_MIN_POINTS = 1 << 12           # below this the row build (a launch) costs more than the saved taps
 LDS_DYNHASH_MIN_POINTS = 1 << 15          # below this the per-sample direct-gather path wins (table fills dominate)
 BINNED_SCATTER_MIN_RECORDS = 1 << 16  # below this the global-atomic path is cheaper than two extra launches
 
@@ -181,6 +182,12 @@ def mlp_fwd(x16, weights16, n_hidden, save_act=True, n_rows=None, y=None, act=No
     return y, act
 
 
+def mlp_recompute_supported(in_pad, n_hidden):
+    """Shapes for which l4d_mlp_bwd can recompute the hidden activations itself (act = None): the forward then does not
+    store them."""
+    return (in_pad <= 32 and 1 <= n_hidden <= 3) or (in_pad == 128 and n_hidden == 1)
+
+
 def mlp_bwd(x16, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale, n_rows=None, want_dx=True, dx=None):
     _chk(x16, torch.float16, "x"), _chk(act, torch.float16, "act"), _chk(dy16, torch.float16, "dy")
     _chk(weights16, torch.float16, "weights"), _chk(grad_w, torch.float32, "grad_w"), _chk(n_rows, torch.int32, "n_rows")
@@ -307,7 +314,10 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
                                            field_desc.hash_dynamic[2].size[field_desc.hash_dynamic[2].n_levels - 1]) <= 8192:
         n_dyn = sum(field_desc.hash_dynamic[i].n_levels for i in range(3))
         scratch = torch.empty(n_dyn * P, dtype=torch.float16, device=xt.device)
-    call("l4d_density_encode_fwd", C.byref(field_desc), _p(xt), _p(flow16), _p(tinfo), P, _p(X), in_pad, _p(scratch), _stream())
+    rows = None
+    if P >= PLANE_ROWS_MIN_POINTS:  # time planes through per-call 1-D rows (two taps instead of four)
+        rows = torch.empty(_lib.lib().l4d_plane_rows_workspace(C.byref(field_desc)) // 4, dtype=torch.float32, device=xt.device)
+    call("l4d_density_encode_fwd", C.byref(field_desc), _p(xt), _p(flow16), _p(tinfo), P, _p(X), in_pad, _p(scratch), _p(rows), _stream())
     return X
 
 
@@ -381,3 +391,12 @@ def scaler_update(scaler_state, growth_factor=2.0, backoff_factor=0.5, growth_in
 def mark_time_slices(tinfo, n_slices, gates):
     _chk(tinfo, torch.float32, "tinfo"), _chk(gates, torch.float32, "gates")
     call("l4d_mark_time_slices", _p(tinfo), int(n_slices), _p(gates), _stream())
+
+
+def dyn_pairs_build(slice_tables16, pairs):
+    """pairs [n_slices - 1, n_entries, 8] fp16 <- pair-interleaved copy of one plane's time-slice tables."""
+    for tb in slice_tables16:
+        _chk(tb, torch.float16, "slice table")
+    _chk(pairs, torch.float16, "pairs")
+    n_entries = slice_tables16[0].numel() // 4
+    call("l4d_dyn_pairs_build", _ptrs(slice_tables16), len(slice_tables16), n_entries, _p(pairs), _stream())

@@ -48,6 +48,7 @@ class ParamStore:
         self.flat_grad = None
         self.flat16 = None
         self._key16 = None
+        self.version16 = 0  # bumped whenever the contents of the fp16 compute copy change (derived copies key on it)
         self.build()
 
     def build(self):
@@ -78,11 +79,13 @@ class ParamStore:
                 self.flat16 = torch.empty(self.numel, dtype=torch.float16, device=self.flat.device)
             ops.cast_f32_to_f16(self.flat, self.flat16)
             self._key16 = key
+            self.version16 += 1
         return self.flat16
 
     def mark16_current(self):
         """The caller has just written flat16 itself (Adam kernel emits the fp16 copy)."""
         self._key16 = self._key()
+        self.version16 += 1
 
     def half(self, param):
         off, n = self.by_param[id(param)]

@@ -25,6 +25,7 @@ int main(void) {
       (fn_t)&l4d_density_encode_bwd,
       (fn_t)&l4d_density_encode_bwd_workspace,
       (fn_t)&l4d_density_encode_fwd,
+      (fn_t)&l4d_dyn_pairs_build,
       (fn_t)&l4d_field_width,
       (fn_t)&l4d_freq_fwd,
       (fn_t)&l4d_grad_nonfinite_check,
@@ -43,6 +44,7 @@ int main(void) {
       (fn_t)&l4d_pano_to_lidar_workspace,
       (fn_t)&l4d_planes_bwd,
       (fn_t)&l4d_planes_fwd,
+      (fn_t)&l4d_plane_rows_workspace,
       (fn_t)&l4d_planes_relayout,
       (fn_t)&l4d_profile_count,
       (fn_t)&l4d_profile_enable,

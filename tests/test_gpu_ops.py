@@ -155,6 +155,30 @@ def test_mlp_fwd_bwd(n_in, n_out, n_hidden):
     rel_close(xg.grad, x.grad, rtol=2e-2, atol=2e-3 * x.grad.abs().max().item(), what="mlp dX")
 
 
+@pytest.mark.parametrize("in_pad,n_hidden", [(16, 2), (16, 3), (32, 1), (128, 1)])
+def test_mlp_bwd_recomputed_activations_equal_saved(in_pad, n_hidden):
+    """l4d_mlp_bwd with act = null recomputes the hidden activations from x with the forward chain: the same MFMAs in the
+    same order as the forward, so dx is bit-identical to the saved-activation path and dW differs by atomics order only."""
+    from lidar4d_amd import ops
+    assert ops.mlp_recompute_supported(in_pad, n_hidden) and not ops.mlp_recompute_supported(96, 2)
+    P = 70001  # ragged tail
+    w = (det_uniform((64 * in_pad + (n_hidden - 1) * 64 * 64 + 16 * 64,), f"rw{in_pad}", -0.3, 0.3)).half().to(DEV)
+    x = det_uniform((P, in_pad), "rx", -1, 1).half().to(DEV)
+    dy = det_uniform((P, 16), "rdy", -1, 1).half().to(DEV)
+    n = torch.tensor([P - 37], dtype=torch.int32, device=DEV)
+    y, act = ops.mlp_fwd(x, w, n_hidden, save_act=True, n_rows=n)
+    y2, none = ops.mlp_fwd(x, w, n_hidden, save_act=False, n_rows=n)
+    assert none is None and torch.equal(y[:P - 37], y2[:P - 37])
+    g1, g2 = torch.zeros(w.numel(), device=DEV), torch.zeros(w.numel(), device=DEV)
+    dx1 = ops.mlp_bwd(x, act, dy, w, n_hidden, g1, 1.0 / 128, n_rows=n)
+    dx2 = ops.mlp_bwd(x, None, dy, w, n_hidden, g2, 1.0 / 128, n_rows=n)
+    assert torch.equal(dx1[:P - 37], dx2[:P - 37])
+    assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max()) and float(g1.abs().max()) > 0
+    with pytest.raises(Exception):
+        ops.mlp_bwd(x[:, :16].contiguous().repeat(1, 6), None, dy, torch.zeros(64 * 96 + 64 * 64 + 16 * 64, device=DEV).half(), 2,
+                    torch.zeros(64 * 96 + 64 * 64 + 16 * 64, device=DEV), 1.0)
+
+
 def test_mlp_empty_and_row_count():
     from lidar4d_amd import ops
     w = torch.randn(64 * 96 + 64 * 64 + 16 * 64, device=DEV).half() * 0.1

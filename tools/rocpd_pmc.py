@@ -1,9 +1,40 @@
-"""Per-kernel sums/averages of the PMC counters in a rocprofv3 rocpd SQLite database."""
+"""Per-kernel sums/averages of the PMC counters in a rocprofv3 rocpd SQLite database.
+
+    python tools/rocpd_pmc.py results.db [--json out.json]
+
+--json: {kernel (demangled, as written at the launch site, e.g. "mlp_fwd_kernel<8, 1>"): {counter: {"launches": n, "sum": s}}}
+"""
+import json
+import re
+import shutil
 import sqlite3
+import subprocess
 import sys
 
 
-def main(path):
+def demangle(names):
+    filt = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        out = subprocess.run([filt], input="\n".join(n.replace(".kd", "") for n in names), capture_output=True, text=True, check=True).stdout.splitlines()
+    except Exception:
+        return {n: n for n in names}
+    res = {}
+    for n, d in zip(names, out):
+        d = re.sub(r"^void\s+", "", d.strip())
+        depth, cut = 0, len(d)
+        for i, ch in enumerate(d):  # cut the argument list: the first "(" outside template brackets
+            if ch == "<":
+                depth += 1
+            elif ch == ">":
+                depth -= 1
+            elif ch == "(" and depth == 0:
+                cut = i
+                break
+        res[n] = d[:cut]
+    return res
+
+
+def main(path, json_out=None):
     db = sqlite3.connect(path)
     cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -11,18 +42,22 @@ def main(path):
     ip = [t for t in tabs if t.startswith("rocpd_info_pmc")][0]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    cols_pe = [r[1] for r in cur.execute(f"pragma table_info({pe})")]
     cols_ip = [r[1] for r in cur.execute(f"pragma table_info({ip})")]
-    print("# pmc_event columns:", cols_pe)
-    print("# info_pmc columns:", cols_ip)
     name_col = "name" if "name" in cols_ip else cols_ip[1]
     q = (f"select s.kernel_name, p.{name_col}, count(distinct d.id), sum(e.value), sum(d.end - d.start) / count(distinct e.pmc_id) "
          f"from {pe} e join {ip} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id "
          f"group by s.kernel_name, p.{name_col} order by 4 desc")
-    print(f"{'kernel':64s} {'counter':12s} {'launches':>8s} {'sum':>14s} {'per_launch':>14s}")
-    for r in cur.execute(q).fetchall()[:200]:
-        print(f"{r[0][:64]:64s} {str(r[1]):12s} {r[2]:8d} {r[3]:14.4e} {r[3] / max(r[2], 1):14.4e}")
+    rows = cur.execute(q).fetchall()
+    names = demangle(sorted({r[0] for r in rows}))
+    print(f"{'kernel':56s} {'counter':28s} {'launches':>8s} {'sum':>14s} {'per_launch':>14s} {'kernel_ns/launch':>16s}")
+    for r in rows[:240]:
+        print(f"{names[r[0]][:56]:56s} {str(r[1]):28s} {r[2]:8d} {r[3]:14.4e} {r[3] / max(r[2], 1):14.4e} {r[4] / max(r[2], 1):16.0f}")
+    if json_out:
+        out = {}
+        for r in rows:
+            out.setdefault(names[r[0]], {})[str(r[1])] = {"launches": r[2], "sum": r[3], "kernel_ns": r[4]}
+        json.dump(out, open(json_out, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None)
