@@ -93,19 +93,34 @@ def kernel_models(model, P, M):
     lds_alg = 2 * 3 * (2 * L * 4 * 8)                                            # xz, yz stacks x 3 frames
     X = 2 * in_pad
     m = {}
-    m["density_encode_fwd_kernel<true>"] = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P,
-                                                note="planes + static hash + xy dynamic hash gathers; row staged in LDS, written once")
-    m["density_encode_fwd_kernel<false>"] = dict(bound="l2", bytes=(enc_alg + lds_alg) * P, hbm=(16 + 32 + X) * P, note="all gathers direct")
+    enc = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P,
+               note="planes + static hash + xy dynamic hash gathers (time planes via per-call 1-D rows, both time slices of a corner "
+                    "in one 16-B load); row staged in LDS, written once")
+    m["density_encode_fwd_kernel<true, true>"] = enc
+    m["density_encode_fwd_kernel<true, false>"] = enc
+    m["density_encode_fwd_kernel<false, false>"] = dict(bound="l2", bytes=(enc_alg + lds_alg) * P, hbm=(16 + 32 + X) * P, note="all gathers direct")
+    m["density_encode_fwd_kernel<false, true>"] = m["density_encode_fwd_kernel<false, false>"]
     m["dynhash_fwd_lds_kernel"] = dict(bound="lds", bytes=lds_alg * P, hbm=(2 * L * (16 + 16) + 2 * 2 * L) * P,
                                        note="xz / yz HashGridT stacks from LDS-resident slice tables; one streaming pass of xt / flow per (plane, level)")
-    m[f"hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="l2", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, note="flow grid + interpT")
-    for name, pad, nh, rows in ((f"<{in_pad // 16}, {nh_s}>", in_pad, nh_s, P), (f"<{a_pad // 16}, {nh_a}>", a_pad, nh_a, M),
-                                (f"<1, {model.flow_net.n_hidden}>", 16, model.flow_net.n_hidden, P)):
-        fl = 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
-        m["mlp_fwd_kernel" + name] = dict(bound="hbm", bytes=(2 * pad + 32 + nh * 128) * rows, flops=fl * rows, note="x + y + saved activations")
-        it = pad // 16
-        m[f"mlp_bwd_kernel<{it}, {nh}, 0, {it}, true>"] = dict(bound="hbm", bytes=(2 * pad + nh * 128 + 32 + 2 * pad) * rows, flops=2 * fl * rows,
-                                                             note="x + activations + dy read, dx written (algorithmic flops: dX + dW)")
+    m["hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="l2", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, note="flow grid + interpT")
+    fl = lambda pad, nh: 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
+    it_s, nf = in_pad // 16, model.flow_net.n_hidden
+    # sigma network: x + y + saved activations; backward also writes dx
+    m[f"mlp_fwd_kernel<{it_s}, {nh_s}>"] = dict(bound="hbm", bytes=(X + 32 + nh_s * 128) * P, flops=fl(in_pad, nh_s) * P, note="x + y + saved activations")
+    m[f"mlp_bwd_kernel<{it_s}, {nh_s}, 0, {it_s}, true>"] = dict(bound="hbm", bytes=(X + nh_s * 128 + 32 + X) * P, flops=2 * fl(in_pad, nh_s) * P,
+                                                               note="x + activations + dy read, dx written (algorithmic flops: dX + dW)")
+    # flow network: activations are recomputed in the backward, not stored
+    m[f"mlp_fwd_kernel<1, {nf}>"] = dict(bound="hbm", bytes=(32 + 32) * P, flops=fl(16, nf) * P, note="x in, y out (no activations stored)")
+    m[f"mlp_bwd_kernel<1, {nf}, 0, 1, true, true>"] = dict(bound="hbm", bytes=(32 + 32 + 32) * P, flops=3 * fl(16, nf) * P,
+                                                         note="x + dy read, dx written; activations recomputed (algorithmic flops: fwd + dX + dW)")
+    # attribute networks on the work list: rows assembled in the kernel (index + sigma-net output row), geo-feature gradient only
+    it_a = a_pad // 16
+    m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true>"] = dict(bound="hbm", bytes=(4 + 32 + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M,
+                                                      note="idx + h row in (direction encoding per ray: cache resident), y + activations out")
+    m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, false, true, 4>"] = dict(bound="hbm", bytes=(4 + 32 + nh_a * 128 + 32 + 64) * M,
+                                                                               flops=2 * fl(a_pad, nh_a) * M, note="idx + h row + activations + dy in, 32 gradient columns out")
+    m[f"mlp_fwd_kernel<{it_a}, {nh_a}>"] = dict(bound="hbm", bytes=(2 * a_pad + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M, note="materialised input rows")
+    m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true>"] = dict(bound="hbm", bytes=(4 * a_pad + nh_a * 128 + 32) * M, flops=2 * fl(a_pad, nh_a) * M, note="materialised input rows")
     rec = 8 * 12  # one 12-byte record per corner (upper bound: equal-cell runs along a ray are merged first)
     m["bin_pass1_kernel<3, 4>"] = dict(bound="hbm", bytes=(16 + 8 * L + L * rec) * P, note="static grid: xt + dX columns read, sorted records written (upper bound)")
     m["bin_pass2_kernel<3, 4>"] = dict(bound="hbm", bytes=L * rec * P, note="static grid: records read, segments reduced in LDS")

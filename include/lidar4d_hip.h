@@ -129,8 +129,8 @@ int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad,
 /* dy [P,16] fp16 (already multiplied by the caller's loss scale); dx [P, in_pad] fp16 or null;
  * grad_w fp32, same layout as weights, ACCUMULATED with 1/loss_scale applied.
  * act: the forward's saved activations, or null = recompute them from x inside the kernel (saves 128 B/row/layer of HBM
- * traffic twice; built for in_pad <= 32 with 1-3 hidden layers and for in_pad 128 with one hidden layer -- wider / deeper
- * shapes would spill registers and return an error). */
+ * traffic twice; built for in_pad <= 32 with 1-3 hidden layers -- measured neutral at in_pad 128, and wider / deeper shapes
+ * would spill registers: those return an error). */
 int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64_t P, const int32_t* n_rows, int32_t in_pad,
                 int32_t n_hidden, const void* weights, void* dx, float* grad_w, float inv_loss_scale, void* stream);
 
@@ -175,6 +175,17 @@ int l4d_attr_scatter_bwd(const int32_t* idx, const int32_t* count, int64_t cap, 
 int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int64_t cap, const void* dxa_raydrop,
                         const void* dxa_intensity, int32_t in_pad, int32_t n_enc, int32_t n_geo, void* dh,
                         void* stream);
+/* The attribute networks straight on the work list: l4d_mlp_fwd / l4d_mlp_bwd whose input row j is assembled in the kernel from
+ * dir_enc[idx[j] / T] (n_enc columns), h[idx[j]][1 .. n_geo] and ones (the row l4d_attr_gather would write), so the
+ * [cap, in_pad] matrix never exists.  in_pad = 96, 64 <= n_enc < 80.  bwd: dx_tail [cap, in_pad - 64] fp16 <- the input
+ * gradient's columns 64 .. in_pad - 1 (the tiles that hold the geo features; the direction encoding has no trainable input):
+ * feed it to l4d_attr_gather_bwd with in_pad = in_pad - 64, n_enc = n_enc - 64. */
+int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
+                     const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* weights, void* y, void* act,
+                     void* stream);
+int l4d_attr_mlp_bwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
+                     const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* act, const void* dy,
+                     const void* weights, void* dx_tail, float* grad_w, float inv_loss_scale, void* stream);
 /* sigma = trunc_exp(h[:,0]) (model/activation.py:6-20) on the sigma net's fp16 output h [P,16], and its
  * adjoint dh[:,0] = d_sigma * exp(clamp(h0,-15,15)) * loss_scale (fp16) */
 int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* stream);

@@ -26,6 +26,9 @@
 #ifndef BS_GROUP
 #define BS_GROUP 8
 #endif
+#ifndef BS_UNROLL
+#define BS_UNROLL 1
+#endif
 
 template <int NV>
 struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
@@ -221,21 +224,49 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   // then its records): small groups = many independent chains in flight, which is what hides that latency
   constexpr int NGRP = 1024 / BS_GROUP;
   const int grp = threadIdx.x / BS_GROUP, l16 = threadIdx.x % BS_GROUP;
-  for (int w = grp; w < n_wg; w += NGRP) {
-    const uint64_t slot = (uint64_t)lvl * n_wg + w;
-    const uint16_t* o = offs + slot * (BS_MAX_BINS + 1);
-    const uint32_t s0 = o[b], s1 = o[b + 1];
-    const uint32_t* rec = bins + slot * (uint64_t)(BS_THREADS * NC * NW);
-    for (uint32_t r = s0 + l16; r < s1; r += BS_GROUP) {
-      const uint32_t key = rec[r * NW] - lo;
-      uint32_t wd[NW - 1];
+  auto add = [&](uint32_t key, const uint32_t* wd) {
+    const half_t* hv = reinterpret_cast<const half_t*>(wd);
 #pragma unroll
-      for (int q = 0; q < NW - 1; ++q) wd[q] = rec[r * NW + 1 + q];
-      const half_t* hv = reinterpret_cast<const half_t*>(wd);
+    for (int j = 0; j < NV; ++j) {
+      const float v = h2f(hv[j]);
+      if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(key - lo) * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
+    }
+  };
+  // BS_UNROLL runs (pass-1 workgroups) per group and iteration: their offset loads, and then the first record of each, are
+  // in flight together -- the walk is a chain of dependent loads (offsets -> records) and is bound by their latency
+  for (int w0 = grp; w0 < n_wg; w0 += NGRP * BS_UNROLL) {
+    uint32_t s0[BS_UNROLL], s1[BS_UNROLL];
+    const uint32_t* rec[BS_UNROLL];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const float v = h2f(hv[j]);
-        if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[key * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
+    for (int u = 0; u < BS_UNROLL; ++u) {
+      const int w = w0 + u * NGRP;
+      const uint64_t slot = (uint64_t)lvl * n_wg + (w < n_wg ? w : w0);
+      const uint16_t* o = offs + slot * (BS_MAX_BINS + 1);
+      s0[u] = o[b];
+      s1[u] = w < n_wg ? (uint32_t)o[b + 1] : s0[u];  // past the end: an empty run
+      rec[u] = bins + slot * (uint64_t)(BS_THREADS * NC * NW);
+    }
+    uint32_t key0[BS_UNROLL], wd0[BS_UNROLL][NW - 1];
+#pragma unroll
+    for (int u = 0; u < BS_UNROLL; ++u) {
+      const uint32_t r = s0[u] + l16;
+      key0[u] = lo;
+#pragma unroll
+      for (int q = 0; q < NW - 1; ++q) wd0[u][q] = 0u;
+      if (r < s1[u]) {
+        key0[u] = rec[u][r * NW];
+#pragma unroll
+        for (int q = 0; q < NW - 1; ++q) wd0[u][q] = rec[u][r * NW + 1 + q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BS_UNROLL; ++u) {
+      add(key0[u], wd0[u]);  // an absent record carries zeros: no atomics issued
+      for (uint32_t r = s0[u] + l16 + BS_GROUP; r < s1[u]; r += BS_GROUP) {
+        uint32_t wd[NW - 1];
+#pragma unroll
+        for (int q = 0; q < NW - 1; ++q) wd[q] = rec[u][r * NW + 1 + q];
+        add(rec[u][r * NW], wd);
       }
     }
   }

@@ -75,14 +75,42 @@ __device__ __forceinline__ h8 relu_pack(const f4& lo, const f4& hi) {
 
 __device__ __forceinline__ float clamp_h(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
 
+// Input rows of the attribute networks assembled on the fly (model/lidar4d.py:196-213: row j of the work list =
+// [frequency encoding of the ray direction (n_enc) | geo_feat of sample idx[j] = h[:, 1 : 1 + n_geo] | ones]) instead of
+// being materialised as a [rows, in_pad] matrix that is written once and read four times (two networks, forward and backward).
+struct AttrSrc {
+  const int32_t* idx;   // work list (null: row j is sample j)
+  const half_t* denc;   // [rays, n_enc] fp16, n_enc a multiple of 8
+  const half_t* h;      // [samples, 16] fp16 sigma-network output
+  int T, n_enc, n_geo;
+};
+// columns k0 .. k0 + 7 of the row of sample p (k0 a multiple of 8)
+__device__ __forceinline__ uint4 attr_chunk(const AttrSrc& s, int64_t p, int k0) {
+  const int64_t ray = p / s.T;
+  if (k0 + 8 <= s.n_enc) return *reinterpret_cast<const uint4*>(s.denc + ray * s.n_enc + k0);
+  half_t hrow[16];
+  *reinterpret_cast<uint4*>(hrow) = *reinterpret_cast<const uint4*>(s.h + p * 16);
+  *reinterpret_cast<uint4*>(hrow + 8) = *reinterpret_cast<const uint4*>(s.h + p * 16 + 8);
+  half_t v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int gcol = 1 + (k0 + e - s.n_enc);  // column of h that holds this geo feature
+    half_t t = (half_t)1.0f;                  // padding columns carry 1.0 (tiny-cuda-nn pads the network input with ones)
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t = (gcol == q && q <= s.n_geo) ? hrow[q] : t;  // register select: no dynamic indexing
+    v[e] = t;
+  }
+  return *reinterpret_cast<uint4*>(v);
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
 // weight layout (fp16): W1 [64, in_pad], (NH-1) x [64, 64], Wo [16, 64]
-template <int IN_TILES, int NH>
+template <int IN_TILES, int NH, bool GATHER = false>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__ x, int64_t cap, const int32_t* __restrict__ n_rows,
                                                      const half_t* __restrict__ weights, half_t* __restrict__ y,
-                                                     half_t* __restrict__ act) {
+                                                     half_t* __restrict__ act, AttrSrc src) {
   // cap = rows the buffers were sized for (stride of the act planes); P = rows actually present
   const int64_t P = n_rows ? min((int64_t)*n_rows, cap) : cap;
   constexpr int IN_PAD = IN_TILES * 16;
@@ -116,13 +144,14 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t row = tile * 16 + i;
     const bool ok = row < P;
+    const int64_t psrc = (GATHER && ok) ? (src.idx ? (int64_t)src.idx[row] : row) : 0;
     // input fragments
     h8 xb[KS_IN];
 #pragma unroll
     for (int ks = 0; ks < KS_IN; ++ks) {
       const int k0 = 32 * ks + 8 * g;
       uint4 u = make_uint4(0, 0, 0, 0);
-      if (ok && k0 < IN_PAD) u = *reinterpret_cast<const uint4*>(x + row * IN_PAD + k0);
+      if (ok && k0 < IN_PAD) u = GATHER ? attr_chunk(src, psrc, k0) : *reinterpret_cast<const uint4*>(x + row * IN_PAD + k0);
       xb[ks] = *reinterpret_cast<h8*>(&u);
     }
     // layer 1
@@ -193,12 +222,15 @@ struct BwdFrags {
 // RECOMP: the hidden activations are not read from `act` but recomputed from x with the forward chain (forward weight
 // fragments in LDS as well): trades 128 B/row/layer of HBM traffic (written by the forward, read here) for 4 KS_IN + 8 (NH-1)
 // MFMAs per 16 rows.  Used where the activations dominate the traffic (the flow network: 32-byte rows, 256 B of activations).
-template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST, bool RECOMP = false>
+// GATHER: x rows come from AttrSrc; DX_LO: dx is produced only for the column tiles DX_LO .. COL_HI - 1 and stored compactly
+// as [rows, (COL_HI - DX_LO) * 16] (the attribute networks need the gradient of their geo_feat columns only: the direction
+// encoding has no trainable input).
+template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST, bool RECOMP = false, bool GATHER = false, int DX_LO = COL_LO>
 __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
                                                      const half_t* __restrict__ dy, int64_t cap,
                                                      const int32_t* __restrict__ n_rows,
                                                      const half_t* __restrict__ weights, half_t* __restrict__ dx,
-                                                     float* __restrict__ grad_w, float inv_scale) {
+                                                     float* __restrict__ grad_w, float inv_scale, AttrSrc src) {
   const int64_t P = n_rows ? min((int64_t)*n_rows, cap) : cap;
   using L = BwdFrags<IN_TILES, NH>;
   constexpr int IN_PAD = IN_TILES * 16;
@@ -274,6 +306,12 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       rows[a] = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
       ok[a] = rows[a] < P;
     }
+    int64_t psrc[2] = {0, 0};
+    if (GATHER) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        if (ok[a]) psrc[a] = src.idx ? (int64_t)src.idx[rows[a]] : rows[a];
+    }
     // ---- (RECOMP) forward chain from x: hidden activations of every layer, chain layout [layer][a][ks] ----
     h8 xf[2][KS_IN];
     h8 hrec[RECOMP ? NH : 1][2][2];
@@ -284,7 +322,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
         for (int ks = 0; ks < KS_IN; ++ks) {
           const int k0 = 32 * ks + 8 * g;
           uint4 u = make_uint4(0, 0, 0, 0);
-          if (ok[a] && k0 < IN_PAD) u = *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
+          if (ok[a] && k0 < IN_PAD) u = GATHER ? attr_chunk(src, psrc[a], k0) : *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
           xf[a][ks] = *reinterpret_cast<h8*>(&u);
         }
         f4 acc[4];
@@ -479,7 +517,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
           for (int ks = 0; ks < KS_IN; ++ks) {
             const int k0 = 32 * ks + 8 * g;
             uint4 u = make_uint4(0, 0, 0, 0);
-            if (ok[a] && k0 < IN_PAD) u = *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
+            if (ok[a] && k0 < IN_PAD) u = GATHER ? attr_chunk(src, psrc[a], k0) : *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
             xf[a][ks] = *reinterpret_cast<h8*>(&u);
           }
       }
@@ -498,17 +536,19 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
         for (int mt = 0; mt < 4; ++mt) dW1[mt][nt - COL_LO] = MFMA(dzT[mt], xT, dW1[mt][nt - COL_LO]);
       }
       if (dx) {
+        constexpr int DX_PITCH = DX_LO == COL_LO ? IN_PAD : (COL_HI - DX_LO) * 16;  // full rows, or only the tiles from DX_LO on
+        constexpr int DX_T0 = DX_LO == COL_LO ? 0 : DX_LO;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int mt = COL_LO; mt < COL_HI; ++mt) {
+          for (int mt = DX_LO; mt < COL_HI; ++mt) {
             f4 c = MFMA(FR(L::W1T + mt * 2 + 0), dzf[a][0], (f4{0, 0, 0, 0}));
             c = MFMA(FR(L::W1T + mt * 2 + 1), dzf[a][1], c);
             if (ok[a]) {
               h4 ov;
 #pragma unroll
               for (int r = 0; r < 4; ++r) ov[r] = f2h_grad(c[r]);
-              *reinterpret_cast<h4*>(dx + rows[a] * IN_PAD + 16 * mt + 4 * g) = ov;
+              *reinterpret_cast<h4*>(dx + rows[a] * DX_PITCH + 16 * (mt - DX_T0) + 4 * g) = ov;
             }
           }
       }
@@ -572,7 +612,7 @@ extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int3
 #define X(IT, NHH)                                                                                                   \
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_fwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, P, \
-                       n_rows, (const half_t*)weights, (half_t*)y, (half_t*)act);                                           \
+                       n_rows, (const half_t*)weights, (half_t*)y, (half_t*)act, AttrSrc{});                                \
     done = true;                                                                                                     \
   }
   FOR_EACH_CFG(X)
@@ -599,20 +639,20 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (!done && !act && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                      \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
                (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,           \
-               (half_t*)dx, grad_w, inv_loss_scale);                                                                 \
+               (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{});                                                      \
     done = true;                                                                                                     \
   }
-  X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3) X(8, 1)  // <6, 2> and wider / deeper spill registers: those keep their saved activations
+  X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3)  // <8, 1>: measured neutral; <6, 2> and wider / deeper spill registers
 #undef X
   if (!done && !act) {
-    l4d_set_error(1, "l4d_mlp_bwd: act == null (recompute the activations) is only built for in_pad <= 32 and (in_pad 128, 1 hidden layer)");
+    l4d_set_error(1, "l4d_mlp_bwd: act == null (recompute the activations) is only built for in_pad <= 32");
     return 1;
   }
 #define X(IT, NHH)                                                                                                   \
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,         \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale);                                                         \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{});                                              \
     done = true;                                                                                                     \
   }
   FOR_EACH_CFG(X)
@@ -621,10 +661,10 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, 6, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale);                                                         \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{});                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 6, IT, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale);                                                         \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{});                                              \
     done = true;                                                                                                     \
   }
   FOR_EACH_WIDE_CFG(X)
@@ -634,5 +674,54 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
     return 1;
   }
   L4D_LAUNCH_CHECK("l4d_mlp_bwd");
+  return 0;
+}
+
+// ---- attribute networks on a work list, input rows assembled in the kernel (AttrSrc) ------------------------------------
+static int attr_src(const int32_t* idx, int32_t T, const void* dir_enc, int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad,
+                    AttrSrc& s, const char* where) {
+  if (in_pad != 96 || n_enc % 8 || n_enc / 16 != 4 || n_enc + n_geo > in_pad || n_geo > 15 || T <= 0) {
+    l4d_set_error(1, where);
+    return 1;
+  }
+  s.idx = idx; s.denc = (const half_t*)dir_enc; s.h = (const half_t*)h; s.T = T; s.n_enc = n_enc; s.n_geo = n_geo;
+  return 0;
+}
+
+extern "C" int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
+                                const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* weights, void* y,
+                                void* act, void* stream) {
+  if (cap == 0) return 0;
+  AttrSrc src;
+  if (attr_src(idx, T, dir_enc, n_enc, h, n_geo, in_pad, src, "l4d_attr_mlp_fwd: needs in_pad 96, 64 <= n_enc < 80 (multiple of 8), n_geo <= 15")) return 1;
+  const int grid = grid_for((cap + 15) / 16);
+#define X(NHH)                                                                                                         \
+  if (n_hidden == NHH)                                                                                                 \
+    L4D_LAUNCH((mlp_fwd_kernel<6, NHH, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)nullptr, cap, count, \
+               (const half_t*)weights, (half_t*)y, (half_t*)act, src);
+  X(1) X(2) X(3)
+#undef X
+  if (n_hidden < 1 || n_hidden > 3) { l4d_set_error(1, "l4d_attr_mlp_fwd: n_hidden in 1..3"); return 1; }
+  L4D_LAUNCH_CHECK("l4d_attr_mlp_fwd");
+  return 0;
+}
+
+extern "C" int l4d_attr_mlp_bwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
+                                const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* act, const void* dy,
+                                const void* weights, void* dx_tail, float* grad_w, float inv_loss_scale, void* stream) {
+  if (cap == 0) return 0;
+  AttrSrc src;
+  if (attr_src(idx, T, dir_enc, n_enc, h, n_geo, in_pad, src, "l4d_attr_mlp_bwd: needs in_pad 96, 64 <= n_enc < 80 (multiple of 8), n_geo <= 15")) return 1;
+  int grid = grid_for((cap + 31) / 32);
+  if (grid > 512) grid = 512;
+#define X(NHH)                                                                                                          \
+  if (n_hidden == NHH)                                                                                                  \
+    L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, true, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,     \
+               (const half_t*)nullptr, (const half_t*)act, (const half_t*)dy, cap, count, (const half_t*)weights,       \
+               (half_t*)dx_tail, grad_w, inv_loss_scale, src);
+  X(1) X(2) X(3)
+#undef X
+  if (n_hidden < 1 || n_hidden > 3) { l4d_set_error(1, "l4d_attr_mlp_bwd: n_hidden in 1..3"); return 1; }
+  L4D_LAUNCH_CHECK("l4d_attr_mlp_bwd");
   return 0;
 }

@@ -129,9 +129,17 @@ class RenderFn(torch.autograd.Function):
         # attribute (lidar4d.py:191-223) on the compacted work list
         denc = ops.freq_fwd(((rays_d + 1) / 2).contiguous(), model.view_encoder.n_frequencies)
         an = model.intensity_net
-        XA = ops.attr_gather(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad)
-        yR, actR = ops.mlp_fwd(XA, store.half(model.raydrop_net.params), an.n_hidden_layers, save_act=train, n_rows=count)
-        yI, actI = ops.mlp_fwd(XA, store.half(model.intensity_net.params), an.n_hidden_layers, save_act=train, n_rows=count)
+        gathered = ops.attr_mlp_supported(an.in_pad, denc.shape[1], model.geo_feat_dim)
+        if gathered:  # the networks assemble their input rows themselves: no [rows, 96] matrix (written once, read four times)
+            XA = None
+            yR, actR = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.raydrop_net.params),
+                                        an.n_hidden_layers, save_act=train)
+            yI, actI = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.intensity_net.params),
+                                        an.n_hidden_layers, save_act=train)
+        else:
+            XA = ops.attr_gather(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad)
+            yR, actR = ops.mlp_fwd(XA, store.half(model.raydrop_net.params), an.n_hidden_layers, save_act=train, n_rows=count)
+            yI, actI = ops.mlp_fwd(XA, store.half(model.intensity_net.params), an.n_hidden_layers, save_act=train, n_rows=count)
         attr = torch.zeros(P, 2, dtype=torch.float32, device=dev)
         attr_c = torch.empty(P, 2, dtype=torch.float32, device=dev)
         ops.attr_scatter(idx, count, P, yR, yI, attr, attr_c)
@@ -140,7 +148,7 @@ class RenderFn(torch.autograd.Function):
         if train:
             ctx.model, ctx.T, ctx.sample_dist = model, T, sample_dist
             ctx.save_for_backward(t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count,
-                                  XA, actR, actI, attr, attr_c)
+                                  XA, actR, actI, attr, attr_c, denc)
         ctx.mark_non_differentiable(z_vals, idx, count)
         return depth, image, wsum, weights, z_vals, idx, count
 
@@ -149,7 +157,7 @@ class RenderFn(torch.autograd.Function):
     def backward(ctx, d_depth, d_image, d_wsum, d_weights, _dz, _di, _dc):
         model, T, sample_dist = ctx.model, ctx.T, ctx.sample_dist
         (t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count, XA, actR, actI, attr,
-         attr_c) = ctx.saved_tensors
+         attr_c, denc) = ctx.saved_tensors
         store = model._store
         store.prepare_grads()
         # the current frame's time-slice pair is what receives dynamic-hash gradients (hash_field.py:79-85): raise its
@@ -168,12 +176,20 @@ class RenderFn(torch.autograd.Function):
         dyR = torch.empty(P, 16, dtype=torch.float16, device=dev)
         dyI = torch.empty(P, 16, dtype=torch.float16, device=dev)
         ops.attr_scatter_bwd(idx, count, P, d_attr, attr_c, ls, dyR, dyI)
-        dxaR = ops.mlp_bwd(XA, actR, dyR, store.half(model.raydrop_net.params), an.n_hidden_layers,
-                           store.grad_view(model.raydrop_net.params), inv, n_rows=count)
-        dxaI = ops.mlp_bwd(XA, actI, dyI, store.half(model.intensity_net.params), an.n_hidden_layers,
-                           store.grad_view(model.intensity_net.params), inv, n_rows=count)
         dh = torch.zeros(P, 16, dtype=torch.float16, device=dev)
-        ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad, model.view_encoder.n_output_dims, model.geo_feat_dim, dh)
+        n_enc = model.view_encoder.n_output_dims
+        if XA is None:  # gathered inputs; only the input gradient's tail (the tiles holding geo_feat) is produced
+            dxaR = ops.attr_mlp_bwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, actR, dyR, store.half(model.raydrop_net.params),
+                                    an.n_hidden_layers, store.grad_view(model.raydrop_net.params), inv)
+            dxaI = ops.attr_mlp_bwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, actI, dyI, store.half(model.intensity_net.params),
+                                    an.n_hidden_layers, store.grad_view(model.intensity_net.params), inv)
+            ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad - 64, n_enc - 64, model.geo_feat_dim, dh)
+        else:
+            dxaR = ops.mlp_bwd(XA, actR, dyR, store.half(model.raydrop_net.params), an.n_hidden_layers,
+                               store.grad_view(model.raydrop_net.params), inv, n_rows=count)
+            dxaI = ops.mlp_bwd(XA, actI, dyI, store.half(model.intensity_net.params), an.n_hidden_layers,
+                               store.grad_view(model.intensity_net.params), inv, n_rows=count)
+            ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad, n_enc, model.geo_feat_dim, dh)
         ops.sigma_bwd(h, d_sigma.view(-1), ls, dh)
         # sigma network
         dX = ops.mlp_bwd(X, act_s, dh, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,

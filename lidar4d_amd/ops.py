@@ -183,9 +183,11 @@ def mlp_fwd(x16, weights16, n_hidden, save_act=True, n_rows=None, y=None, act=No
 
 
 def mlp_recompute_supported(in_pad, n_hidden):
-    """Shapes for which l4d_mlp_bwd can recompute the hidden activations itself (act = None): the forward then does not
-    store them."""
-    return (in_pad <= 32 and 1 <= n_hidden <= 3) or (in_pad == 128 and n_hidden == 1)
+    """Shapes for which l4d_mlp_bwd recomputes the hidden activations itself (act = None), so that the forward does not store
+    them: narrow inputs (the flow network: 32-byte rows against 256 B of activations; measured forward 1.11 -> 0.33 ms,
+    backward 1.64 -> 1.41 ms at 12.6 M rows).  For the 128-wide sigma network the same trade was measured neutral (forward
+    0.91 -> 0.67 ms, backward 1.93 -> 2.13 ms) and wider / deeper shapes spill registers, so those keep their activations."""
+    return in_pad <= 32 and 1 <= n_hidden <= 3
 
 
 def mlp_bwd(x16, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale, n_rows=None, want_dx=True, dx=None):
@@ -267,6 +269,30 @@ def attr_gather(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, xa=None):
     call("l4d_attr_gather", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, _p(xa), in_pad,
          _stream())
     return xa
+
+
+def attr_mlp_supported(in_pad, n_enc, n_geo):
+    return in_pad == 96 and n_enc % 8 == 0 and n_enc // 16 == 4 and n_enc + n_geo <= in_pad and n_geo <= 15
+
+
+def attr_mlp_fwd(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, weights16, n_hidden, save_act=True):
+    """Attribute network on the compacted work list without materialising its input matrix -> y [cap,16] (+ act)."""
+    _chk(idx, torch.int32, "idx"), _chk(count, torch.int32, "count"), _chk(dir_enc16, torch.float16, "dir_enc")
+    _chk(h16, torch.float16, "h"), _chk(weights16, torch.float16, "weights")
+    y = torch.empty(cap, 16, dtype=torch.float16, device=h16.device)
+    act = torch.empty(n_hidden, cap, 64, dtype=torch.float16, device=h16.device) if save_act else None
+    call("l4d_attr_mlp_fwd", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad, n_hidden,
+         _p(weights16), _p(y), _p(act), _stream())
+    return y, act
+
+
+def attr_mlp_bwd(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale):
+    """-> dx_tail [cap, in_pad - 64] fp16: the input gradient's columns 64 .. in_pad - 1 (geo features at n_enc - 64 ..)."""
+    _chk(act, torch.float16, "act"), _chk(dy16, torch.float16, "dy"), _chk(grad_w, torch.float32, "grad_w")
+    dx = torch.empty(cap, in_pad - 64, dtype=torch.float16, device=h16.device)
+    call("l4d_attr_mlp_bwd", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad, n_hidden,
+         _p(act), _p(dy16), _p(weights16), _p(dx), _p(grad_w), float(inv_loss_scale), _stream())
+    return dx
 
 
 def attr_scatter(idx, count, cap, y_raydrop, y_intensity, attr_dense, attr_compact):

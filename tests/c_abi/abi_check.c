@@ -13,6 +13,8 @@ int main(void) {
       (fn_t)&l4d_adam_step_ranges,
       (fn_t)&l4d_attr_gather,
       (fn_t)&l4d_attr_gather_bwd,
+      (fn_t)&l4d_attr_mlp_bwd,
+      (fn_t)&l4d_attr_mlp_fwd,
       (fn_t)&l4d_attr_scatter,
       (fn_t)&l4d_attr_scatter_bwd,
       (fn_t)&l4d_cast_f32_to_f16,

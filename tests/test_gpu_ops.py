@@ -155,7 +155,7 @@ def test_mlp_fwd_bwd(n_in, n_out, n_hidden):
     rel_close(xg.grad, x.grad, rtol=2e-2, atol=2e-3 * x.grad.abs().max().item(), what="mlp dX")
 
 
-@pytest.mark.parametrize("in_pad,n_hidden", [(16, 2), (16, 3), (32, 1), (128, 1)])
+@pytest.mark.parametrize("in_pad,n_hidden", [(16, 2), (16, 3), (32, 1)])
 def test_mlp_bwd_recomputed_activations_equal_saved(in_pad, n_hidden):
     """l4d_mlp_bwd with act = null recomputes the hidden activations from x with the forward chain: the same MFMAs in the
     same order as the forward, so dx is bit-identical to the saved-activation path and dW differs by atomics order only."""
@@ -292,3 +292,44 @@ def test_chamfer_fwd_bwd(b, n, m):
         assert torch.equal(d1[0, sel], ref.values) and torch.equal(i1[0, sel].long(), ref.indices)
         s1, s2, k1, _ = chamfer_3DDist()(ag, ag)
         assert float(s1.abs().max()) == 0.0 and torch.equal(k1[0].long().cpu(), torch.arange(n))
+
+
+def test_attr_mlp_gathered_equals_materialised():
+    """l4d_attr_mlp_fwd / _bwd (input rows assembled in the kernel from the direction encoding, the sigma network's output and
+    ones) against l4d_attr_gather + l4d_mlp_fwd / _bwd on the materialised [rows, 96] matrix: same MFMAs on the same
+    operands -> bit-identical outputs, activations and geo-feature gradients; dW up to atomics order."""
+    from lidar4d_amd import ops
+    n_rays, T, n_geo, in_pad = 37, 64, 15, 96
+    P = n_rays * T
+    dirs = torch.nn.functional.normalize(det_uniform((n_rays, 3), "gad", -1, 1), dim=-1).to(DEV)
+    denc = ops.freq_fwd(((dirs + 1) / 2).contiguous(), 12)
+    h = det_uniform((P, 16), "gah", -1, 1).half().to(DEV)
+    keep = det_uniform((P,), "gak", 0, 1) > 0.6
+    idx_host = torch.nonzero(keep).reshape(-1).to(torch.int32)
+    idx_host = idx_host[torch.randperm(idx_host.numel(), generator=torch.Generator().manual_seed(1))]  # arrival order is arbitrary
+    M = idx_host.numel()
+    idx = torch.zeros(P, dtype=torch.int32, device=DEV)
+    idx[:M] = idx_host.to(DEV)
+    count = torch.tensor([M], dtype=torch.int32, device=DEV)
+    for n_hidden in (1, 2):
+        w = det_uniform((64 * in_pad + (n_hidden - 1) * 64 * 64 + 16 * 64,), f"gaw{n_hidden}", -0.3, 0.3).half().to(DEV)
+        assert ops.attr_mlp_supported(in_pad, denc.shape[1], n_geo)
+        xa = ops.attr_gather(idx, count, P, T, denc, h, n_geo, in_pad)
+        y0, act0 = ops.mlp_fwd(xa, w, n_hidden, save_act=True, n_rows=count)
+        y1, act1 = ops.attr_mlp_fwd(idx, count, P, T, denc, h, n_geo, in_pad, w, n_hidden, save_act=True)
+        assert torch.equal(y0[:M], y1[:M]) and torch.equal(act0[:, :M], act1[:, :M])
+        dy = torch.zeros(P, 16, dtype=torch.float16, device=DEV)
+        dy[:, 0] = det_uniform((P,), "gady", -1, 1).half().to(DEV)
+        g0, g1 = torch.zeros(w.numel(), device=DEV), torch.zeros(w.numel(), device=DEV)
+        dx0 = ops.mlp_bwd(xa, act0, dy, w, n_hidden, g0, 1.0 / 128, n_rows=count)
+        dx1 = ops.attr_mlp_bwd(idx, count, P, T, denc, h, n_geo, in_pad, act1, dy, w, n_hidden, g1, 1.0 / 128)
+        assert dx1.shape == (P, 32) and torch.equal(dx0[:M, 64:], dx1[:M])
+        assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max()) and float(g0.abs().max()) > 0
+        dh0, dh1 = torch.zeros(P, 16, dtype=torch.float16, device=DEV), torch.zeros(P, 16, dtype=torch.float16, device=DEV)
+        ops.attr_gather_bwd(idx, count, P, dx0, dx0, in_pad, denc.shape[1], n_geo, dh0)
+        ops.attr_gather_bwd(idx, count, P, dx1, dx1, in_pad - 64, denc.shape[1] - 64, n_geo, dh1)
+        assert torch.equal(dh0, dh1) and float(dh0.abs().max()) > 0
+    # empty work list
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)
+    y, _ = ops.attr_mlp_fwd(idx, zero, P, T, denc, h, n_geo, in_pad, w, 2, save_act=False)
+    assert y.shape == (P, 16)
