@@ -174,18 +174,23 @@ int l4d_attr_scatter_bwd(const int32_t* idx, const int32_t* count, int64_t cap, 
  * columns); column 0 of those rows is written as 0 -- call l4d_sigma_bwd AFTER this to fill it. */
 int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int64_t cap, const void* dxa_raydrop,
                         const void* dxa_intensity, int32_t in_pad, int32_t n_enc, int32_t n_geo, void* dh,
+                        int32_t h_layout /*0; 1: columns n_enc .. n_enc + 15 are ordered [-, g0 .. g14] (l4d_attr_mlp_bwd)*/,
                         void* stream);
-/* The attribute networks straight on the work list: l4d_mlp_fwd / l4d_mlp_bwd whose input row j is assembled in the kernel from
- * dir_enc[idx[j] / T] (n_enc columns), h[idx[j]][1 .. n_geo] and ones (the row l4d_attr_gather would write), so the
- * [cap, in_pad] matrix never exists.  in_pad = 96, 64 <= n_enc < 80.  bwd: dx_tail [cap, in_pad - 64] fp16 <- the input
- * gradient's columns 64 .. in_pad - 1 (the tiles that hold the geo features; the direction encoding has no trainable input):
- * feed it to l4d_attr_gather_bwd with in_pad = in_pad - 64, n_enc = n_enc - 64. */
+/* The attribute networks straight on the work list.  l4d_attr_mlp_fwd = l4d_mlp_fwd whose input row j is assembled in the kernel
+ * from dir_enc[idx[j] / T] (n_enc columns), the sigma network's output row h[idx[j]] and ones, instead of reading the
+ * [cap, in_pad] matrix l4d_attr_gather would have to write first.  in_pad = 96, n_enc in {64, 72, 80}, n_geo = 15.  The 16
+ * columns from n_enc on are taken in the order of the sigma network's row -- [1.0, g0 .. g14], two aligned 16-byte loads -- and
+ * the weight columns are permuted to match ("physical" column order).  x_rows_out: null, or [cap, in_pad] fp16 that receives the
+ * assembled rows in physical order for l4d_attr_mlp_bwd (one network of the pair stores them, both read them).
+ * l4d_attr_mlp_bwd: x_rows as stored by the forward; dx_tail [cap, in_pad - 64] fp16 <- the input gradient's columns 64 ..
+ * in_pad - 1 in physical order (the direction encoding has no trainable input): feed it to l4d_attr_gather_bwd with
+ * in_pad = in_pad - 64, n_enc = n_enc - 64, h_layout = 1. */
 int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
                      const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* weights, void* y, void* act,
-                     void* stream);
-int l4d_attr_mlp_bwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
-                     const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* act, const void* dy,
-                     const void* weights, void* dx_tail, float* grad_w, float inv_loss_scale, void* stream);
+                     void* x_rows_out, void* stream);
+int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_t cap, int32_t n_enc, int32_t n_geo, int32_t in_pad,
+                     int32_t n_hidden, const void* act, const void* dy, const void* weights, void* dx_tail, float* grad_w,
+                     float inv_loss_scale, void* stream);
 /* sigma = trunc_exp(h[:,0]) (model/activation.py:6-20) on the sigma net's fp16 output h [P,16], and its
  * adjoint dh[:,0] = d_sigma * exp(clamp(h0,-15,15)) * loss_scale (fp16) */
 int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* stream);
@@ -247,7 +252,8 @@ int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f /*host*/, int64
 int l4d_density_encode_bwd(const l4d_field_desc* f /*host*/, const l4d_field_grads* g /*host*/, const float* xt,
                            const void* flow16, const float* tinfo, int64_t P, const void* dX, int32_t in_pad,
                            float param_scale, const float* plane_abs_max, int32_t samples_per_ray, void* workspace,
-                           void* dflow16, void* stream);
+                           void* dflow16, float* plane_rows /*null, or l4d_plane_rows_workspace() bytes: see the forward*/,
+                           void* stream);
 
 /* ---- chamfer_3DDist : utils/chamfer3D/chamfer3D.cu:11-194, dist_chamfer_3D.py:31-83 (SURVEY 8f "next" row 1) ----
  * xyz1 [b,n,3], xyz2 [b,m,3] fp32 -> dist1 [b,n], dist2 [b,m] (squared distance to the nearest point of the other

@@ -79,15 +79,15 @@ SIGNATURES = {
     "l4d_attr_gather": [P, P, I64, I32, P, I32, P, I32, P, I32, P],
     "l4d_attr_scatter": [P, P, I64, P, P, P, P, P],
     "l4d_attr_scatter_bwd": [P, P, I64, P, P, F32, P, P, P],
-    "l4d_attr_gather_bwd": [P, P, I64, P, P, I32, I32, I32, P, P],
-    "l4d_attr_mlp_fwd": [P, P, I64, I32, P, I32, P, I32, I32, I32, P, P, P, P],
-    "l4d_attr_mlp_bwd": [P, P, I64, I32, P, I32, P, I32, I32, I32, P, P, P, P, P, F32, P],
+    "l4d_attr_gather_bwd": [P, P, I64, P, P, I32, I32, I32, P, I32, P],
+    "l4d_attr_mlp_fwd": [P, P, I64, I32, P, I32, P, I32, I32, I32, P, P, P, P, P],
+    "l4d_attr_mlp_bwd": [P, P, I64, I32, I32, I32, I32, P, P, P, P, P, F32, P],
     "l4d_sigma_from_h": [P, I64, P, P],
     "l4d_sigma_bwd": [P, P, I64, F32, P, P],
     "l4d_time_setup": [P, I32, P, P],
     "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P, P, P],
     "l4d_plane_rows_workspace": [FD],
-    "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P],
+    "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P, P],
     "l4d_density_encode_bwd_workspace": [FD, I64],
     "l4d_field_width": [FD],
     "l4d_dyn_pairs_build": [PP, I32, I64, P, P],

@@ -53,12 +53,19 @@ __device__ __forceinline__ void group_taps(const FieldDesc& fd, int s, const flo
 // ------------------------------------------------------------------------------------------------
 // 1. prep
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const float* __restrict__ xt,
+// The gradient rows are read through LDS: a thread needs its row in 16-byte pieces spread over the kernel (between plane
+// gathers), i.e. 64 different cache lines per load instruction, and the lines did not survive in L1 from one piece to the
+// next (12.2 GB fetched for 3.4 GB of rows, profiles/r01_pmc_FETCH_SIZE_c3_v10.txt).  Each wave now copies the two column
+// ranges the kernel uses -- plane columns [0, 16 nS) and dynamic-hash columns -- of its 64 rows with full-width coalesced
+// loads into LDS (row pitch + 8 halfs: spreads the lanes' rows over the banks) and every piece is served from there.
+#define PREP_THREADS 128
+__global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                             const float* __restrict__ tinfo,
                                                             int64_t P, const half_t* __restrict__ dX, int in_pad, float pscale,
                                                             half_t* __restrict__ gvs, half_t* __restrict__ gdynT,
-                                                            float* __restrict__ stats) {
+                                                            float* __restrict__ stats, int staged) {
   constexpr int C = 8;
+  extern __shared__ __attribute__((aligned(16))) half_t prep_lds[];
   const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = pr < P;
   const int64_t p = valid ? pr : P - 1;  // every lane runs the whole body: the wave helpers need all 64 lanes
@@ -67,8 +74,27 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
   const float t0 = tinfo[0];
   const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
   const float x0[4] = {c4[0], c4[1], c4[2], t0};
-  const half_t* row = dX + p * in_pad;
   const int nS = fd.planes.n_scales;
+  const half_t* row = dX + p * in_pad;
+  int dyn_shift = 0;  // staged: the dynamic-hash columns sit right behind the plane columns in the LDS row
+  if (staged) {
+    const int colsA = 2 * nS * C, colD = colsA + fd.hs.n_levels * 4;
+    const int L3 = fd.hd[0].n_levels + fd.hd[1].n_levels + fd.hd[2].n_levels;
+    const int pitch = colsA + L3 + 8;
+    const int wave = threadIdx.x >> 6;
+    const int64_t wave_p0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+    half_t* wl = prep_lds + wave * 64 * pitch;
+    const int chA = colsA / 8, chB = L3 / 8;
+    for (int i = lane; i < 64 * (chA + chB); i += 64) {  // consecutive lanes: consecutive 16-byte pieces of a row
+      const int r = i / (chA + chB), c = i - r * (chA + chB);
+      const int64_t gp = min(wave_p0 + r, P - 1);
+      const int src_col = c < chA ? c * 8 : colD + (c - chA) * 8;
+      *reinterpret_cast<uint4*>(wl + r * pitch + c * 8) = *reinterpret_cast<const uint4*>(dX + gp * in_pad + src_col);
+    }
+    __syncthreads();
+    row = wl + lane * pitch;
+    dyn_shift = colD - colsA;
+  }
   const float c0 = 0.5f + (has_fwd ? 0.0f : 0.25f) + (has_bwd ? 0.0f : 0.25f);
   float gd_max = 0.0f;
   float my_stat = 0.0f;  // lane i collects the wave maximum destined for stats[i] (ST_* indices are all < 64)
@@ -127,7 +153,7 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
     for (int plane = 0; plane < 3; ++plane) {
       const int L = fd.hd[plane].n_levels;
       for (int lvl = 0; lvl < L; ++lvl, ++cidx) {
-        const half_t hv = f2h_grad(h2f(row[col + lvl]) * c0);
+        const half_t hv = f2h_grad(h2f(row[col - dyn_shift + lvl]) * c0);
         const float a = valid ? amax_nf(0.0f, h2f(hv)) : 0.0f;
         if (valid) gdynT[(int64_t)cidx * P + p] = hv;
         const float m = wave_max(a);
@@ -148,12 +174,16 @@ __global__ void __launch_bounds__(256) field_bwd_prep_kernel(FieldDesc fd, const
 // their weights are launch-uniform: LDS accumulates, per (scale, plane, frame e), ONE row  S[x][c] = sum gv * w_x  over
 // the spatial axis only (int32 fixed point), and the flush distributes it to the rows y0(e), y1(e) of the gradient
 // plane with the weights wy0(e), wy1(e).  [scale][plane][frame][W][C] ints = 138 KB at the default configuration.
+// ROWS: the time-plane VALUES the product rule needs come from the per-call 1-D rows (field_dev.h PlaneRows: two texels per
+// plane instead of four taps), and the coordinate adjoint of a warped lookup is sum_c gv_c (row[x1] - row[x0])_c from the
+// same two texels -- 144 instead of 480 texel loads per sample in a kernel that is bound by their latency.
 #define TFRAMES 3
+template <bool ROWS>
 __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
                                                             int64_t P, int64_t chunk, const half_t* __restrict__ dX,
                                                             int in_pad, float pscale, const float* __restrict__ stats,
-                                                            half_t* __restrict__ dflow16) {
+                                                            half_t* __restrict__ dflow16, PlaneRows prows) {
   constexpr int C = 8;
   extern __shared__ int lds_i[];
   const int nS = fd.planes.n_scales;
@@ -212,8 +242,29 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
                              c4[2] + (e == 1 ? fl[2] : e == 2 ? fl[5] : 0.0f), e == 0 ? t0 : e == 1 ? t1 : t2};
         Tap taps[3];
         float v[3][C];
+        float dv[3][C];  // ROWS: row[x1] - row[x0] per channel (d value / d ix)
         int cis[3];
-        group_taps<C>(fd, s, xe, true, taps, v, cis);
+        if (ROWS) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int W = fd.planes.res[s][j];
+            axis_tap(xe[j], W, taps[j].x0, taps[j].x1, taps[j].wx0, taps[j].wx1, taps[j].mx);
+            const char* b = reinterpret_cast<const char*>(prows.base + prows.off[s][j] + e * W * C);
+            const float4_t* p0 = reinterpret_cast<const float4_t*>(b + (uint32_t)taps[j].x0 * (C * 4u));
+            const float4_t* p1 = reinterpret_cast<const float4_t*>(b + (uint32_t)taps[j].x1 * (C * 4u));
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q) {
+              const float4_t a = p0[q], c = p1[q];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[j][q * 4 + k] = a[k] * taps[j].wx0 + c[k] * taps[j].wx1;
+                dv[j][q * 4 + k] = c[k] - a[k];
+              }
+            }
+          }
+        } else {
+          group_taps<C>(fd, s, xe, true, taps, v, cis);
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const Tap& t = taps[j];
@@ -222,11 +273,16 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
 #pragma unroll
           for (int k = 0; k < C; ++k) gv[k] = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
           if (e > 0) {  // coordinate adjoint of the warped lookups (time plane j pairs spatial axis j with t)
-            TapVals<C> tv;
-            float dummy[C];
-            load_taps<C>(fd.planes_cl + fd.planes.off[s][cis[j]], W, t, tv, dummy);  // L1 hits
             float gix = 0.0f, giy = 0.0f;
-            coord_grad_from_taps<C>(tv, t, gv, gix, giy);
+            if (ROWS) {
+#pragma unroll
+              for (int k = 0; k < C; ++k) gix += dv[j][k] * gv[k];
+            } else {
+              TapVals<C> tv;
+              float dummy[C];
+              load_taps<C>(fd.planes_cl + fd.planes.off[s][cis[j]], W, t, tv, dummy);  // L1 hits
+              coord_grad_from_taps<C>(tv, t, gv, gix, giy);
+            }
             gflow[(e - 1) * 3 + j] += gix * t.mx;
           }
           const RowRuns runs = row_runs((uint32_t)t.x0);  // lanes of a run share x0, hence x1 too
@@ -504,7 +560,7 @@ extern "C" int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f, int
 extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_grads* g, const float* xt, const void* flow16,
                                       const float* tinfo, int64_t P, const void* dX, int32_t in_pad, float param_scale,
                                       const float* plane_abs_max, int32_t samples_per_ray, void* workspace, void* dflow16,
-                                      void* stream_) {
+                                      float* plane_rows, void* stream_) {
   if (P == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   FieldDesc d;
@@ -526,8 +582,13 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   if (e == hipSuccess) e = hipMemcpyAsync(stats + ST_VMAX, plane_abs_max, sizeof(float), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
 
-  L4D_LAUNCH(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, stream, d, xt,
-                     tinfo, P, (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats);
+  {
+    const int colsA = 2 * d.planes.n_scales * 8, colD = colsA + d.hs.n_levels * 4;
+    const int staged = (colD % 8 == 0 && L3 % 8 == 0) ? 1 : 0;  // 16-byte pieces
+    const int lds = staged ? PREP_THREADS * (colsA + L3 + 8) * 2 : 0;
+    L4D_LAUNCH(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, PREP_THREADS)), dim3(PREP_THREADS), lds, stream, d, xt, tinfo, P,
+               (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, staged);
+  }
 
   // static 3-D hash grid: sorted scatter of dX[:, 2*nS*8 + lvl*4 ..] (binscatter.hip)
   {
@@ -550,9 +611,17 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     for (int s = 0; s < d.planes.n_scales; ++s)
       for (int j = 0; j < 3; ++j) lds += TFRAMES * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
-    (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    L4D_LAUNCH(planes_dyn_lds_kernel, dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16,
-                       tinfo, P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16);
+    const PlaneRows pr = make_plane_rows(d, plane_rows);
+    if (plane_rows) {
+      L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, stream, d, pr, tinfo, plane_rows);
+      (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      L4D_LAUNCH((planes_dyn_lds_kernel<true>), dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
+                 P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr);
+    } else {
+      (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      L4D_LAUNCH((planes_dyn_lds_kernel<false>), dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
+                 P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr);
+    }
   }
   // static planes
   {

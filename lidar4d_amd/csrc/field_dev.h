@@ -100,6 +100,67 @@ __device__ __forceinline__ float hash_t_level(const FieldDesc& fd, int plane, in
   return r;
 }
 
+// ---- time planes as 1-D rows ------------------------------------------------------------------------------------
+// The time coordinate of a frame is the same for every sample of a call, so the two time rows a time-plane tap touches and
+// their weights are launch-uniform: rows[s][j][e][x][c] = wy0(e) * plane[y0(e)][x][c] + wy1(e) * plane[y1(e)][x][c] is built
+// once per call (35 k floats at the default sizes) and a time-plane sample becomes a 1-D interpolation -- two 32-byte
+// texels instead of four.  The kernel is bound by L1 bandwidth on exactly these fp32 texel reads (12 KB per sample), and
+// 3/4 of the plane taps belong to time planes (3 planes at x, 3 + 3 at the two warped points).
+struct PlaneRows {
+  const float* base;  // null: sample the planes directly
+  int off[MAX_SCALES][3];
+};
+#define TROWS_FRAMES 3
+static __global__ void __launch_bounds__(256) plane_time_rows_kernel(FieldDesc fd, PlaneRows pr, const float* __restrict__ tinfo, float* __restrict__ rows) {
+  constexpr int C = 8;
+  const int s = blockIdx.y / 3, j = blockIdx.y % 3, e = blockIdx.z;
+  const int W = fd.planes.res[s][j], Ht = fd.planes.res[s][3];
+  int y0, y1;
+  float wy0, wy1, my;
+  axis_tap(tinfo[e], Ht, y0, y1, wy0, wy1, my);
+  const float* plane = fd.planes_cl + fd.planes.off[s][j == 0 ? 2 : j == 1 ? 4 : 5];
+  float* dst = rows + pr.off[s][j] + e * W * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * C; i += gridDim.x * blockDim.x)
+    dst[i] = plane[(size_t)y0 * W * C + i] * wy0 + plane[(size_t)y1 * W * C + i] * wy1;
+}
+
+// product over the three time planes of scale s at frame e, from the 1-D rows
+template <int C>
+__device__ __forceinline__ void planes_time_group(const FieldDesc& fd, const PlaneRows& pr, int s, int e, const float coord[4], float out[C]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int W = fd.planes.res[s][j];
+    int x0, x1;
+    float wx0, wx1, mx;
+    axis_tap(coord[j], W, x0, x1, wx0, wx1, mx);
+    const char* b = reinterpret_cast<const char*>(pr.base + pr.off[s][j] + e * W * C);
+    const float4_t* p0 = reinterpret_cast<const float4_t*>(b + (uint32_t)x0 * (C * 4u));
+    const float4_t* p1 = reinterpret_cast<const float4_t*>(b + (uint32_t)x1 * (C * 4u));
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      const float4_t a = p0[q], c = p1[q];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = a[k] * wx0 + c[k] * wx1;
+        out[q * 4 + k] = j == 0 ? v : out[q * 4 + k] * v;
+      }
+    }
+  }
+}
+
+// offsets of the row blocks and (optionally) the launch that fills them for the call's three frame times
+static inline PlaneRows make_plane_rows(const FieldDesc& d, float* rows) {
+  PlaneRows pr;
+  pr.base = rows;
+  int o = 0;
+  for (int s = 0; s < MAX_SCALES; ++s)
+    for (int j = 0; j < 3; ++j) {
+      pr.off[s][j] = o;
+      if (s < d.planes.n_scales) o += TROWS_FRAMES * d.planes.res[s][j] * 8;
+    }
+  return pr;
+}
+
 static inline int make_field(const l4d_field_desc* f, FieldDesc& d) {
   if (f->n_slices > MAX_SLICES || f->n_scales > MAX_SCALES || f->plane_channels != 8 || f->hash_static.n_features != 4 ||
       f->hash_static.n_dims != 3) {

@@ -39,16 +39,24 @@ __device__ __forceinline__ int perm_row(int mt, int i) { return 32 * (mt >> 1) +
 // value(row, k) of an A/B fragment: lane (i, g), element e -> k = 32*ks + 8g + e
 // kind 0: W[row_of(i)][k]          (forward A: rows = neurons of this layer, k = its inputs)
 // kind 1: W[k][row_of(i)]          (W^T: rows = inputs of the layer, k = its neurons)
-__device__ __forceinline__ h8 build_frag(const half_t* __restrict__ W, int R, int Cw, int kind, int row, int kbase) {
+// cperm >= 0 (the attribute networks fed from AttrSrc): the kernel's PHYSICAL input column order differs from the weight
+// matrix' logical one so that the geo features can be taken from the sigma network's output row [h0, g0 .. g14] with two
+// aligned 16-byte loads: physical column cperm carries the constant 1.0 (logical column cperm + 15, the first padding
+// column), physical cperm + 1 .. cperm + 15 carry g0 .. g14 (logical cperm .. cperm + 14); all other columns coincide.
+__device__ __forceinline__ int col_map(int c, int cperm) {
+  if (cperm < 0 || c < cperm || c >= cperm + 16) return c;
+  return c == cperm ? cperm + 15 : c - 1;
+}
+__device__ __forceinline__ h8 build_frag(const half_t* __restrict__ W, int R, int Cw, int kind, int row, int kbase, int cperm = -1) {
   h8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int k = kbase + e;
     float x = 0.0f;
     if (kind == 0) {
-      if (row < R && k < Cw) x = h2f(W[row * Cw + k]);
+      if (row < R && k < Cw) x = h2f(W[row * Cw + col_map(k, cperm)]);
     } else {
-      if (k < R && row < Cw) x = h2f(W[k * Cw + row]);
+      if (k < R && row < Cw) x = h2f(W[k * Cw + col_map(row, cperm)]);
     }
     v[e] = f2h(x);
   }
@@ -81,36 +89,30 @@ __device__ __forceinline__ float clamp_h(float x) { return fminf(fmaxf(x, -65504
 struct AttrSrc {
   const int32_t* idx;   // work list (null: row j is sample j)
   const half_t* denc;   // [rays, n_enc] fp16, n_enc a multiple of 8
-  const half_t* h;      // [samples, 16] fp16 sigma-network output
-  int T, n_enc, n_geo;
+  const half_t* h;      // [samples, 16] fp16 sigma-network output: geo_feat = columns 1 .. 15
+  int T, n_enc;
+  int cperm;            // = n_enc when gathering, -1 otherwise (col_map)
 };
-// columns k0 .. k0 + 7 of the row of sample p (k0 a multiple of 8)
+// PHYSICAL columns k0 .. k0 + 7 of the row of sample p (k0 a multiple of 8; column order: col_map with cperm = n_enc)
 __device__ __forceinline__ uint4 attr_chunk(const AttrSrc& s, int64_t p, int k0) {
-  const int64_t ray = p / s.T;
-  if (k0 + 8 <= s.n_enc) return *reinterpret_cast<const uint4*>(s.denc + ray * s.n_enc + k0);
-  half_t hrow[16];
-  *reinterpret_cast<uint4*>(hrow) = *reinterpret_cast<const uint4*>(s.h + p * 16);
-  *reinterpret_cast<uint4*>(hrow + 8) = *reinterpret_cast<const uint4*>(s.h + p * 16 + 8);
-  half_t v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int gcol = 1 + (k0 + e - s.n_enc);  // column of h that holds this geo feature
-    half_t t = (half_t)1.0f;                  // padding columns carry 1.0 (tiny-cuda-nn pads the network input with ones)
-#pragma unroll
-    for (int q = 1; q < 16; ++q) t = (gcol == q && q <= s.n_geo) ? hrow[q] : t;  // register select: no dynamic indexing
-    v[e] = t;
-  }
-  return *reinterpret_cast<uint4*>(v);
+  if (k0 + 8 <= s.n_enc) return *reinterpret_cast<const uint4*>(s.denc + (p / s.T) * s.n_enc + k0);
+  const int q = (k0 - s.n_enc) >> 3;
+  if (q >= 2) return make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);  // ones
+  uint4 u = *reinterpret_cast<const uint4*>(s.h + p * 16 + 8 * q);
+  if (q == 0) u.x = (u.x & 0xFFFF0000u) | 0x3C00u;  // [1.0, g0 .. g6]: the sigma logit's slot carries the constant
+  return u;
 }
 
 // ================================================================================================
 // forward
 // ================================================================================================
 // weight layout (fp16): W1 [64, in_pad], (NH-1) x [64, 64], Wo [16, 64]
-template <int IN_TILES, int NH, bool GATHER = false>
+// GATHER: input rows assembled from AttrSrc; WRITE_X: the assembled rows (physical column order) are also stored to xout
+// [cap, IN_PAD] for a backward pass that reads them as a plain matrix.
+template <int IN_TILES, int NH, bool GATHER = false, bool WRITE_X = false>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__ x, int64_t cap, const int32_t* __restrict__ n_rows,
                                                      const half_t* __restrict__ weights, half_t* __restrict__ y,
-                                                     half_t* __restrict__ act, AttrSrc src) {
+                                                     half_t* __restrict__ act, AttrSrc src, half_t* __restrict__ xout = nullptr) {
   // cap = rows the buffers were sized for (stride of the act planes); P = rows actually present
   const int64_t P = n_rows ? min((int64_t)*n_rows, cap) : cap;
   constexpr int IN_PAD = IN_TILES * 16;
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__
     h8 v;
     if (f < NF_L1) {
       const int mt = f / KS_IN, ks = f % KS_IN;
-      v = build_frag(weights, HID, IN_PAD, 0, perm_row(mt, i), 32 * ks + 8 * g);
+      v = build_frag(weights, HID, IN_PAD, 0, perm_row(mt, i), 32 * ks + 8 * g, src.cperm);
     } else if (f < NF_L1 + (NH - 1) * 8) {
       const int q = f - NF_L1, layer = q / 8, mt = (q % 8) / 2, ks = q % 2;
       v = build_frag(weights + HID * IN_PAD + layer * HID * HID, HID, HID, 0, perm_row(mt, i), 32 * ks + 8 * g);
@@ -153,6 +155,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__
       uint4 u = make_uint4(0, 0, 0, 0);
       if (ok && k0 < IN_PAD) u = GATHER ? attr_chunk(src, psrc, k0) : *reinterpret_cast<const uint4*>(x + row * IN_PAD + k0);
       xb[ks] = *reinterpret_cast<h8*>(&u);
+      if (WRITE_X && ok && k0 < IN_PAD) *reinterpret_cast<uint4*>(xout + row * IN_PAD + k0) = u;
     }
     // layer 1
     f4 acc[4];
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       v = build_frag(Wl, HID, HID, 1, row, 32 * ks + 8 * g);
     } else {
       const int q = f - L::W1T, mt = q / 2, ks = q % 2;
-      v = build_frag(W1, HID, IN_PAD, 1, 16 * mt + i, 32 * ks + 8 * g);
+      v = build_frag(W1, HID, IN_PAD, 1, 16 * mt + i, 32 * ks + 8 * g, src.cperm);
     }
     frags[f][lane] = *reinterpret_cast<uint4*>(&v);
   }
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       h8 v;
       if (f < 4 * KS_IN) {
         const int mt = f / KS_IN, ks = f % KS_IN;
-        v = build_frag(weights, HID, IN_PAD, 0, perm_row(mt, i), 32 * ks + 8 * g);
+        v = build_frag(weights, HID, IN_PAD, 0, perm_row(mt, i), 32 * ks + 8 * g, src.cperm);
       } else {
         const int q = f - 4 * KS_IN, layer = q / 8, mt = (q % 8) / 2, ks = q % 2;
         v = build_frag(weights + HID * IN_PAD + layer * HID * HID, HID, HID, 0, perm_row(mt, i), 32 * ks + 8 * g);
@@ -306,12 +309,9 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       rows[a] = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
       ok[a] = rows[a] < P;
     }
-    int64_t psrc[2] = {0, 0};
-    if (GATHER) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-        if (ok[a]) psrc[a] = src.idx ? (int64_t)src.idx[rows[a]] : rows[a];
-    }
+    // (GATHER) the work-list entries are looked up right where the rows are loaded: keeping them live across the whole
+    // tile body costs registers this kernel does not have
+    auto src_row = [&](int a) -> int64_t { return ok[a] ? (src.idx ? (int64_t)src.idx[rows[a]] : rows[a]) : 0; };
     // ---- (RECOMP) forward chain from x: hidden activations of every layer, chain layout [layer][a][ks] ----
     h8 xf[2][KS_IN];
     h8 hrec[RECOMP ? NH : 1][2][2];
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
         for (int ks = 0; ks < KS_IN; ++ks) {
           const int k0 = 32 * ks + 8 * g;
           uint4 u = make_uint4(0, 0, 0, 0);
-          if (ok[a] && k0 < IN_PAD) u = GATHER ? attr_chunk(src, psrc[a], k0) : *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
+          if (ok[a] && k0 < IN_PAD) u = GATHER ? attr_chunk(src, src_row(a), k0) : *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
           xf[a][ks] = *reinterpret_cast<h8*>(&u);
         }
         f4 acc[4];
@@ -512,14 +512,16 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
     {
       if (!RECOMP) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+          const int64_t ps = GATHER ? src_row(a) : 0;
 #pragma unroll
           for (int ks = 0; ks < KS_IN; ++ks) {
             const int k0 = 32 * ks + 8 * g;
             uint4 u = make_uint4(0, 0, 0, 0);
-            if (ok[a] && k0 < IN_PAD) u = GATHER ? attr_chunk(src, psrc[a], k0) : *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
+            if (ok[a] && k0 < IN_PAD) u = GATHER ? attr_chunk(src, ps, k0) : *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
             xf[a][ks] = *reinterpret_cast<h8*>(&u);
           }
+        }
       }
 #pragma unroll
       for (int nt = COL_LO; nt < COL_HI; ++nt) {
@@ -565,7 +567,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = dW1[mt][nt - COL_LO][r] * inv_scale;
-        if (v != 0.0f) atomicAdd(gW1 + (16 * mt + 4 * g + r) * IN_PAD + 16 * nt + i, v);
+        if (v != 0.0f) atomicAdd(gW1 + (16 * mt + 4 * g + r) * IN_PAD + col_map(16 * nt + i, src.cperm), v);
       }
   if (!REST) return;
 #pragma unroll
@@ -612,7 +614,7 @@ extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int3
 #define X(IT, NHH)                                                                                                   \
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_fwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, P, \
-                       n_rows, (const half_t*)weights, (half_t*)y, (half_t*)act, AttrSrc{});                                \
+                       n_rows, (const half_t*)weights, (half_t*)y, (half_t*)act, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                \
     done = true;                                                                                                     \
   }
   FOR_EACH_CFG(X)
@@ -639,7 +641,7 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (!done && !act && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                      \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
                (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,           \
-               (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{});                                                      \
+               (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                                      \
     done = true;                                                                                                     \
   }
   X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3)  // <8, 1>: measured neutral; <6, 2> and wider / deeper spill registers
@@ -652,7 +654,7 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,         \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{});                                              \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                              \
     done = true;                                                                                                     \
   }
   FOR_EACH_CFG(X)
@@ -661,10 +663,10 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, 6, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{});                                              \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 6, IT, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{});                                              \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                              \
     done = true;                                                                                                     \
   }
   FOR_EACH_WIDE_CFG(X)
@@ -680,25 +682,30 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
 // ---- attribute networks on a work list, input rows assembled in the kernel (AttrSrc) ------------------------------------
 static int attr_src(const int32_t* idx, int32_t T, const void* dir_enc, int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad,
                     AttrSrc& s, const char* where) {
-  if (in_pad != 96 || n_enc % 8 || n_enc / 16 != 4 || n_enc + n_geo > in_pad || n_geo > 15 || T <= 0) {
+  if (in_pad != 96 || n_enc % 8 || n_enc / 16 != 4 || n_enc + 16 > in_pad || n_geo != 15 || T <= 0) {
     l4d_set_error(1, where);
     return 1;
   }
-  s.idx = idx; s.denc = (const half_t*)dir_enc; s.h = (const half_t*)h; s.T = T; s.n_enc = n_enc; s.n_geo = n_geo;
+  s.idx = idx; s.denc = (const half_t*)dir_enc; s.h = (const half_t*)h; s.T = T; s.n_enc = n_enc; s.cperm = n_enc;
   return 0;
 }
 
 extern "C" int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
                                 const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* weights, void* y,
-                                void* act, void* stream) {
+                                void* act, void* x_rows_out, void* stream) {
   if (cap == 0) return 0;
   AttrSrc src;
-  if (attr_src(idx, T, dir_enc, n_enc, h, n_geo, in_pad, src, "l4d_attr_mlp_fwd: needs in_pad 96, 64 <= n_enc < 80 (multiple of 8), n_geo <= 15")) return 1;
+  if (attr_src(idx, T, dir_enc, n_enc, h, n_geo, in_pad, src, "l4d_attr_mlp_fwd: needs in_pad 96, 64 <= n_enc <= 80 (multiple of 8), n_geo = 15")) return 1;
   const int grid = grid_for((cap + 15) / 16);
 #define X(NHH)                                                                                                         \
-  if (n_hidden == NHH)                                                                                                 \
-    L4D_LAUNCH((mlp_fwd_kernel<6, NHH, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)nullptr, cap, count, \
-               (const half_t*)weights, (half_t*)y, (half_t*)act, src);
+  if (n_hidden == NHH) {                                                                                               \
+    if (x_rows_out)                                                                                                    \
+      L4D_LAUNCH((mlp_fwd_kernel<6, NHH, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)nullptr, cap, \
+                 count, (const half_t*)weights, (half_t*)y, (half_t*)act, src, (half_t*)x_rows_out);                   \
+    else                                                                                                               \
+      L4D_LAUNCH((mlp_fwd_kernel<6, NHH, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)nullptr, cap, \
+                 count, (const half_t*)weights, (half_t*)y, (half_t*)act, src, (half_t*)nullptr);                      \
+  }
   X(1) X(2) X(3)
 #undef X
   if (n_hidden < 1 || n_hidden > 3) { l4d_set_error(1, "l4d_attr_mlp_fwd: n_hidden in 1..3"); return 1; }
@@ -706,18 +713,20 @@ extern "C" int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_
   return 0;
 }
 
-extern "C" int l4d_attr_mlp_bwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
-                                const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* act, const void* dy,
-                                const void* weights, void* dx_tail, float* grad_w, float inv_loss_scale, void* stream) {
+extern "C" int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_t cap, int32_t n_enc, int32_t n_geo, int32_t in_pad,
+                                int32_t n_hidden, const void* act, const void* dy, const void* weights, void* dx_tail,
+                                float* grad_w, float inv_loss_scale, void* stream) {
   if (cap == 0) return 0;
   AttrSrc src;
-  if (attr_src(idx, T, dir_enc, n_enc, h, n_geo, in_pad, src, "l4d_attr_mlp_bwd: needs in_pad 96, 64 <= n_enc < 80 (multiple of 8), n_geo <= 15")) return 1;
+  if (attr_src(nullptr, 1, nullptr, n_enc, nullptr, n_geo, in_pad, src, "l4d_attr_mlp_bwd: needs in_pad 96, 64 <= n_enc <= 80 (multiple of 8), n_geo = 15")) return 1;
   int grid = grid_for((cap + 31) / 32);
   if (grid > 512) grid = 512;
+  // the rows l4d_attr_mlp_fwd stored (physical column order: src.cperm permutes the weight columns); a version that
+  // assembles the rows here as well was measured slower: this kernel has no register to spare (3.65 vs 2.0 ms per launch)
 #define X(NHH)                                                                                                          \
   if (n_hidden == NHH)                                                                                                  \
-    L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, true, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,     \
-               (const half_t*)nullptr, (const half_t*)act, (const half_t*)dy, cap, count, (const half_t*)weights,       \
+    L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, false, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,    \
+               (const half_t*)x_rows, (const half_t*)act, (const half_t*)dy, cap, count, (const half_t*)weights,        \
                (half_t*)dx_tail, grad_w, inv_loss_scale, src);
   X(1) X(2) X(3)
 #undef X

@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256) attr_gather_bwd_kernel(const int32_t* __r
 __global__ void __launch_bounds__(256) attr_gather_bwd_rows_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
                                                                   int64_t cap, const half_t* __restrict__ dxa_r,
                                                                   const half_t* __restrict__ dxa_i, int in_pad, int n_enc,
-                                                                  int n_geo, half_t* __restrict__ dh) {
+                                                                  int n_geo, half_t* __restrict__ dh, int h_layout) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t M = count ? min((int64_t)*count, cap) : cap;
   if (j >= M) return;
@@ -387,7 +387,8 @@ __global__ void __launch_bounds__(256) attr_gather_bwd_rows_kernel(const int32_t
   o[0] = (half_t)0.0f;
 #pragma unroll
   for (int k = 0; k < 15; ++k) {
-    const float v = h2f(r[k]) + h2f(q[k]);
+    // h_layout: the 16 columns read already have the sigma-network row's order [-, g0 .. g14] (l4d_attr_mlp_bwd)
+    const float v = h_layout ? h2f(r[1 + k]) + h2f(q[1 + k]) : h2f(r[k]) + h2f(q[k]);
     o[1 + k] = k < n_geo ? f2h_grad(v) : (half_t)0.0f;
   }
   *reinterpret_cast<uint4*>(dh + p * 16) = *reinterpret_cast<uint4*>(o);
@@ -497,12 +498,16 @@ extern "C" int l4d_attr_scatter_bwd(const int32_t* idx, const int32_t* count, in
 
 extern "C" int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int64_t cap, const void* dxa_raydrop,
                                    const void* dxa_intensity, int32_t in_pad, int32_t n_enc, int32_t n_geo, void* dh,
-                                   void* stream) {
+                                   int32_t h_layout, void* stream) {
   if (cap == 0) return 0;
+  if (h_layout && !((n_enc & 7) == 0 && n_enc + 16 <= in_pad && n_geo <= 15)) {
+    l4d_set_error(1, "l4d_attr_gather_bwd: h_layout needs 16 aligned columns at n_enc");
+    return 1;
+  }
   if ((n_enc & 7) == 0 && n_enc + 16 <= in_pad && n_geo <= 15)
     L4D_LAUNCH(attr_gather_bwd_rows_kernel, dim3((unsigned)ceil_div64(cap, 256)), dim3(256), 0, (hipStream_t)stream,
                        idx, count, cap, (const half_t*)dxa_raydrop, (const half_t*)dxa_intensity, in_pad, n_enc, n_geo,
-                       (half_t*)dh);
+                       (half_t*)dh, h_layout);
   else
     L4D_LAUNCH(attr_gather_bwd_kernel, dim3((unsigned)ceil_div64(cap * n_geo, 256)), dim3(256), 0, (hipStream_t)stream,
                        idx, count, cap, (const half_t*)dxa_raydrop, (const half_t*)dxa_intensity, in_pad, n_enc, n_geo,

@@ -130,10 +130,10 @@ class RenderFn(torch.autograd.Function):
         denc = ops.freq_fwd(((rays_d + 1) / 2).contiguous(), model.view_encoder.n_frequencies)
         an = model.intensity_net
         gathered = ops.attr_mlp_supported(an.in_pad, denc.shape[1], model.geo_feat_dim)
-        if gathered:  # the networks assemble their input rows themselves: no [rows, 96] matrix (written once, read four times)
-            XA = None
+        if gathered:  # the networks assemble their input rows themselves; the first one stores them for the backward pass
+            XA = torch.empty(P, an.in_pad, dtype=torch.float16, device=dev) if train else None
             yR, actR = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.raydrop_net.params),
-                                        an.n_hidden_layers, save_act=train)
+                                        an.n_hidden_layers, save_act=train, x_rows_out=XA)
             yI, actI = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.intensity_net.params),
                                         an.n_hidden_layers, save_act=train)
         else:
@@ -146,7 +146,7 @@ class RenderFn(torch.autograd.Function):
         image = ops.composite_image(weights, attr, 2)
 
         if train:
-            ctx.model, ctx.T, ctx.sample_dist = model, T, sample_dist
+            ctx.model, ctx.T, ctx.sample_dist, ctx.gathered = model, T, sample_dist, gathered
             ctx.save_for_backward(t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count,
                                   XA, actR, actI, attr, attr_c, denc)
         ctx.mark_non_differentiable(z_vals, idx, count)
@@ -178,12 +178,12 @@ class RenderFn(torch.autograd.Function):
         ops.attr_scatter_bwd(idx, count, P, d_attr, attr_c, ls, dyR, dyI)
         dh = torch.zeros(P, 16, dtype=torch.float16, device=dev)
         n_enc = model.view_encoder.n_output_dims
-        if XA is None:  # gathered inputs; only the input gradient's tail (the tiles holding geo_feat) is produced
-            dxaR = ops.attr_mlp_bwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, actR, dyR, store.half(model.raydrop_net.params),
+        if ctx.gathered:  # rows in the forward's physical column order; only the input gradient's tail (geo_feat tiles) is produced
+            dxaR = ops.attr_mlp_bwd(XA, count, n_enc, model.geo_feat_dim, actR, dyR, store.half(model.raydrop_net.params),
                                     an.n_hidden_layers, store.grad_view(model.raydrop_net.params), inv)
-            dxaI = ops.attr_mlp_bwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, actI, dyI, store.half(model.intensity_net.params),
+            dxaI = ops.attr_mlp_bwd(XA, count, n_enc, model.geo_feat_dim, actI, dyI, store.half(model.intensity_net.params),
                                     an.n_hidden_layers, store.grad_view(model.intensity_net.params), inv)
-            ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad - 64, n_enc - 64, model.geo_feat_dim, dh)
+            ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad - 64, n_enc - 64, model.geo_feat_dim, dh, h_layout=True)
         else:
             dxaR = ops.mlp_bwd(XA, actR, dyR, store.half(model.raydrop_net.params), an.n_hidden_layers,
                                store.grad_view(model.raydrop_net.params), inv, n_rows=count)

@@ -272,26 +272,31 @@ def attr_gather(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, xa=None):
 
 
 def attr_mlp_supported(in_pad, n_enc, n_geo):
-    return in_pad == 96 and n_enc % 8 == 0 and n_enc // 16 == 4 and n_enc + n_geo <= in_pad and n_geo <= 15
+    return in_pad == 96 and n_enc % 8 == 0 and n_enc // 16 == 4 and n_enc + 16 <= in_pad and n_geo == 15
 
 
-def attr_mlp_fwd(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, weights16, n_hidden, save_act=True):
-    """Attribute network on the compacted work list without materialising its input matrix -> y [cap,16] (+ act)."""
+def attr_mlp_fwd(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, weights16, n_hidden, save_act=True, x_rows_out=None):
+    """Attribute network on the compacted work list, input rows assembled in the kernel -> y [cap,16] (+ act).
+    x_rows_out: [cap, in_pad] fp16 that receives the assembled rows (physical column order) for attr_mlp_bwd."""
     _chk(idx, torch.int32, "idx"), _chk(count, torch.int32, "count"), _chk(dir_enc16, torch.float16, "dir_enc")
-    _chk(h16, torch.float16, "h"), _chk(weights16, torch.float16, "weights")
+    _chk(h16, torch.float16, "h"), _chk(weights16, torch.float16, "weights"), _chk(x_rows_out, torch.float16, "x_rows_out")
     y = torch.empty(cap, 16, dtype=torch.float16, device=h16.device)
     act = torch.empty(n_hidden, cap, 64, dtype=torch.float16, device=h16.device) if save_act else None
     call("l4d_attr_mlp_fwd", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad, n_hidden,
-         _p(weights16), _p(y), _p(act), _stream())
+         _p(weights16), _p(y), _p(act), _p(x_rows_out), _stream())
     return y, act
 
 
-def attr_mlp_bwd(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale):
-    """-> dx_tail [cap, in_pad - 64] fp16: the input gradient's columns 64 .. in_pad - 1 (geo features at n_enc - 64 ..)."""
-    _chk(act, torch.float16, "act"), _chk(dy16, torch.float16, "dy"), _chk(grad_w, torch.float32, "grad_w")
-    dx = torch.empty(cap, in_pad - 64, dtype=torch.float16, device=h16.device)
-    call("l4d_attr_mlp_bwd", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad, n_hidden,
-         _p(act), _p(dy16), _p(weights16), _p(dx), _p(grad_w), float(inv_loss_scale), _stream())
+def attr_mlp_bwd(x_rows, count, n_enc, n_geo, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale):
+    """x_rows [cap, in_pad]: the rows attr_mlp_fwd stored.  -> dx_tail [cap, in_pad - 64] fp16: the input gradient's columns
+    64 .. in_pad - 1, the 16 columns from n_enc - 64 on in the sigma network row's order [-, g0 .. g14]
+    (attr_gather_bwd(..., h_layout=True))."""
+    _chk(x_rows, torch.float16, "x_rows"), _chk(act, torch.float16, "act"), _chk(dy16, torch.float16, "dy")
+    _chk(grad_w, torch.float32, "grad_w"), _chk(count, torch.int32, "count")
+    cap, in_pad = x_rows.shape
+    dx = torch.empty(cap, in_pad - 64, dtype=torch.float16, device=x_rows.device)
+    call("l4d_attr_mlp_bwd", _p(x_rows), _p(count), cap, n_enc, n_geo, in_pad, n_hidden, _p(act), _p(dy16), _p(weights16), _p(dx),
+         _p(grad_w), float(inv_loss_scale), _stream())
     return dx
 
 
@@ -305,8 +310,8 @@ def attr_scatter_bwd(idx, count, cap, d_attr, attr_compact, loss_scale, dy_r, dy
          _p(dy_i), _stream())
 
 
-def attr_gather_bwd(idx, count, cap, dxa_r, dxa_i, in_pad, n_enc, n_geo, dh16):
-    call("l4d_attr_gather_bwd", _p(idx), _p(count), cap, _p(dxa_r), _p(dxa_i), in_pad, n_enc, n_geo, _p(dh16), _stream())
+def attr_gather_bwd(idx, count, cap, dxa_r, dxa_i, in_pad, n_enc, n_geo, dh16, h_layout=False):
+    call("l4d_attr_gather_bwd", _p(idx), _p(count), cap, _p(dxa_r), _p(dxa_i), in_pad, n_enc, n_geo, _p(dh16), int(h_layout), _stream())
 
 
 def sigma_from_h(h16):
@@ -357,8 +362,11 @@ def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_sca
         dflow16 = torch.empty(P, 16, dtype=torch.float16, device=dX.device)
     nbytes = _lib.lib().l4d_density_encode_bwd_workspace(C.byref(field_desc), P)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dX.device)
+    rows = None
+    if P >= PLANE_ROWS_MIN_POINTS:
+        rows = torch.empty(_lib.lib().l4d_plane_rows_workspace(C.byref(field_desc)) // 4, dtype=torch.float32, device=dX.device)
     call("l4d_density_encode_bwd", C.byref(field_desc), C.byref(field_grads), _p(xt), _p(flow16), _p(tinfo), P, _p(dX),
-         in_pad, float(param_scale), _p(plane_abs_max), int(samples_per_ray), _p(ws), _p(dflow16), _stream())
+         in_pad, float(param_scale), _p(plane_abs_max), int(samples_per_ray), _p(ws), _p(dflow16), _p(rows), _stream())
     return dflow16
 
 

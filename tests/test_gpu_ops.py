@@ -297,7 +297,9 @@ def test_chamfer_fwd_bwd(b, n, m):
 def test_attr_mlp_gathered_equals_materialised():
     """l4d_attr_mlp_fwd / _bwd (input rows assembled in the kernel from the direction encoding, the sigma network's output and
     ones) against l4d_attr_gather + l4d_mlp_fwd / _bwd on the materialised [rows, 96] matrix: same MFMAs on the same
-    operands -> bit-identical outputs, activations and geo-feature gradients; dW up to atomics order."""
+    operands (the kernel takes the 16 columns behind the direction encoding in the order of the sigma network's row and
+    permutes the weight columns to match: each product is the same, the fp32 accumulation order inside a k-chunk changes) ->
+    outputs / activations / gradients equal up to fp16 rounding of reordered fp32 sums; dW up to atomics order."""
     from lidar4d_amd import ops
     n_rays, T, n_geo, in_pad = 37, 64, 15, 96
     P = n_rays * T
@@ -316,19 +318,32 @@ def test_attr_mlp_gathered_equals_materialised():
         assert ops.attr_mlp_supported(in_pad, denc.shape[1], n_geo)
         xa = ops.attr_gather(idx, count, P, T, denc, h, n_geo, in_pad)
         y0, act0 = ops.mlp_fwd(xa, w, n_hidden, save_act=True, n_rows=count)
-        y1, act1 = ops.attr_mlp_fwd(idx, count, P, T, denc, h, n_geo, in_pad, w, n_hidden, save_act=True)
-        assert torch.equal(y0[:M], y1[:M]) and torch.equal(act0[:, :M], act1[:, :M])
+        xr = torch.zeros(P, in_pad, dtype=torch.float16, device=DEV)
+        y1, act1 = ops.attr_mlp_fwd(idx, count, P, T, denc, h, n_geo, in_pad, w, n_hidden, save_act=True, x_rows_out=xr)
+        y2, _ = ops.attr_mlp_fwd(idx, count, P, T, denc, h, n_geo, in_pad, w, n_hidden, save_act=False)
+        assert torch.equal(y1[:M], y2[:M])
+        # the stored rows: the materialised matrix with the 16 columns behind the direction encoding in the order [1, g0 .. g14]
+        assert torch.equal(xr[:M, :72], xa[:M, :72]) and torch.equal(xr[:M, 73:88], xa[:M, 72:87]) and bool((xr[:M, 72] == 1).all())
+        assert torch.equal(xr[:M, 88:], xa[:M, 88:])
+        def near(a, b, what):  # equal up to an fp16 ulp on a small fraction of the elements
+            a, b = a.float(), b.float()
+            d = (a - b).abs()
+            assert float(d.max()) <= 2 ** -9 * max(float(b.abs().max()), 1e-6) and float((d > 0).float().mean()) < 0.05, (what, float(d.max()), float((d > 0).float().mean()))
+        near(y0[:M], y1[:M], "y"), near(act0[:, :M], act1[:, :M], "act")
         dy = torch.zeros(P, 16, dtype=torch.float16, device=DEV)
         dy[:, 0] = det_uniform((P,), "gady", -1, 1).half().to(DEV)
         g0, g1 = torch.zeros(w.numel(), device=DEV), torch.zeros(w.numel(), device=DEV)
         dx0 = ops.mlp_bwd(xa, act0, dy, w, n_hidden, g0, 1.0 / 128, n_rows=count)
-        dx1 = ops.attr_mlp_bwd(idx, count, P, T, denc, h, n_geo, in_pad, act1, dy, w, n_hidden, g1, 1.0 / 128)
-        assert dx1.shape == (P, 32) and torch.equal(dx0[:M, 64:], dx1[:M])
+        dx1 = ops.attr_mlp_bwd(xr, count, denc.shape[1], n_geo, act1, dy, w, n_hidden, g1, 1.0 / 128)
+        # dx_tail's physical columns: [64 .. 71 | junk (d/d ones), g0 .. g14 | 88 .. 95]
+        assert dx1.shape == (P, 32)
+        near(dx0[:M, 64:72], dx1[:M, :8], "dx tile head"), near(dx0[:M, 72:87], dx1[:M, 9:24], "d geo")
         assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max()) and float(g0.abs().max()) > 0
         dh0, dh1 = torch.zeros(P, 16, dtype=torch.float16, device=DEV), torch.zeros(P, 16, dtype=torch.float16, device=DEV)
         ops.attr_gather_bwd(idx, count, P, dx0, dx0, in_pad, denc.shape[1], n_geo, dh0)
-        ops.attr_gather_bwd(idx, count, P, dx1, dx1, in_pad - 64, denc.shape[1] - 64, n_geo, dh1)
-        assert torch.equal(dh0, dh1) and float(dh0.abs().max()) > 0
+        ops.attr_gather_bwd(idx, count, P, dx1, dx1, in_pad - 64, denc.shape[1] - 64, n_geo, dh1, h_layout=True)
+        near(dh0, dh1, "dh")
+        assert float(dh0.abs().max()) > 0 and bool((dh1[:, 0] == 0).all())
     # empty work list
     zero = torch.zeros(1, dtype=torch.int32, device=DEV)
     y, _ = ops.attr_mlp_fwd(idx, zero, P, T, denc, h, n_geo, in_pad, w, 2, save_act=False)
