@@ -429,21 +429,27 @@ def _run(args):
         noise = torch.rand(n_rays, 768, device=dev)
         _, xt = ops.sample_rays_xt(b["rays_o_lidar"].view(-1, 3).contiguous(), b["rays_d_lidar"].view(-1, 3).contiguous(), lin, noise,
                                    b["time"].view(-1), float(np.float32(model.near_lidar)), float(np.float32(model.far_lidar)), model.bound)
-        hash_enc = {"what": "static 3-D hash grid forward alone (l4d_hashgrid_fwd), ray-ordered samples of one batch, F = 4, 2^19-entry tables, fp16",
+        hash_enc = {"what": "static 3-D hash grid forward alone (l4d_hashgrid_fwd / l4d_hashgrid_fwd_ws), ray-ordered samples of one batch, F = 4, 2^19-entry tables, fp16; "
+                            "rows_kernel: one thread per point, all levels; xcd_pinned: level l on XCD l % 8 (table L2-resident), level-major scratch, row assembly (both kernels timed)",
                     "samples": xt.shape[0], "peak": HBM_PEAK_GBS, "unit": "GB/s", "target_frac": 0.40}
         for Lh in (8, 16):
             meta = GridMeta(3, Lh, 4, 19, 512, np.exp2(np.log2(32768 / 512) / (Lh - 1)))
             table = ((torch.rand(meta.n_params, device=dev) - 0.5)).half()
-            out = ops.hashgrid_fwd(meta, xt, (0, 1, 2), table)
-            torch.cuda.synchronize()
-            _lib.profile_start()
-            for _ in range(5):
-                ops.hashgrid_fwd(meta, xt, (0, 1, 2), table, out=out)
-            recs = _lib.profile_stop()
-            ms = sum(v for _, v in recs) / 5
-            gbs = Lh * 64 * xt.shape[0] / (ms * 1e-3) / 1e9
-            hash_enc[f"L{Lh}"] = {"ms": round(ms, 4), "algorithmic_bytes_per_sample": Lh * 64, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
-            del table, out
+            entry = {"algorithmic_bytes_per_sample": Lh * 64}
+            for tag, pinned in (("rows_kernel", False), ("xcd_pinned", True)):
+                out = ops.hashgrid_fwd(meta, xt, (0, 1, 2), table, xcd_pinned=pinned)
+                torch.cuda.synchronize()
+                _lib.profile_start()
+                for _ in range(5):
+                    ops.hashgrid_fwd(meta, xt, (0, 1, 2), table, out=out, xcd_pinned=pinned)
+                ms = sum(v for _, v in _lib.profile_stop()) / 5
+                gbs = Lh * 64 * xt.shape[0] / (ms * 1e-3) / 1e9
+                entry[tag] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                del out
+            best = max(("rows_kernel", "xcd_pinned"), key=lambda t: entry[t]["frac"])
+            entry.update(ms=entry[best]["ms"], achieved=entry[best]["achieved"], frac=entry[best]["frac"], variant=best)
+            hash_enc[f"L{Lh}"] = entry
+            del table
         variants = {}
         if use_chamfer or use_flow:
             trainer.chamfer = trainer.flow = False

@@ -63,6 +63,13 @@ int l4d_profile_get(int32_t i, const char** name /*host out*/, float* ms /*host 
 int l4d_hashgrid_fwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
                      const int32_t* cols /*host*/, const void* table, void* out, int32_t out_stride,
                      void* stream);
+/* The same with l4d_hashgrid_fwd_workspace() bytes of device scratch: level l is evaluated by the workgroups that land on XCD
+ * l % 8 (each XCD's L2 then holds one level's table instead of all of them), level-major into the scratch, and a second
+ * streaming kernel writes the rows.  Worthwhile from ~1e6 points with tables that exceed an L2 (4 MB). */
+int64_t l4d_hashgrid_fwd_workspace(const l4d_grid_desc* desc /*host*/, int64_t P);
+int l4d_hashgrid_fwd_ws(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
+                        const int32_t* cols /*host*/, const void* table, void* out, int32_t out_stride, void* workspace,
+                        void* stream);
 /* dout [P, dout_stride] fp16 (dout_is_half=1) or fp32; grad_table [n_entries, F] fp32, ACCUMULATED
  * into (atomics); gradient is multiplied by grad_scale before accumulation. */
 int l4d_hashgrid_bwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,

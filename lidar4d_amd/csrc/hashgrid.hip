@@ -77,6 +77,69 @@ __global__ void __launch_bounds__(HG_ROWS_THREADS) hashgrid_fwd_rows_kernel(Grid
   }
 }
 
+// native vector types (the non-temporal builtins do not take HIP's uint2 / uint4 structs)
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int F> struct NtVec;
+template <> struct NtVec<2> { typedef uint32_t type; };
+template <> struct NtVec<4> { typedef u32x2_t type; };
+template <> struct NtVec<8> { typedef u32x4_t type; };
+
+// Level <-> XCD pinning.  A level's table (4 MB at 2^19 entries x 8 B) is as large as one XCD's L2, and all eight XCDs
+// read every table: measured (tools/ubench/gather.hip), a gather that misses L2 costs 4.6x one that hits (64 G vs 292 G
+// lane-loads/s chip-wide), and the fine levels miss nearly always.  The dispatcher places block b on XCD b % 8, so here
+// block b works on level (b % 8) + 8 k only: each XCD's L2 then holds ONE level's table at a time and the gathers hit it.
+// The coordinate stream is read with non-temporal loads (it must not evict the table), results go level-major to a
+// scratch array (coalesced 2F-byte stores) and a second, streaming kernel assembles the [P, L * F] rows.
+// (Placement is a performance assumption only: any block -> XCD map gives the same result.)
+template <int D, int F>
+__global__ void __launch_bounds__(256) hashgrid_fwd_xcd_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
+                                                              Cols cols, const half_t* __restrict__ table, int64_t n_tiles,
+                                                              half_t* __restrict__ lvlT) {
+  const int xcd = blockIdx.x & 7;
+  const int64_t q = blockIdx.x >> 3;
+  const int li = (int)(q / n_tiles);
+  const int64_t tile = q - (int64_t)li * n_tiles;
+  const int lvl = xcd + 8 * li;
+  if (lvl >= desc.n_levels) return;
+  const int64_t p = tile * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float xin[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = __builtin_nontemporal_load(x + p * x_stride + cols.c[d]);
+  float acc[F];
+  level_lookup<D, F>(table + (size_t)desc.offset[lvl] * F, desc.scale[lvl], desc.res[lvl], desc.size[lvl],
+                     (desc.hashed_mask >> lvl) & 1u, xin, acc);
+  half_t h[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) h[f] = f2h(acc[f]);
+  typedef typename NtVec<F>::type V;
+  __builtin_nontemporal_store(*reinterpret_cast<V*>(h), reinterpret_cast<V*>(lvlT + ((int64_t)lvl * P + p) * F));
+}
+
+// rows [P, out_stride] <- level-major lvlT [L][P][F]; one thread per point, row staged in LDS, coalesced 16-byte stores
+template <int F>
+__global__ void __launch_bounds__(HG_ROWS_THREADS) hashgrid_rows_from_levels_kernel(int n_levels, int64_t P, const half_t* __restrict__ lvlT,
+                                                                                  half_t* __restrict__ out, int out_stride) {
+  extern __shared__ __attribute__((aligned(16))) half_t hg_stage[];
+  typedef typename NtVec<F>::type V;
+  const int width = n_levels * F, pitch = width + 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wave_p0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;
+  const int64_t p = min(wave_p0 + lane, P - 1);
+  half_t* row = hg_stage + (wave * 64 + lane) * pitch;
+  for (int lvl = 0; lvl < n_levels; ++lvl)
+    *reinterpret_cast<V*>(row + lvl * F) = __builtin_nontemporal_load(reinterpret_cast<const V*>(lvlT + ((int64_t)lvl * P + p) * F));
+  __syncthreads();
+  const half_t* wst = hg_stage + wave * 64 * pitch;
+  const int chunks = width / 8;
+  for (int i = lane; i < 64 * chunks; i += 64) {
+    const int r = i / chunks, c = i - r * chunks;
+    if (wave_p0 + r < P)
+      *reinterpret_cast<uint4*>(out + (wave_p0 + r) * out_stride + c * 8) = *reinterpret_cast<const uint4*>(wst + r * pitch + c * 8);
+  }
+}
+
 template <int D, int F, bool HALF_IN>
 __global__ void __launch_bounds__(256) hashgrid_bwd_kernel(GridDesc desc, const float* __restrict__ x, int64_t P,
                                                           int x_stride, Cols cols, const void* __restrict__ dout,
@@ -260,6 +323,38 @@ static inline Cols make_cols(const int32_t* cols, int D) {
   else if (D_ == 3 && F_ == 4) { CALL(3, 4) }            \
   else if (D_ == 3 && F_ == 8) { CALL(3, 8) }            \
   else { l4d_set_error(1, "hashgrid: unsupported n_dims/n_features"); return 1; }
+
+extern "C" int64_t l4d_hashgrid_fwd_workspace(const l4d_grid_desc* desc, int64_t P) {
+  return (int64_t)desc->n_levels * P * desc->n_features * 2;
+}
+
+extern "C" int l4d_hashgrid_fwd_ws(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride, const int32_t* cols,
+                                   const void* table, void* out, int32_t out_stride, void* workspace, void* stream) {
+  if (P == 0) return 0;
+  const int width = desc->n_levels * desc->n_features;
+  if (!workspace || width % 8 || out_stride % 8 || ((uintptr_t)out & 15) || (desc->n_features != 4 && desc->n_features != 8 && desc->n_features != 2))
+    return l4d_hashgrid_fwd(desc, x, P, x_stride, cols, table, out, out_stride, stream);
+  GridDesc g = make_grid_desc(desc);
+  Cols c = make_cols(cols, desc->n_dims);
+  const int64_t n_tiles = ceil_div64(P, 256);
+  const int rounds = (desc->n_levels + 7) / 8;
+  dim3 grid((unsigned)(n_tiles * rounds * 8)), block(256);
+#define CALL(D, F)                                                                                                        \
+  L4D_LAUNCH((hashgrid_fwd_xcd_kernel<D, F>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, (const half_t*)table, \
+             n_tiles, (half_t*)workspace);
+  DISPATCH_DF(desc->n_dims, desc->n_features, CALL)
+#undef CALL
+  const int lds = HG_ROWS_THREADS * (width + 8) * 2;
+  dim3 rgrid((unsigned)ceil_div64(P, HG_ROWS_THREADS)), rblock(HG_ROWS_THREADS);
+  if (desc->n_features == 2)
+    L4D_LAUNCH((hashgrid_rows_from_levels_kernel<2>), rgrid, rblock, lds, (hipStream_t)stream, desc->n_levels, P, (const half_t*)workspace, (half_t*)out, out_stride);
+  else if (desc->n_features == 4)
+    L4D_LAUNCH((hashgrid_rows_from_levels_kernel<4>), rgrid, rblock, lds, (hipStream_t)stream, desc->n_levels, P, (const half_t*)workspace, (half_t*)out, out_stride);
+  else
+    L4D_LAUNCH((hashgrid_rows_from_levels_kernel<8>), rgrid, rblock, lds, (hipStream_t)stream, desc->n_levels, P, (const half_t*)workspace, (half_t*)out, out_stride);
+  L4D_LAUNCH_CHECK("l4d_hashgrid_fwd_ws");
+  return 0;
+}
 
 extern "C" int l4d_hashgrid_fwd(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride,
                                 const int32_t* cols, const void* table, void* out, int32_t out_stride,

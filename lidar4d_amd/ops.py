@@ -14,6 +14,7 @@ def call(name, *args):
     _lib.call(name, *args)
 
 
+XCD_PINNED_MIN_POINTS = 1 << 20           # stand-alone hash-grid forward: level <-> XCD pinning from here on
 PLANE_ROWS_MIN_POINTS = 1 << 12           # below this the row build (a launch) costs more than the saved taps
 LDS_DYNHASH_MIN_POINTS = 1 << 15          # below this the per-sample direct-gather path wins (table fills dominate)
 BINNED_SCATTER_MIN_RECORDS = 1 << 16  # below this the global-atomic path is cheaper than two extra launches
@@ -53,7 +54,7 @@ def _ptrs(tensors):
 
 
 # ---- hash grid -----------------------------------------------------------------------------------
-def hashgrid_fwd(meta, x, cols, table16, out=None, out_col=0):
+def hashgrid_fwd(meta, x, cols, table16, out=None, out_col=0, xcd_pinned=None):
     """x [P, S] fp32 (grid coords = columns ``cols``), table16 fp16 flat -> out [P, >= L*F] fp16."""
     _chk(x, torch.float32, "x"), _chk(table16, torch.float16, "table")
     P = x.shape[0]
@@ -61,6 +62,13 @@ def hashgrid_fwd(meta, x, cols, table16, out=None, out_col=0):
         out = torch.empty(P, meta.n_output_dims, dtype=torch.float16, device=x.device)
     _chk(out, torch.float16, "out")
     d = meta.desc()
+    if xcd_pinned is None:
+        xcd_pinned = P >= XCD_PINNED_MIN_POINTS and max(meta.size) * meta.n_features * 2 >= (2 << 20)
+    if xcd_pinned:  # one level per XCD at a time (its table stays in that XCD's L2), level-major scratch, then rows
+        ws = torch.empty(_lib.lib().l4d_hashgrid_fwd_workspace(C.byref(d), P), dtype=torch.uint8, device=x.device)
+        call("l4d_hashgrid_fwd_ws", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _p(table16),
+             C.c_void_p(out.data_ptr() + 2 * out_col), out.stride(0), _p(ws), _stream())
+        return out
     call("l4d_hashgrid_fwd", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _p(table16),
          C.c_void_p(out.data_ptr() + 2 * out_col), out.stride(0), _stream())
     return out

@@ -33,6 +33,8 @@ int main(void) {
       (fn_t)&l4d_grad_nonfinite_check,
       (fn_t)&l4d_hashgrid_bwd,
       (fn_t)&l4d_hashgrid_fwd,
+      (fn_t)&l4d_hashgrid_fwd_workspace,
+      (fn_t)&l4d_hashgrid_fwd_ws,
       (fn_t)&l4d_hashgrid_t_bwd,
       (fn_t)&l4d_hashgrid_t_bwd_workspace,
       (fn_t)&l4d_hashgrid_t_fwd,
