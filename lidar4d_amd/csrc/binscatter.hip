@@ -16,13 +16,16 @@
 //
 // Non-hashed (dense, coarse) levels fall back to run-reduced global atomics.
 #include <algorithm>
+#include <cstdlib>
 
 #include "hashgrid_dev.h"
 #include "wave_dev.h"
 #include "binscatter.h"
 
 #define BS_THREADS 512
-#define BS_MAX_BINS 128
+#ifndef BS_MAX_BINS
+#define BS_MAX_BINS 256
+#endif
 #ifndef BS_GROUP
 #define BS_GROUP 8
 #endif
@@ -30,39 +33,8 @@
 #define BS_UNROLL 1
 #endif
 
-// Record = key dword + NV fp16 payload values + (pair records) the x fraction as unorm16.
-//   key  bits 0..23  entry (level-local);  bits 24..28  k;  bit 31  SINGLE
-//   SINGLE: the payload goes to `entry` as it is (one corner; used for run-merged coarse levels and the rare pair that
-//           straddles a bin boundary).
-//   pair:   the two corners that differ in x only.  On a hashed level idx = (x ^ h(y, z)) & mask, so the second corner's
-//           entry is  entry ^ (((2 << k) - 1) & mask)  with k = number of trailing one bits of the cell's x: it is almost
-//           always in the same bin (same cache line 7 times out of 8), and one record { entry, k, w_yz * g, frac_x } serves
-//           both: v0 = payload * (1 - fx), v1 = payload * fx.  Half as many records to rank, 2/3 of the bytes.
 template <int NV>
-struct RecWords { static constexpr int n = NV == 4 ? 4 : NV == 2 ? 3 : 2; };
-#define BS_SINGLE 0x80000000u
-__device__ __forceinline__ uint32_t pair_partner(uint32_t entry, uint32_t k, uint32_t mask) { return entry ^ (((2u << k) - 1u) & mask); }
-template <int NV>
-__device__ __forceinline__ void rec_pack(uint32_t* dst, uint32_t key, const float v[NV], float fx) {
-  half_t hv[4] = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
-#pragma unroll
-  for (int j = 0; j < NV; ++j) hv[j] = f2h_grad(v[j]);
-  const uint32_t fxq = (uint32_t)__float2int_rn(fx * 65535.0f);
-  const uint32_t* hw = reinterpret_cast<const uint32_t*>(hv);
-  dst[0] = key;
-  if (NV == 4) { dst[1] = hw[0]; dst[2] = hw[1]; dst[3] = fxq; }
-  else if (NV == 2) { dst[1] = hw[0]; dst[2] = fxq; }
-  else { dst[1] = (hw[0] & 0xFFFFu) | (fxq << 16); }
-}
-template <int NV>
-__device__ __forceinline__ void rec_unpack(const uint32_t* w, float v[NV], float& fx) {
-  uint32_t hw[2] = {w[1], NV == 4 ? w[2] : 0u};
-  const half_t* hv = reinterpret_cast<const half_t*>(hw);
-#pragma unroll
-  for (int j = 0; j < NV; ++j) v[j] = h2f(hv[j]);
-  const uint32_t fxq = NV == 4 ? w[3] : NV == 2 ? w[2] : (w[1] >> 16);
-  fx = (float)(fxq & 0xFFFFu) * (1.0f / 65535.0f);
-}
+struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
 
 template <int D, int NV>
 __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
@@ -76,7 +48,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   // LDS atomics onto every counter
   constexpr int NWAVES = BS_THREADS / 64;
   __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
-  extern __shared__ uint32_t stage[];  // [BS_THREADS * NC * NW]: up to one SINGLE record per corner (64 KB at D = 3, NV = 4)
+  __shared__ uint32_t stage[BS_THREADS * NC * NW];
   __shared__ uint32_t total_s;
   // Block order: the n_levels passes over one tile of samples read the same xyz rows and the same cache lines of the
   // gradient rows (a level's 2-8 bytes out of a 128-B line).  They are placed next to each other in time AND on one XCD
@@ -117,12 +89,10 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   float vals[NC][NV];
   bool emit[NC];
   uint32_t pos[NC];
-  float fxs_[NC];  // pair records: x fraction
   const bool wave_any = __any(any);
   // Consecutive lanes are consecutive samples of a ray: on coarse levels several of them sit in one cell and hit the same
-  // 2^D entries.  Binned levels merge such runs inside 16-lane rows with the DPP scan (one SINGLE record per run and
-  // corner); where there is nothing to merge (the fine levels: most of the volume) the two x-neighbours of a cell share a
-  // pair record.  The dense fallback keeps the wave-wide shuffle reduction (global atomics are the expensive resource there).
+  // 2^D entries.  Binned levels merge such runs inside 16-lane rows with the DPP scan (one record per run and corner);
+  // the dense fallback keeps the wave-wide shuffle reduction (global atomics are the expensive resource there).
   int n_heads = 64;
   RowRuns runs;
   bool use_scan = false;
@@ -138,14 +108,11 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
     runs = row_runs((uint32_t)__popcll(brk & (~0ull >> (63 - lane))), &n_heads);
     use_scan = n_heads <= 56;  // wave-uniform: otherwise there is nothing worth merging
   }
-  const bool pow2 = (size & (size - 1)) == 0;
-  const bool pair_mode = binned && !use_scan && pow2 && size <= (1u << 24);  // wave-uniform
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     uint32_t gg[D];
     const float w = corner<D>(c, k, gg);
     keys[k] = grid_index<D>(gg, desc.res[lvl], size, hashed);
-    fxs_[k] = 0.0f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) vals[k][j] = w * gv[j];
     if (binned) {
@@ -163,26 +130,6 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
       for (int j = 0; j < NV; ++j) nz |= vals[k][j] != 0.0f;
       emit[k] = nz;
     }
-    keys[k] |= BS_SINGLE;  // default: one record per corner
-  }
-  if (pair_mode) {
-    const uint32_t mask = size - 1u;
-    const uint32_t kx = (uint32_t)__builtin_ctz(~c.cell[0] | 0x80000000u);  // trailing ones of the cell's x (capped at 31)
-    const uint32_t m = ((2u << kx) - 1u) & mask;
-#pragma unroll
-    for (int k = 0; k < NC; k += 2) {  // corner k: x bit clear; corner k + 1: x + 1
-      const uint32_t e0 = keys[k] & 0xFFFFFFu, e1 = keys[k + 1] & 0xFFFFFFu;
-      const bool same_bin = ((e0 ^ e1) >> shift) == 0;
-      if (same_bin && (e0 ^ m) == e1) {  // (the second test always holds on a hashed power-of-two level; kept as a guard)
-        // payload = w_yz * g = (vals[k] + vals[k + 1]): exact partition, fraction re-applied in pass 2
-#pragma unroll
-        for (int j = 0; j < NV; ++j) vals[k][j] = vals[k][j] + vals[k + 1][j];
-        keys[k] = e0 | (kx << 24);
-        fxs_[k] = c.frac[0];
-        emit[k] = emit[k] || emit[k + 1];
-        emit[k + 1] = false;
-      }
-    }
   }
   if (!binned) {  // dense / tiny level: run-reduced atomics straight into the output (block-uniform branch)
     float* o = out + (size_t)desc.offset[lvl] * NV;
@@ -191,7 +138,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
       if (emit[k]) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-          if (vals[k][j] != 0.0f) atomicAdd(o + (size_t)(keys[k] & 0xFFFFFFu) * NV + j, vals[k][j] * out_scale);
+          if (vals[k][j] != 0.0f) atomicAdd(o + (size_t)keys[k] * NV + j, vals[k][j] * out_scale);
       }
     return;
   }
@@ -201,7 +148,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   // rank inside the workgroup
   const int wave_id = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[wave_id][(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
+  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[wave_id][keys[k] >> shift], 1u) : 0u;
   __syncthreads();
   if (threadIdx.x < BS_MAX_BINS) {  // exclusive prefix over the waves of each bin; hist[0][b] <- bin total
     uint32_t run = 0;
@@ -214,33 +161,48 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   }
   __syncthreads();
   const uint64_t wg_slot = (uint64_t)lvl * n_wg + tile;
-  if (threadIdx.x < 64) {  // exclusive scan of <= 128 bins by one wave
-    uint32_t c0 = lane < nbins ? boff[lane] : 0u, c1 = lane + 64 < nbins ? boff[lane + 64] : 0u;
-    uint32_t inc0 = c0, inc1 = c1;
+  if (threadIdx.x < 64) {  // exclusive scan of the bin totals by one wave: BPL consecutive bins per lane
+    constexpr int BPL = BS_MAX_BINS / 64;
+    uint32_t c[BPL], sum = 0;
+#pragma unroll
+    for (int q = 0; q < BPL; ++q) {
+      const int b = lane * BPL + q;
+      c[q] = b < nbins ? boff[b] : 0u;
+      sum += c[q];
+    }
+    uint32_t inc = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      uint32_t a = __shfl_up(inc0, d, 64), b = __shfl_up(inc1, d, 64);
-      if (lane >= d) { inc0 += a; inc1 += b; }
+      const uint32_t a = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += a;
     }
-    const uint32_t tot0 = __shfl(inc0, 63, 64);
     uint16_t* o = offs + wg_slot * (BS_MAX_BINS + 1);
-    boff[lane] = inc0 - c0;
-    boff[lane + 64] = tot0 + inc1 - c1;
-    o[lane] = (uint16_t)(inc0 - c0);
-    o[lane + 64] = (uint16_t)(tot0 + inc1 - c1);
+    uint32_t excl = inc - sum;
+#pragma unroll
+    for (int q = 0; q < BPL; ++q) {
+      const int b = lane * BPL + q;
+      boff[b] = excl;
+      o[b] = (uint16_t)excl;
+      excl += c[q];
+    }
     if (lane == 63) {
-      total_s = tot0 + inc1;
-      boff[BS_MAX_BINS] = tot0 + inc1;
-      o[BS_MAX_BINS] = (uint16_t)(tot0 + inc1);
+      total_s = inc;
+      boff[BS_MAX_BINS] = inc;
+      o[BS_MAX_BINS] = (uint16_t)inc;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < NC; ++k)
     if (emit[k]) {
-      const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
+      const uint32_t b = keys[k] >> shift;
       const uint32_t r = boff[b] + hist[wave_id][b] + pos[k];
-      rec_pack<NV>(&stage[r * NW], keys[k], vals[k], fxs_[k]);
+      stage[r * NW] = keys[k];
+      half_t hv[2 * (NW - 1)];
+#pragma unroll
+      for (int j = 0; j < 2 * (NW - 1); ++j) hv[j] = j < NV ? f2h_grad(vals[k][j]) : (half_t)0.0f;
+#pragma unroll
+      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = reinterpret_cast<uint32_t*>(hv)[q];
     }
   __syncthreads();
   const uint32_t total = total_s;
@@ -275,27 +237,12 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   // then its records): small groups = many independent chains in flight, which is what hides that latency
   constexpr int NGRP = 1024 / BS_GROUP;
   const int grp = threadIdx.x / BS_GROUP, l16 = threadIdx.x % BS_GROUP;
-  const uint32_t emask = size - 1u;  // pair records only exist on power-of-two levels
-  auto add1 = [&](uint32_t entry, const float v[NV], float w) {
+  auto add = [&](uint32_t key, const uint32_t* wd) {
+    const half_t* hv = reinterpret_cast<const half_t*>(wd);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const float t = v[j] * w;
-      if (t != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(entry - lo) * NV + j]), (unsigned long long)__float2ll_rn(t * fxs));
-    }
-  };
-  auto add = [&](uint32_t key, const uint32_t* wd) {  // wd[0 .. NW - 2]: the record's words after the key
-    uint32_t w[NW];
-    w[0] = key;
-#pragma unroll
-    for (int q = 0; q < NW - 1; ++q) w[1 + q] = wd[q];
-    float v[NV], fx;
-    rec_unpack<NV>(w, v, fx);
-    const uint32_t entry = key & 0xFFFFFFu;
-    if (key & BS_SINGLE) {
-      add1(entry, v, 1.0f);
-    } else {
-      add1(entry, v, 1.0f - fx);
-      add1(pair_partner(entry, (key >> 24) & 31u, emask), v, fx);
+      const float v = h2f(hv[j]);
+      if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(key - lo) * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
     }
   };
   // BS_UNROLL runs (pass-1 workgroups) per group and iteration: their offset loads, and then the first record of each, are
@@ -316,7 +263,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
 #pragma unroll
     for (int u = 0; u < BS_UNROLL; ++u) {
       const uint32_t r = s0[u] + l16;
-      key0[u] = lo | BS_SINGLE;  // an absent record: zero payload, no atomics
+      key0[u] = lo;
 #pragma unroll
       for (int q = 0; q < NW - 1; ++q) wd0[u][q] = 0u;
       if (r < s1[u]) {
@@ -327,7 +274,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
     }
 #pragma unroll
     for (int u = 0; u < BS_UNROLL; ++u) {
-      add(key0[u], wd0[u]);
+      add(key0[u], wd0[u]);  // an absent record carries zeros: no atomics issued
       for (uint32_t r = s0[u] + l16 + BS_GROUP; r < s1[u]; r += BS_GROUP) {
         uint32_t wd[NW - 1];
 #pragma unroll
@@ -346,12 +293,19 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-static int bs_shift(int NV) { return NV == 4 ? 12 : NV == 2 ? 12 : 13; }  // <= 128 KB of int64 per bin; more, smaller bins also spread the pass-1 histogram atomics
+// Entries per bin = 2^shift: the bin's int64 accumulators take 2^shift * NV * 8 bytes of LDS in pass 2 (64 KB -> two
+// workgroups per CU, which is what hides the latency of the record walk), and more, smaller bins spread the pass-1
+// histogram atomics.  L4D_BS_SHIFT4 / L4D_BS_SHIFT2 override (tuning).
+static int bs_shift(int NV) {
+  const char* e = getenv(NV == 4 ? "L4D_BS_SHIFT4" : NV == 2 ? "L4D_BS_SHIFT2" : "L4D_BS_SHIFT1");
+  if (e && atoi(e) >= 9 && atoi(e) <= 13) return atoi(e);
+  return NV == 4 ? 11 : NV == 2 ? 12 : 13;
+}
 
 BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
   BsPlan pl;
   pl.shift = bs_shift(NV);
-  pl.rec_words = NV == 4 ? 4 : NV == 2 ? 3 : 2;
+  pl.rec_words = 1 + (NV + 1) / 2;
   pl.n_wg = ceil_div64(P, BS_THREADS);
   const int64_t rec_per_wg = (int64_t)BS_THREADS << n_dims;
   pl.off_max = 0;
@@ -364,8 +318,6 @@ BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
 int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t P, int x_stride, const int* cols, const half_t* g,
                int g_stride, int g_col, float pre_scale, float* out, float out_scale, void* workspace, hipStream_t stream) {
   if (P == 0) return 0;
-  for (int l = 0; l < desc.n_levels; ++l)
-    if (desc.size[l] > (1u << 24)) { l4d_set_error(1, "bs_scatter: levels of more than 2^24 entries are not supported (record key)"); return 1; }
   const BsPlan pl = bs_plan(desc, n_dims, NV, P);
   char* ws = (char*)workspace;
   float* lvl_max = (float*)(ws + pl.off_max);
@@ -383,9 +335,7 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   const int lds2 = (1 << pl.shift) * NV * 8;
 #define BS_LAUNCH(D, V)                                                                                                      \
   {                                                                                                                          \
-    const int lds1 = BS_THREADS * (1 << D) * RecWords<V>::n * 4;                                                             \
-    (void)hipFuncSetAttribute((const void*)bin_pass1_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);        \
-    L4D_LAUNCH((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), lds1, stream, desc, x, P, x_stride, c, g, g_stride,   \
+    L4D_LAUNCH((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
                        g_col, pre_scale, pl.shift, (int64_t)pl.n_wg, offs, bins, lvl_max, out, out_scale);                                     \
     (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);              \
     L4D_LAUNCH((bin_pass2_kernel<D, V>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
