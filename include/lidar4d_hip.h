@@ -241,12 +241,13 @@ int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, const float* li
                        const float* t, int64_t N, int32_t T, float near, float far, float bound, float* z_vals,
                        float* xt, void* stream);
 /* flow16 [P,16] fp16: flow network output (cols 0-2 forward, 3-5 backward); X [P,in_pad] fp16.
- * hd_scratch: null, or (levels of the 3 dynamic grids) * P fp16 of device scratch -> the 2-D x time hash stacks are
+ * hd_scratch: null, or l4d_density_encode_fwd_workspace() bytes of device scratch -> the xz / yz 2-D x time hash stacks are
  * evaluated by a separate kernel from LDS-resident slice tables (faster from ~1e5 samples).
  * plane_rows: null, or l4d_plane_rows_workspace() bytes of device scratch -> the time planes are first reduced to the
  * 1-D rows of the call's three frame times (their time coordinate is the same for every sample) and sampled with two
  * taps instead of four. */
 int64_t l4d_plane_rows_workspace(const l4d_field_desc* f /*host*/);
+int64_t l4d_density_encode_fwd_workspace(const l4d_field_desc* f /*host*/, int64_t P);
 int l4d_density_encode_fwd(const l4d_field_desc* f /*host*/, const float* xt, const void* flow16,
                            const float* tinfo, int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows,
                            void* stream);

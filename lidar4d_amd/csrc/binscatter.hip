@@ -22,7 +22,9 @@
 #include "wave_dev.h"
 #include "binscatter.h"
 
+#ifndef BS_THREADS
 #define BS_THREADS 512
+#endif
 #ifndef BS_MAX_BINS
 #define BS_MAX_BINS 256
 #endif
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   // LDS atomics onto every counter
   constexpr int NWAVES = BS_THREADS / 64;
   __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
-  __shared__ uint32_t stage[BS_THREADS * NC * NW];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[BS_THREADS * NC * NW];
   __shared__ uint32_t total_s;
   // Block order: the n_levels passes over one tile of samples read the same xyz rows and the same cache lines of the
   // gradient rows (a level's 2-8 bytes out of a 128-B line).  They are placed next to each other in time AND on one XCD
@@ -207,7 +209,9 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   __syncthreads();
   const uint32_t total = total_s;
   uint32_t* dst = bins + wg_slot * (uint64_t)(BS_THREADS * NC * NW);
-  for (uint32_t dw = threadIdx.x; dw < total * NW; dw += blockDim.x) dst[dw] = stage[dw];  // already sorted by bin
+  // already sorted by bin; 16 bytes per lane (the slot is 16-byte aligned and large enough for the rounded-up tail)
+  const uint32_t n16 = (total * NW + 3) >> 2;
+  for (uint32_t q = threadIdx.x; q < n16; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
 }
 
 template <int D, int NV>

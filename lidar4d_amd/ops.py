@@ -351,8 +351,7 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
     scratch = None
     if P >= LDS_DYNHASH_MIN_POINTS and max(field_desc.hash_dynamic[1].size[field_desc.hash_dynamic[1].n_levels - 1],
                                            field_desc.hash_dynamic[2].size[field_desc.hash_dynamic[2].n_levels - 1]) <= 8192:
-        n_dyn = sum(field_desc.hash_dynamic[i].n_levels for i in range(3))
-        scratch = torch.empty(n_dyn * P, dtype=torch.float16, device=xt.device)
+        scratch = torch.empty(_lib.lib().l4d_density_encode_fwd_workspace(C.byref(field_desc), P), dtype=torch.uint8, device=xt.device)
     rows = None
     if P >= PLANE_ROWS_MIN_POINTS:  # time planes through per-call 1-D rows (two taps instead of four)
         rows = torch.empty(_lib.lib().l4d_plane_rows_workspace(C.byref(field_desc)) // 4, dtype=torch.float32, device=xt.device)
