@@ -380,6 +380,17 @@ def _run(args):
         peaks = {"hbm": HBM_PEAK_GBS, "l2": L2_PEAK_GBS, "lds": LDS_PEAK_GBS}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic_r02.json")
         traffic = json.load(open(tpath)).get("kernels", {}) if os.path.exists(tpath) and args.workload == "c3" else {}
+        pmc_path = os.path.join(ROOT, "profiles", "r02_mfma_pmc.json")
+        mfma_pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) and args.workload == "c3" else {}
+        def pmc_lookup(table, name):
+            """profiles/ keys carry every template argument (rocprofv3's symbol), launch-site names only the explicit ones."""
+            if name in table:
+                return table[name]
+            for k, v in table.items():
+                if name.endswith(">") and k.startswith(name[:-1] + ","):
+                    return v
+            return None
+
         rows, mf = [], []
         for name, times in kernels.items():
             row = {"kernel": name, "ms_per_step": round(per_step[name], 3), "launches_per_step": len(times) / args.profile_steps,
@@ -394,13 +405,15 @@ def _run(args):
                 ach = mod["bytes"] / (avg_ms * 1e-3) / 1e9
                 row.update(bound=mod["bound"], bytes_per_launch=mod["bytes"], modelled_launches_per_step=len(big) / args.profile_steps,
                            modelled_launch_ms=round(avg_ms, 4), achieved=round(ach, 1), peak=peaks[mod["bound"]], unit="GB/s",
-                           frac=round(ach / peaks[mod["bound"]], 4), traffic=traffic.get(name), note=mod["note"])
+                           frac=round(ach / peaks[mod["bound"]], 4), traffic=pmc_lookup(traffic, name), note=mod["note"])
                 if "hbm" in mod:
                     row["compulsory_hbm_GBps"] = round(mod["hbm"] / (avg_ms * 1e-3) / 1e9, 1)
                     row["compulsory_hbm_frac"] = round(row["compulsory_hbm_GBps"] / HBM_PEAK_GBS, 4)
                 if "flops" in mod:
                     tf = mod["flops"] / (avg_ms * 1e-3) / 1e12
-                    mf.append({"kernel": name, "algorithmic_tflops": round(tf, 1), "frac_of_dense_f16_peak": round(tf / MFMA_F16_PEAK_TFLOPS, 4)})
+                    pm = pmc_lookup(mfma_pmc.get("kernels", {}), name)
+                    mf.append({"kernel": name, "algorithmic_tflops": round(tf, 1), "frac_of_dense_f16_peak": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+                               "pmc_mfma_util_percent": pm["mfma_util_percent"] if pm else None})
             rows.append(row)
         rows.sort(key=lambda r: -r["ms_per_step"])
         roofline_kernels = rows
@@ -414,10 +427,11 @@ def _run(args):
                                       "lds": "table-entry bytes served from LDS"}[d["bound"]],
                         "compulsory_hbm_GBps": d.get("compulsory_hbm_GBps"), "compulsory_hbm_frac": d.get("compulsory_hbm_frac"),
                         "samples_per_launch": P, "attribute_rows": M}
-        pmc_path = os.path.join(ROOT, "profiles", "r02_mfma_pmc.json")
         mfma = {"kernels": mf, "peak_tflops": MFMA_F16_PEAK_TFLOPS,
-                "pmc": json.load(open(pmc_path)) if os.path.exists(pmc_path) else None,
-                "note": "MLPs are 18-55 kFLOP per sample (SURVEY 8d): the matrix cores are a few % busy at HBM-streaming speed; the binding roof of these kernels is HBM"}
+                "pmc_source": "profiles/r02_mfma_pmc.json (rocprofv3 --pmc pass of this command: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))" if mfma_pmc else None,
+                "note": "algorithmic flops = the network's multiply-adds; the backward kernels execute about twice that on the matrix cores (operands are "
+                        "produced in both orientations instead of being transposed through LDS), which is why their PMC utilisation is higher. "
+                        "MLPs are 18-55 kFLOP per sample (SURVEY 8d): these kernels are bound by HBM streaming of their rows, not by the MFMA rate"}
 
     # ---- secondary measurements (single GPU): hash encoder alone, three-loss step, trained state ----
     hash_enc, variants = None, None

@@ -108,7 +108,9 @@ int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc /*host*/, const float* x, int64
  */
 int l4d_planes_relayout(const float* const* planes /*host: n_scales*6 device ptrs, [1,C,H,W]*/,
                         const int32_t* res /*host*/, int32_t n_scales, int32_t C, float* planes_cl,
-                        const int64_t* plane_off /*host*/, int32_t to_channel_last, void* stream);
+                        const int64_t* plane_off /*host*/,
+                        int32_t to_channel_last /*1: planes -> planes_cl; 0: planes_cl -> planes; 2: planes += planes_cl*/,
+                        void* stream);
 int l4d_planes_fwd(const float* planes_cl, const int64_t* plane_off /*host*/, const int32_t* res /*host*/,
                    int32_t n_scales, int32_t C, const float* xt, int64_t P, int32_t which, float* out_s,
                    float* out_d, void* stream);

@@ -52,20 +52,25 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
   __shared__ __attribute__((aligned(16))) uint32_t stage[BS_THREADS * NC * NW];
   __shared__ uint32_t total_s;
-  // Block order: the n_levels passes over one tile of samples read the same xyz rows and the same cache lines of the
-  // gradient rows (a level's 2-8 bytes out of a 128-B line).  They are placed next to each other in time AND on one XCD
-  // (blocks b, b+8, b+16, ... share an XCD and its L2): block = (8 L) q + 8 level + x  ->  tile 8 q + x.
-  // (With level as the slow grid dimension every line was fetched from the fabric once per level: 16.7 GB instead of ~5.)
+  // One workgroup walks ALL levels of its tile of samples.  (Earlier: one workgroup per (tile, level), ordered level-fast
+  // and XCD-aware so that the levels of a tile at least met in one L2.  Every such workgroup started with a cold,
+  // 256-byte-strided read of its level's 2-8 bytes of the gradient rows and sat out that latency at two workgroups per
+  // CU.)  The coordinates are read once, a level's gradient values are fetched while the previous level is being ranked.
   const int n_lv = desc.n_levels;
-  const int64_t bq = blockIdx.x / (8 * n_lv);
-  const int br = (int)(blockIdx.x - bq * 8 * n_lv);
-  const int lvl = br >> 3;
-  const int64_t tile = bq * 8 + (br & 7);
+  const int64_t tile = xcd_tile(blockIdx.x, gridDim.x);
   if (tile >= n_wg) return;  // block-uniform, before any barrier
   const int lane = __lane_id();
   const int64_t pr = tile * blockDim.x + threadIdx.x;
   const bool valid = pr < P;
   const int64_t p = valid ? pr : P - 1;
+  float xin[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = x[p * x_stride + cols.c[d]];
+  const half_t* grow = g + p * g_stride + g_col;
+  half_t gnext[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) gnext[j] = grow[j];
+  for (int lvl = 0; lvl < n_lv; ++lvl) {
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   const uint32_t size = desc.size[lvl];
   const int nbins = (int)((size + (1u << shift) - 1) >> shift);
@@ -76,16 +81,18 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   float amax = 0.0f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    gv[j] = valid ? h2f(g[p * g_stride + g_col + lvl * NV + j]) * pre_scale : 0.0f;
+    gv[j] = valid ? h2f(gnext[j]) * pre_scale : 0.0f;
     any |= gv[j] != 0.0f;
     amax = amax_nf(amax, gv[j]);
   }
+  if (lvl + 1 < n_lv) {  // the next level's values: in flight during this level's ranking
+#pragma unroll
+    for (int j = 0; j < NV; ++j) gnext[j] = grow[(lvl + 1) * NV + j];
+  }
+  __syncthreads();  // the previous level's copy-out has finished reading the staging buffer / bin offsets
   for (int i = threadIdx.x; i < NWAVES * BS_MAX_BINS; i += BS_THREADS) (&hist[0][0])[i] = 0;
   __syncthreads();
 
-  float xin[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) xin[d] = x[p * x_stride + cols.c[d]];
   Cell<D> c = locate<D>(xin, desc.scale[lvl]);
   uint32_t keys[NC];
   float vals[NC][NV];
@@ -142,7 +149,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
         for (int j = 0; j < NV; ++j)
           if (vals[k][j] != 0.0f) atomicAdd(o + (size_t)keys[k] * NV + j, vals[k][j] * out_scale);
       }
-    return;
+    continue;  // block-uniform: next level
   }
   amax = wave_max(amax);
   if (lane == 0 && amax > 0.0f) atomic_max_nonneg(lvl_max + lvl, amax);
@@ -212,6 +219,7 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
   // already sorted by bin; 16 bytes per lane (the slot is 16-byte aligned and large enough for the rounded-up tail)
   const uint32_t n16 = (total * NW + 3) >> 2;
   for (uint32_t q = threadIdx.x; q < n16; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
+  }  // levels
 }
 
 template <int D, int NV>
@@ -334,7 +342,7 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   int max_bins = 1;
   for (int l = 0; l < desc.n_levels; ++l) max_bins = std::max<int>(max_bins, (int)(((int64_t)desc.size[l] + (1 << pl.shift) - 1) >> pl.shift));
   max_bins = std::min(max_bins, BS_MAX_BINS);
-  dim3 grid1((unsigned)(ceil_div64(pl.n_wg, 8) * 8 * desc.n_levels));
+  dim3 grid1((unsigned)xcd_grid(pl.n_wg));
   dim3 grid2(max_bins, desc.n_levels);
   const int lds2 = (1 << pl.shift) * NV * 8;
 #define BS_LAUNCH(D, V)                                                                                                      \

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
                                                             const float* __restrict__ tinfo,
                                                             int64_t P, const half_t* __restrict__ dX, int in_pad, float pscale,
                                                             half_t* __restrict__ gvs, half_t* __restrict__ gdynT,
-                                                            float* __restrict__ stats, int staged) {
+                                                            float* __restrict__ stats, int staged, float* __restrict__ xsoa) {
   constexpr int C = 8;
   extern __shared__ __attribute__((aligned(16))) half_t prep_lds[];
   const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,6 +74,10 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
   const float t0 = tinfo[0];
   const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
   const float x0[4] = {c4[0], c4[1], c4[2], t0};
+  if (valid) {  // coordinates once more as [3][P]: the multi-pass kernels below read one or two of them per sample and pass,
+#pragma unroll  // densely, instead of 16-byte xt rows
+    for (int a = 0; a < 3; ++a) xsoa[(int64_t)a * P + pr] = c4[a];
+  }
   const int nS = fd.planes.n_scales;
   const half_t* row = dX + p * in_pad;
   int dyn_shift = 0;  // staged: the dynamic-hash columns sit right behind the plane columns in the LDS row
@@ -356,6 +360,7 @@ struct BandTasks {
   short s[MAX_TASKS], j[MAX_TASKS], row0[MAX_TASKS], nrows[MAX_TASKS];
 };
 
+// xt here: the [3][P] coordinate arrays the prep kernel wrote (xsoa)
 __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, BandTasks tasks, float* __restrict__ garena,
                                                                const float* __restrict__ xt, int64_t P, int64_t chunk,
                                                                int wave_skip, const half_t* __restrict__ gvs, float pscale,
@@ -388,8 +393,8 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
         const int64_t pl = min(pw + 63, hi_p - 1);
         int r0a, r1a, r0b, r1b;
         float w0, w1, m;
-        axis_tap(xt[pw * 4 + b], H, r0a, r1a, w0, w1, m);
-        axis_tap(xt[pl * 4 + b], H, r0b, r1b, w0, w1, m);
+        axis_tap(xt[(int64_t)b * P + pw], H, r0a, r1a, w0, w1, m);
+        axis_tap(xt[(int64_t)b * P + pl], H, r0b, r1b, w0, w1, m);
         hit = !(max(r1a, r1b) < row0 || min(r0a, r0b) >= row0 + nrows);
       }
       todo = __ballot(hit);
@@ -402,7 +407,7 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
     const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
     const bool active = pr < hi_p;
     const int64_t p = active ? pr : hi_p - 1;
-    const float ca = xt[p * 4 + a], cb = xt[p * 4 + b];
+    const float ca = xt[(int64_t)a * P + p], cb = xt[(int64_t)b * P + p];
     Tap t;
     axis_tap(cb, H, t.y0, t.y1, t.wy0, t.wy1, t.my);
     const bool in0 = active && t.y0 >= row0 && t.y0 < row0 + nrows;
@@ -460,6 +465,7 @@ struct HashTasks {
   int hoff[MAX_TASKS];  // offset of (plane, level) in Hbuf
 };
 
+// xt here: the [3][P] coordinate arrays the prep kernel wrote (xsoa)
 __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTasks tasks, const float* __restrict__ xt, int64_t P,
                                                          int64_t chunk, const half_t* __restrict__ gdynT,
                                                          const float* __restrict__ stats, float* __restrict__ Hbuf) {
@@ -487,7 +493,7 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
   for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {  // hashed 2-D cells: no same-address pile-up
     const float go = h2f(gcol[p]);
     if (go == 0.0f) continue;
-    const float q[2] = {xt[p * 4 + ca], xt[p * 4 + cb]};
+    const float q[2] = {xt[(int64_t)ca * P + p], xt[(int64_t)cb * P + p]};
     Cell<2> c = locate<2>(q, scale);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -536,7 +542,7 @@ __global__ void __launch_bounds__(256) dynhash_expand_kernel(FieldDesc fd, Field
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WorkLayout {
-  int64_t gvs, gdynT, stats, hbuf, bins, total;
+  int64_t gvs, gdynT, xsoa, stats, hbuf, bins, total;
   int64_t hbuf_floats;
 };
 static WorkLayout work_layout(const l4d_field_desc* f, int64_t P) {
@@ -550,7 +556,8 @@ static WorkLayout work_layout(const l4d_field_desc* f, int64_t P) {
   w.hbuf = align256(ST_SIZE * 4);
   w.gvs = w.hbuf + align256(hb * 4);
   w.gdynT = w.gvs + align256(P * f->n_scales * 3 * 8 * 2);
-  w.bins = w.gdynT + align256(L3 * P * 2);
+  w.xsoa = w.gdynT + align256(L3 * P * 2);
+  w.bins = w.xsoa + align256(3 * P * 4);
   w.total = w.bins + align256(bs_plan(make_grid_desc(&f->hash_static), 3, 4, P).bytes);
   return w;
 }
@@ -578,6 +585,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   float* Hbuf = (float*)(ws + w.hbuf);
   half_t* gvs = (half_t*)(ws + w.gvs);
   half_t* gdynT = (half_t*)(ws + w.gdynT);
+  float* xsoa = (float*)(ws + w.xsoa);  // [3][P] coordinates, written by the prep kernel
   hipError_t e = hipMemsetAsync(ws, 0, w.gvs, stream);  // stats + Hbuf
   if (e == hipSuccess) e = hipMemcpyAsync(stats + ST_VMAX, plane_abs_max, sizeof(float), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
@@ -587,7 +595,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     const int staged = (colD % 8 == 0 && L3 % 8 == 0) ? 1 : 0;  // 16-byte pieces
     const int lds = staged ? PREP_THREADS * (colsA + L3 + 8) * 2 : 0;
     L4D_LAUNCH(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, PREP_THREADS)), dim3(PREP_THREADS), lds, stream, d, xt, tinfo, P,
-               (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, staged);
+               (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, staged, xsoa);
   }
 
   // static 3-D hash grid: sorted scatter of dX[:, 2*nS*8 + lvl*4 ..] (binscatter.hip)
@@ -642,7 +650,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
         }
       }
     (void)hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    L4D_LAUNCH(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, stream, d, t, fg.planes_cl, xt, P, chunk,
+    L4D_LAUNCH(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, stream, d, t, fg.planes_cl, xsoa, P, chunk,
                        wave_skip, gvs, param_scale, stats);
   }
   // dynamic hash
@@ -665,7 +673,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
     (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xt, P, chunk, gdynT, stats, Hbuf);
+    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xsoa, P, chunk, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);

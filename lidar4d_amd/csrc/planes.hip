@@ -10,6 +10,7 @@
 #include "common.h"
 
 #include "planes_dev.h"
+#include <algorithm>
 
 template <int C>
 __global__ void __launch_bounds__(256) planes_fwd_kernel(PlaneDesc desc, const float* __restrict__ arena,
@@ -120,20 +121,30 @@ __global__ void __launch_bounds__(256) planes_bwd_kernel(PlaneDesc desc, const f
   if (want_coord) *reinterpret_cast<float4_t*>(dxt + p * 4) = float4_t{gcoord[0], gcoord[1], gcoord[2], gcoord[3]};
 }
 
-// [C,H,W] <-> [H,W,C]
-__global__ void relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W,
-                                int to_cl) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// [C,H,W] <-> [H,W,C], all planes of all scales in one launch (blockIdx.y = plane); mode 0: channel-last -> [C,H,W],
+// 1: [C,H,W] -> channel-last, 2: channel-last ADDED onto [C,H,W] (gradients straight into the parameters' .grad views)
+struct RelayoutPlanes {
+  float* nchw[MAX_SCALES * NPLANES];
+  int64_t off[MAX_SCALES * NPLANES];
+  int H[MAX_SCALES * NPLANES], W[MAX_SCALES * NPLANES];
+};
+__global__ void __launch_bounds__(256) relayout_kernel(RelayoutPlanes pl, float* __restrict__ cl_base, int C, int mode) {
+  const int k = blockIdx.y;
+  const int H = pl.H[k], W = pl.W[k];
   const int64_t n = (int64_t)C * H * W;
-  if (i >= n) return;
-  if (to_cl) {  // i indexes dst [H,W,C]
-    const int c = i % C;
-    const int64_t hw = i / C;
-    dst[i] = src[(int64_t)c * H * W + hw];
-  } else {  // i indexes dst [C,H,W]
-    const int64_t hw = i % ((int64_t)H * W);
-    const int c = i / ((int64_t)H * W);
-    dst[i] = src[hw * C + c];
+  float* nchw = pl.nchw[k];
+  float* cl = cl_base + pl.off[k];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (mode == 1) {  // i indexes cl [H,W,C]
+      const int c = i % C;
+      const int64_t hw = i / C;
+      cl[i] = nchw[(int64_t)c * H * W + hw];
+    } else {  // i indexes nchw [C,H,W]
+      const int64_t hw = i % ((int64_t)H * W);
+      const int c = i / ((int64_t)H * W);
+      const float v = cl[hw * C + c];
+      nchw[i] = mode == 2 ? nchw[i] + v : v;
+    }
   }
 }
 
@@ -153,16 +164,25 @@ static int fill_desc(PlaneDesc& d, const int64_t* plane_off, const int32_t* res,
 extern "C" int l4d_planes_relayout(const float* const* planes, const int32_t* res, int32_t n_scales, int32_t C,
                                    float* planes_cl, const int64_t* plane_off, int32_t to_channel_last,
                                    void* stream) {
-  static const int CA[NPLANES] = {0, 0, 0, 1, 1, 2}, CB[NPLANES] = {1, 2, 3, 2, 3, 3};
+  if (n_scales > MAX_SCALES || to_channel_last < 0 || to_channel_last > 2) {
+    l4d_set_error(1, "l4d_planes_relayout: too many scales / unknown mode");
+    return 1;
+  }
+  RelayoutPlanes pl;
+  int64_t max_n = 0;
   for (int s = 0; s < n_scales; ++s)
     for (int c = 0; c < NPLANES; ++c) {
-      const int W = res[s * 4 + CA[c]], H = res[s * 4 + CB[c]];
-      const int64_t n = (int64_t)C * H * W;
-      float* cl = planes_cl + plane_off[s * NPLANES + c];
-      float* nchw = const_cast<float*>(planes[s * NPLANES + c]);
-      L4D_LAUNCH(relayout_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                         to_channel_last ? nchw : cl, to_channel_last ? cl : nchw, C, H, W, to_channel_last);
+      const int k = s * NPLANES + c;
+      static const int CA[NPLANES] = {0, 0, 0, 1, 1, 2}, CB[NPLANES] = {1, 2, 3, 2, 3, 3};  // comb order of the six planes
+      pl.W[k] = res[s * 4 + CA[c]];
+      pl.H[k] = res[s * 4 + CB[c]];
+      pl.off[k] = plane_off[k];
+      pl.nchw[k] = const_cast<float*>(planes[k]);
+      max_n = std::max<int64_t>(max_n, (int64_t)C * pl.H[k] * pl.W[k]);
     }
+  if (max_n == 0) return 0;
+  const unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(max_n, 256), 512);
+  L4D_LAUNCH(relayout_kernel, dim3(gx, n_scales * NPLANES), dim3(256), 0, (hipStream_t)stream, pl, planes_cl, C, to_channel_last);
   L4D_LAUNCH_CHECK("l4d_planes_relayout");
   return 0;
 }

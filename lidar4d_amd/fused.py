@@ -200,15 +200,9 @@ class RenderFn(torch.autograd.Function):
         fd = _field_desc(model)
         vmax = pe._arena().abs().max().reshape(1)
         dflow16 = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv, vmax, samples_per_ray=T)
-        tmp = torch.empty(pe.layout.numel, dtype=torch.float32, device=dev)
-        planes = pe._flat_planes()
-        views, o = [], 0
-        for p in planes:
-            views.append(tmp[o:o + p.numel()].view(p.shape))
-            o += p.numel()
-        ops.planes_relayout(pe.layout, views, gcl, to_channel_last=False)
-        for p, v in zip(planes, views):
-            store.grad_view(p).add_(v.reshape(-1))
+        # channel-last gradient arena -> added onto the planes' [1, C, H, W] gradient views, one launch
+        ops.planes_relayout(pe.layout, [store.grad_view(p).view(p.shape) for p in pe._flat_planes()], gcl, to_channel_last=False,
+                            accumulate=True)
         # every gradient except the flow field's is final now: a data-parallel trainer starts reducing them here
         hook = getattr(model, "_grads_ready_hook", None)
         if hook is not None:

@@ -139,13 +139,14 @@ class PlaneLayout:
         return (1, self.C, self.res[s][b], self.res[s][a])
 
 
-def planes_relayout(layout, planes, arena, to_channel_last=True):
-    """planes: list (scale-major, 6 per scale) of [1,C,H,W] fp32 tensors <-> arena (flat fp32 channel-last)."""
+def planes_relayout(layout, planes, arena, to_channel_last=True, accumulate=False):
+    """planes: list (scale-major, 6 per scale) of [1,C,H,W] fp32 tensors <-> arena (flat fp32 channel-last); one launch.
+    accumulate (with to_channel_last=False): planes += arena (gradients straight into the parameters' .grad views)."""
     for pl in planes:
         _chk(pl, torch.float32, "plane")
     _chk(arena, torch.float32, "arena")
-    call("l4d_planes_relayout", _ptrs(planes), layout.res_flat, layout.n_scales, layout.C, _p(arena), layout.off_flat,
-         int(to_channel_last), _stream())
+    mode = 1 if to_channel_last else (2 if accumulate else 0)
+    call("l4d_planes_relayout", _ptrs(planes), layout.res_flat, layout.n_scales, layout.C, _p(arena), layout.off_flat, mode, _stream())
 
 
 def planes_fwd(layout, arena, xt, which=0):

@@ -15,14 +15,18 @@ bench.py attaches to its JSON line:
                                  executed MFMA flops SQ_INSTS_VALU_MFMA_MOPS_F16 x 512.
 """
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocpd_pmc import simple_demangle
 
 GATHER = ("density_encode_fwd_kernel", "hashgrid_t_fwd_kernel", "hashgrid_fwd_kernel", "field_bwd_prep_kernel", "planes_dyn_lds_kernel",
           "attr_gather_kernel", "attr_gather_bwd")
 
 
 def main(fetch, write, mfma, out_dir, tag):
-    F, W, M = (json.load(open(p)) for p in (fetch, write, mfma))
+    F, W, M = ({simple_demangle(k): v for k, v in json.load(open(p)).items()} for p in (fetch, write, mfma))
     traffic = {}
     for k in sorted(set(F) | set(W)):
         f = F.get(k, {}).get("FETCH_SIZE")

@@ -12,7 +12,34 @@ import subprocess
 import sys
 
 
+def simple_demangle(n):
+    """Itanium name of a (possibly truncated) kernel symbol -> "name<args>" for integral / bool template arguments, which is
+    all this library uses; anything else is returned unchanged.  (rocprofv3 stores long symbols truncated, which c++filt
+    rejects.)"""
+    m = re.match(r"_Z(\d+)", n)
+    if not m:
+        return n
+    ln = int(m.group(1))
+    name = n[m.end():m.end() + ln]
+    rest = n[m.end() + ln:]
+    if not rest.startswith("I"):
+        return name
+    args, i = [], 1
+    while i < len(rest) and rest[i] == "L":
+        mm = re.match(r"L([a-z])(n?\d+)E", rest[i:])
+        if not mm:
+            return n
+        t, v = mm.group(1), mm.group(2).replace("n", "-")
+        args.append(("true" if v != "0" else "false") if t == "b" else v)
+        i += mm.end()
+    return f"{name}<{', '.join(args)}>" if i < len(rest) and rest[i] == "E" else n
+
+
 def demangle(names):
+    return {n: simple_demangle(n.replace(".kd", "")) for n in names}
+
+
+def demangle_cxxfilt(names):
     filt = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
     try:
         out = subprocess.run([filt], input="\n".join(n.replace(".kd", "") for n in names), capture_output=True, text=True, check=True).stdout.splitlines()
