@@ -55,6 +55,8 @@ HBM_PEAK_GBS = 8000.0     # HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
 L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth, 8 XCDs
 LDS_PEAK_GBS = 150000.0   # ds_read_b64/b128 streaming, 256 CUs
 MFMA_F16_PEAK_TFLOPS = 2500.0
+GATHER_PEAK_G = 292.0     # measured here (tools/ubench/gather.hip, profiles/r02_ubench_gather.txt): G lane-loads/s of a wave-level
+                          # gather whose 64 lanes touch 64 different L2-resident lines (8 or 16 B per lane alike); 64 G/s when they miss L2
 
 WORKLOADS = {
     # name: (model kwargs, rays per GPU per step, description)
@@ -93,7 +95,7 @@ def kernel_models(model, P, M):
     lds_alg = 2 * 3 * (2 * L * 4 * 8)                                            # xz, yz stacks x 3 frames
     X = 2 * in_pad
     m = {}
-    enc = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P,
+    enc = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P, gathers=(L * 8 + 3 * L * 4) * P,
                note="planes + static hash + xy dynamic hash gathers (time planes via per-call 1-D rows, both time slices of a corner "
                     "in one 16-B load); row staged in LDS, written once")
     m["density_encode_fwd_kernel<true, true>"] = enc
@@ -102,7 +104,7 @@ def kernel_models(model, P, M):
     m["density_encode_fwd_kernel<false, true>"] = m["density_encode_fwd_kernel<false, false>"]
     m["dynhash_fwd_lds_kernel"] = dict(bound="lds", bytes=lds_alg * P, hbm=(2 * L * (16 + 16) + 2 * 2 * L) * P,
                                        note="xz / yz HashGridT stacks from LDS-resident slice tables; one streaming pass of xt / flow per (plane, level)")
-    m["hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="l2", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, note="flow grid + interpT")
+    m["hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="l2", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, gathers=Lf * 8 * P, note="flow grid + interpT")
     fl = lambda pad, nh: 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
     it_s, nf = in_pad // 16, model.flow_net.n_hidden
     # sigma network: x + y + saved activations; backward also writes dx
@@ -406,6 +408,10 @@ def _run(args):
                 row.update(bound=mod["bound"], bytes_per_launch=mod["bytes"], modelled_launches_per_step=len(big) / args.profile_steps,
                            modelled_launch_ms=round(avg_ms, 4), achieved=round(ach, 1), peak=peaks[mod["bound"]], unit="GB/s",
                            frac=round(ach / peaks[mod["bound"]], 4), traffic=pmc_lookup(traffic, name), note=mod["note"])
+                if "gathers" in mod:  # hash-entry gathers (one lane = one table entry; plane taps are coherent and not counted)
+                    gl = mod["gathers"] / (avg_ms * 1e-3) / 1e9
+                    row["hash_gathers_G_per_s"] = round(gl, 1)
+                    row["frac_of_measured_random_gather_rate"] = round(gl / GATHER_PEAK_G, 4)
                 if "hbm" in mod:
                     row["compulsory_hbm_GBps"] = round(mod["hbm"] / (avg_ms * 1e-3) / 1e9, 1)
                     row["compulsory_hbm_frac"] = round(row["compulsory_hbm_GBps"] / HBM_PEAK_GBS, 4)
@@ -426,6 +432,10 @@ def _run(args):
                         "bytes_are": {"hbm": "compulsory HBM bytes", "l2": "table-entry bytes gathered through L1/L2 (tables are cache resident)",
                                       "lds": "table-entry bytes served from LDS"}[d["bound"]],
                         "compulsory_hbm_GBps": d.get("compulsory_hbm_GBps"), "compulsory_hbm_frac": d.get("compulsory_hbm_frac"),
+                        "hash_gathers_G_per_s": d.get("hash_gathers_G_per_s"),
+                        "frac_of_measured_random_gather_rate": d.get("frac_of_measured_random_gather_rate"),
+                        "gather_rate_note": "the vector-memory path retires a 64-lane gather of 64 distinct L2-resident lines at 292 G lane-loads/s chip-wide "
+                                            "(64 G/s on L2 misses), measured with tools/ubench/gather.hip: that rate, not a byte rate, is what binds this kernel",
                         "samples_per_launch": P, "attribute_rows": M}
         mfma = {"kernels": mf, "peak_tflops": MFMA_F16_PEAK_TFLOPS,
                 "pmc_source": "profiles/r02_mfma_pmc.json (rocprofv3 --pmc pass of this command: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))" if mfma_pmc else None,
