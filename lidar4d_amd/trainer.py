@@ -457,29 +457,71 @@ class GradReducer:
     RCCL's stream while the flow-field adjoint (several ms of kernels) still runs; ``finish()`` reduces the flow range
     and waits.  Without a preceding ``early()`` it falls back to one all-reduce of the whole arena."""
 
-    def __init__(self, model):
+    def __init__(self, model, transport=None):
+        """transport: "fp32" (default: plain SUM all-reduce) or "bf16" (``L4D_GRAD_TRANSPORT=bf16``): the encoder range --
+        planes + hash tables, 97 % of the bytes -- travels as bf16 with fp32 accumulation on arrival: every rank sends chunk r
+        of its gradient to rank r (all-to-all), sums the world_size chunks it received in fp32, and the reduced chunks are
+        all-gathered as bf16.  Same wire pattern as a ring all-reduce (reduce-scatter + all-gather) at half the bytes per
+        xGMI link; the reduced value is rounded to bf16 once (2^-9 relative: noise Adam's normalisation tolerates; inf / nan
+        survive, so the overflow check still works).  The network ranges and the gates stay fp32."""
         self.store = st = model._store
+        self.transport = transport or os.environ.get("L4D_GRAD_TRANSPORT", "fp32")
+        if self.transport not in ("fp32", "bf16"):
+            raise ValueError(f"GradReducer: unknown transport {self.transport!r}")
         flow = [(off, n) for name, _, off, n, _ in st.entries if name.startswith("flow_net.")]
         after = [off for name, _, off, n, _ in st.entries if name.startswith("sigma_net.")]
         self.flow_lo = min(off for off, _ in flow)
         self.flow_hi = min(after)  # flow_net is the first block of lr group 1 (lidar4d.py:226-237 order); sigma_net follows
         assert self.flow_lo == st.group_ranges[1][0] and all(self.flow_lo <= off < self.flow_hi for off, _ in flow)
         self.works = []
+        self._pending16 = None
+
+    # -- bf16 transport of one range -----------------------------------------------------------------------------------
+    def _start16(self, lo, hi):
+        g = self.store.flat_grad
+        world = dist.get_world_size()
+        n = hi - lo
+        chunk = (n + world - 1) // world
+        send = torch.zeros(world * chunk, dtype=torch.bfloat16, device=g.device)
+        send[:n].copy_(g[lo:hi])
+        recv = torch.empty_like(send)
+        work = dist.all_to_all_single(recv, send, async_op=True)
+        self._pending16 = (lo, hi, chunk, world, send, recv, work)
+
+    def _finish16(self):
+        lo, hi, chunk, world, send, recv, work = self._pending16
+        work.wait()
+        mine = recv.view(world, chunk).float().sum(0)  # fp32 accumulation on arrival
+        out = torch.empty(world * chunk, dtype=torch.bfloat16, device=recv.device)
+        dist.all_gather_into_tensor(out, mine.to(torch.bfloat16))
+        self.store.flat_grad[lo:hi].copy_(out[:hi - lo])
+        self._pending16 = None
 
     def early(self):
         g = self.store.flat_grad
+        if self.transport == "bf16":
+            self._start16(0, self.flow_lo)
+            self.works = [dist.all_reduce(g[self.flow_hi:self.store.grad_numel], op=dist.ReduceOp.SUM, async_op=True)]
+            return
         self.works = [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True)
                       for a, b in ((0, self.flow_lo), (self.flow_hi, self.store.grad_numel)) if b > a]  # incl. the gates
 
     def finish(self):
         g = self.store.flat_grad
         if not self.works:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            if self.transport == "bf16":
+                self._start16(0, self.flow_lo)
+                dist.all_reduce(g[self.flow_lo:self.store.grad_numel], op=dist.ReduceOp.SUM)
+                self._finish16()
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
             return
         dist.all_reduce(g[self.flow_lo:self.flow_hi], op=dist.ReduceOp.SUM)
         for w in self.works:
             w.wait()
         self.works = []
+        if self._pending16 is not None:
+            self._finish16()
 
 
 class Trainer:

@@ -59,6 +59,21 @@ def _worker(rank, world, port, out):
     mine = grads_for(rank * shard, (rank + 1) * shard)
     red.finish()     # no early(): single all-reduce fallback
     fallback_equal = bool(torch.equal(store.flat_grad, g))
+    # bf16 transport of the encoder range (all-to-all, fp32 sum on arrival, all-gather): the fp32 result rounded to bf16 once
+    red16 = GradReducer(shell, transport="bf16")
+    # expected: every rank's contribution rounded to bf16, summed in fp32 in rank order, the sum rounded to bf16 once
+    mine = grads_for(rank * shard, (rank + 1) * shard)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    want16 = sum(p_[:red16.flow_lo].to(torch.bfloat16).float() for p_ in parts).to(torch.bfloat16).float()
+    for two_phase in (True, False):
+        mine = grads_for(rank * shard, (rank + 1) * shard)
+        if two_phase:
+            red16.early()
+        red16.finish()
+        lo = red16.flow_lo
+        bf16_ok = bool(torch.equal(store.flat_grad[:lo], want16)) and bool(torch.equal(store.flat_grad[lo:], g[lo:]))
+        fallback_equal = fallback_equal and bf16_ok
     if rank == 0:
         full = grads_for(0, n_total)
         n = store.numel  # parameter gradients only (the tail behind them holds the gates)
