@@ -117,10 +117,12 @@ def kernel_models(model, P, M):
                                                          note="x + dy read, dx written; activations recomputed (algorithmic flops: fwd + dX + dW)")
     # attribute networks on the work list: rows assembled in the kernel (index + sigma-net output row), geo-feature gradient only
     it_a = a_pad // 16
-    m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true>"] = dict(bound="hbm", bytes=(4 + 32 + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M,
-                                                      note="idx + h row in (direction encoding per ray: cache resident), y + activations out")
-    m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, false, true, 4>"] = dict(bound="hbm", bytes=(4 + 32 + nh_a * 128 + 32 + 64) * M,
-                                                                               flops=2 * fl(a_pad, nh_a) * M, note="idx + h row + activations + dy in, 32 gradient columns out")
+    m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true, false>"] = dict(bound="hbm", bytes=(4 + 32 + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M,
+                                                             note="idx + h row in (direction encoding per ray: cache resident), y + activations out")
+    m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true, true>"] = dict(bound="hbm", bytes=(4 + 32 + 32 + nh_a * 128 + 2 * a_pad) * M, flops=fl(a_pad, nh_a) * M,
+                                                            note="the same + the assembled rows stored once for both networks' backward")
+    m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, false, false, 4>"] = dict(bound="hbm", bytes=(2 * a_pad + nh_a * 128 + 32 + 64) * M,
+                                                                                flops=2 * fl(a_pad, nh_a) * M, note="stored rows + activations + dy in, 32 gradient columns out")
     m[f"mlp_fwd_kernel<{it_a}, {nh_a}>"] = dict(bound="hbm", bytes=(2 * a_pad + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M, note="materialised input rows")
     m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true>"] = dict(bound="hbm", bytes=(4 * a_pad + nh_a * 128 + 32) * M, flops=2 * fl(a_pad, nh_a) * M, note="materialised input rows")
     rec = 8 * 12  # one 12-byte record per corner (upper bound: equal-cell runs along a ray are merged first)
@@ -130,7 +132,7 @@ def kernel_models(model, P, M):
     m["bin_pass1_kernel<3, 2>"] = dict(bound="hbm", bytes=(16 + 4 * Lf + Lf * rec2) * P, note="flow grid records")
     m["bin_pass2_kernel<3, 2>"] = dict(bound="hbm", bytes=Lf * rec2 * P, note="flow grid records")
     m["field_bwd_prep_kernel"] = dict(bound="hbm", bytes=(16 + X + 3 * nS * 16 + 2 * n_dyn) * P, note="dX row read, plane factors + transposed dyn gradient written")
-    m["planes_dyn_lds_kernel"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
+    m["planes_dyn_lds_kernel<true>"] = m["planes_dyn_lds_kernel<false>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
     m["planes_static_lds_kernel"] = dict(bound="hbm", bytes=(3 * nS * 16 + 3 * nS * 8) * P, note="plane-major factors read once per (scale, plane)")
     m["dynhash_lds_kernel"] = dict(bound="hbm", bytes=(2 * n_dyn + n_dyn * 8) * P, note="transposed gradient + 2 coordinates per (plane, level) pass")
     m["composite_fwd_kernel"] = dict(bound="hbm", bytes=(4 + 4 + 4 + 4) * P, note="sigma, z in; weights, index out")
