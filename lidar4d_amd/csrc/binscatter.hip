@@ -35,12 +35,8 @@
 #define BS_UNROLL 1
 #endif
 
-// A record = NV fp16 payload values (PW = 2 payload dwords at NV = 4, 1 below) + a 16-bit key = the entry's index inside
-// its bin (bins have at most 2^13 entries).  A (level, tile) slot keeps them as two arrays -- payloads first, keys behind --
-// so that both are read and written with aligned vector accesses: 10 bytes per record instead of the 12 of {32-bit key,
-// payload}, and the LDS staging buffer of pass 1 shrinks from 48 to 40 KB (three workgroups per CU instead of two).
 template <int NV>
-struct RecWords { static constexpr int n = (NV + 1) / 2; };  // payload dwords
+struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
 
 template <int D, int NV>
 __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
@@ -49,14 +45,12 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
                                                               uint16_t* __restrict__ offs, uint32_t* __restrict__ bins,
                                                               float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
-  constexpr int PW = RecWords<NV>::n;
-  constexpr int NREC = BS_THREADS * NC;  // record capacity of a slot
+  constexpr int NW = RecWords<NV>::n;
   // per-wave histograms: 1024 threads x 2^D records into <= 128 bins would otherwise pile ~64 same-address returning
   // LDS atomics onto every counter
   constexpr int NWAVES = BS_THREADS / 64;
   __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
-  __shared__ __attribute__((aligned(16))) uint32_t stage[NREC * PW];   // payloads, sorted by bin
-  __shared__ __attribute__((aligned(16))) uint16_t stage_key[NREC];    // bin-local entry indices, same order
+  __shared__ __attribute__((aligned(16))) uint32_t stage[BS_THREADS * NC * NW];
   __shared__ uint32_t total_s;
   // One workgroup walks ALL levels of its tile of samples.  (Earlier: one workgroup per (tile, level), ordered level-fast
   // and XCD-aware so that the levels of a tile at least met in one L2.  Every such workgroup started with a cold,
@@ -212,21 +206,19 @@ __global__ void __launch_bounds__(BS_THREADS) bin_pass1_kernel(GridDesc desc, co
     if (emit[k]) {
       const uint32_t b = keys[k] >> shift;
       const uint32_t r = boff[b] + hist[wave_id][b] + pos[k];
-      stage_key[r] = (uint16_t)(keys[k] & ((1u << shift) - 1u));
-      half_t hv[2 * PW];
+      stage[r * NW] = keys[k];
+      half_t hv[2 * (NW - 1)];
 #pragma unroll
-      for (int j = 0; j < 2 * PW; ++j) hv[j] = j < NV ? f2h_grad(vals[k][j]) : (half_t)0.0f;
+      for (int j = 0; j < 2 * (NW - 1); ++j) hv[j] = j < NV ? f2h_grad(vals[k][j]) : (half_t)0.0f;
 #pragma unroll
-      for (int q = 0; q < PW; ++q) stage[r * PW + q] = reinterpret_cast<uint32_t*>(hv)[q];
+      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = reinterpret_cast<uint32_t*>(hv)[q];
     }
   __syncthreads();
   const uint32_t total = total_s;
-  // already sorted by bin; 16 bytes per lane (both arrays of the slot are 16-byte aligned and large enough for the rounded-up tails)
-  uint32_t* dst = bins + wg_slot * (uint64_t)(NREC * PW + NREC / 2);
-  const uint32_t n16p = (total * PW + 3) >> 2, n16k = (total + 7) >> 3;
-  for (uint32_t q = threadIdx.x; q < n16p; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
-  uint4* dstk = reinterpret_cast<uint4*>(dst + NREC * PW);
-  for (uint32_t q = threadIdx.x; q < n16k; q += blockDim.x) dstk[q] = reinterpret_cast<const uint4*>(stage_key)[q];
+  uint32_t* dst = bins + wg_slot * (uint64_t)(BS_THREADS * NC * NW);
+  // already sorted by bin; 16 bytes per lane (the slot is 16-byte aligned and large enough for the rounded-up tail)
+  const uint32_t n16 = (total * NW + 3) >> 2;
+  for (uint32_t q = threadIdx.x; q < n16; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
   }  // levels
 }
 
@@ -235,8 +227,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
                                                        const uint16_t* __restrict__ offs, const uint32_t* __restrict__ bins,
                                                        const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
-  constexpr int PW = RecWords<NV>::n;
-  constexpr int NREC = BS_THREADS * NC;
+  constexpr int NW = RecWords<NV>::n;
   extern __shared__ long long acc[];
   const int lvl = blockIdx.y, b = blockIdx.x;
   const uint32_t size = desc.size[lvl];
@@ -263,7 +254,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const float v = h2f(hv[j]);
-      if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[key * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
+      if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(key - lo) * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
     }
   };
   // BS_UNROLL runs (pass-1 workgroups) per group and iteration: their offset loads, and then the first record of each, are
@@ -278,39 +269,29 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
       const uint16_t* o = offs + slot * (BS_MAX_BINS + 1);
       s0[u] = o[b];
       s1[u] = w < n_wg ? (uint32_t)o[b + 1] : s0[u];  // past the end: an empty run
-      rec[u] = bins + slot * (uint64_t)(NREC * PW + NREC / 2);
+      rec[u] = bins + slot * (uint64_t)(BS_THREADS * NC * NW);
     }
-    uint32_t key0[BS_UNROLL], wd0[BS_UNROLL][PW];
+    uint32_t key0[BS_UNROLL], wd0[BS_UNROLL][NW - 1];
 #pragma unroll
     for (int u = 0; u < BS_UNROLL; ++u) {
       const uint32_t r = s0[u] + l16;
-      key0[u] = 0u;
+      key0[u] = lo;
 #pragma unroll
-      for (int q = 0; q < PW; ++q) wd0[u][q] = 0u;
+      for (int q = 0; q < NW - 1; ++q) wd0[u][q] = 0u;
       if (r < s1[u]) {
-        key0[u] = reinterpret_cast<const uint16_t*>(rec[u] + NREC * PW)[r];
-        if (PW == 2) {
-          const uint2 v2 = reinterpret_cast<const uint2*>(rec[u])[r];
-          wd0[u][0] = v2.x;
-          wd0[u][PW - 1] = v2.y;
-        } else {
-          wd0[u][0] = rec[u][r];
-        }
+        key0[u] = rec[u][r * NW];
+#pragma unroll
+        for (int q = 0; q < NW - 1; ++q) wd0[u][q] = rec[u][r * NW + 1 + q];
       }
     }
 #pragma unroll
     for (int u = 0; u < BS_UNROLL; ++u) {
       add(key0[u], wd0[u]);  // an absent record carries zeros: no atomics issued
       for (uint32_t r = s0[u] + l16 + BS_GROUP; r < s1[u]; r += BS_GROUP) {
-        uint32_t wd[PW];
-        if (PW == 2) {
-          const uint2 v2 = reinterpret_cast<const uint2*>(rec[u])[r];
-          wd[0] = v2.x;
-          wd[PW - 1] = v2.y;
-        } else {
-          wd[0] = rec[u][r];
-        }
-        add(reinterpret_cast<const uint16_t*>(rec[u] + NREC * PW)[r], wd);
+        uint32_t wd[NW - 1];
+#pragma unroll
+        for (int q = 0; q < NW - 1; ++q) wd[q] = rec[u][r * NW + 1 + q];
+        add(rec[u][r * NW], wd);
       }
     }
   }
@@ -336,13 +317,13 @@ static int bs_shift(int NV) {
 BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
   BsPlan pl;
   pl.shift = bs_shift(NV);
-  pl.rec_words = (NV + 1) / 2;  // payload dwords; + one 16-bit key per record
+  pl.rec_words = 1 + (NV + 1) / 2;
   pl.n_wg = ceil_div64(P, BS_THREADS);
   const int64_t rec_per_wg = (int64_t)BS_THREADS << n_dims;
   pl.off_max = 0;
   pl.off_offs = 256;
   pl.off_bins = (pl.off_offs + (int64_t)d.n_levels * pl.n_wg * (BS_MAX_BINS + 1) * 2 + 255) / 256 * 256;
-  pl.bytes = pl.off_bins + (int64_t)d.n_levels * pl.n_wg * (rec_per_wg * pl.rec_words * 4 + rec_per_wg * 2);
+  pl.bytes = pl.off_bins + (int64_t)d.n_levels * pl.n_wg * rec_per_wg * pl.rec_words * 4;
   return pl;
 }
 
