@@ -51,6 +51,50 @@ __device__ __forceinline__ PairSel pair_sel(const SlicePair& sp, int n_slices) {
   return s;
 }
 
+// ---- pair-table lookups in two steps: fetch the four corner entries of a cell, then interpolate / blend -------------
+// The three frames of a sample (the point itself and its two flow-warped copies) are looked up in the same tables; where
+// the warped point falls into the same cell as the point itself -- the flow is zero or tiny wherever the scene is static,
+// which is most of it -- its four corner entries are the ones already fetched and only the weights differ.
+struct PairCorners {
+  uint4 e[4];  // corner k: {slice q: 4 halfs, slice q + 1: 4 halfs}
+};
+// interpolation + time blend + interpT of one level from fetched corners (same operation order as hash_t_level)
+__device__ __forceinline__ float pair_eval(const PairCorners& pc, const Cell<2>& c, const TimeCoef& tc, bool hi) {
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t gv[2];
+    const float w = corner<2>(c, k, gv);
+    const half_t* h = reinterpret_cast<const half_t*>(&pc.e[k]);
+#pragma unroll
+    for (int f = 0; f < 4; f += 2) {
+      const float2_t ra = float2_t{a[f], a[f + 1]} + float2_t{h2f(h[f]), h2f(h[f + 1])} * w;
+      const float2_t rb = float2_t{b[f], b[f + 1]} + float2_t{h2f(h[4 + f]), h2f(h[5 + f])} * w;
+      a[f] = ra[0]; a[f + 1] = ra[1];
+      b[f] = rb[0]; b[f + 1] = rb[1];
+    }
+  }
+  float r = 0.0f;
+  if (tc.sp.i1 != tc.sp.i2) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) r += tc.basis[f] * (tc.sp.w1 * h2f(f2h(a[f])) + tc.sp.w2 * h2f(f2h(b[f])));
+  } else {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) r += tc.basis[f] * h2f(f2h(hi ? b[f] : a[f]));
+  }
+  return r;
+}
+// corners of cell c from `tab` (the level's block of one pair table); lanes with reuse = true keep what `pc` already holds
+__device__ __forceinline__ void pair_fetch(const uint4* __restrict__ tab, const GridDesc& g, int lvl, const Cell<2>& c, bool reuse, PairCorners& pc) {
+  const bool hashed = (g.hashed_mask >> lvl) & 1u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t gv[2];
+    (void)corner<2>(c, k, gv);
+    if (!reuse) pc.e[k] = tab[grid_index<2>(gv, g.res[lvl], g.size[lvl], hashed)];
+  }
+}
+
 // one HashGridT level (F = 4): fp16-rounded slice features, fp32 blend, interpT
 __device__ __forceinline__ float hash_t_level(const FieldDesc& fd, int plane, int lvl, const TimeCoef& tc, const float xy[2]) {
   const GridDesc& g = fd.hd[plane];

@@ -164,6 +164,37 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
       }
       const int ca = plane == 2 ? 1 : 0, cb = plane == 0 ? 1 : 2;  // xy, xz, yz
       const float q0[2] = {x0[ca], x0[cb]}, q1[2] = {x1[ca], x1[cb]}, q2[2] = {x2[ca], x2[cb]};
+      if (fd.hd_pairs[plane]) {  // pair tables: fetch corners once per distinct cell (field_dev.h)
+        const GridDesc& g = fd.hd[plane];
+        const PairSel ps0 = pair_sel(tc0.sp, fd.n_slices), ps1 = pair_sel(tc1.sp, fd.n_slices), ps2 = pair_sel(tc2.sp, fd.n_slices);
+        const uint4* base = reinterpret_cast<const uint4*>(fd.hd_pairs[plane]);
+        const size_t E = fd.hd_entries[plane];
+        for (int lvl = 0; lvl < L; ++lvl) {
+          const uint4* t0p = base + (size_t)ps0.q * E + g.offset[lvl];
+          const Cell<2> c0 = locate<2>(q0, g.scale[lvl]);
+          PairCorners pc;
+          pair_fetch(t0p, g, lvl, c0, false, pc);
+          const float r0 = pair_eval(pc, c0, tc0, ps0.hi);
+          float r1 = r0, r2 = r0;
+          if (has_fwd) {
+            const Cell<2> c1 = locate<2>(q1, g.scale[lvl]);
+            const bool same = ps1.q == ps0.q && c1.cell[0] == c0.cell[0] && c1.cell[1] == c0.cell[1];
+            PairCorners p1 = pc;
+            pair_fetch(base + (size_t)ps1.q * E + g.offset[lvl], g, lvl, c1, same, p1);
+            r1 = pair_eval(p1, c1, tc1, ps1.hi);
+          }
+          if (has_bwd) {
+            const Cell<2> c2 = locate<2>(q2, g.scale[lvl]);
+            const bool same = ps2.q == ps0.q && c2.cell[0] == c0.cell[0] && c2.cell[1] == c0.cell[1];
+            PairCorners p2 = pc;
+            pair_fetch(base + (size_t)ps2.q * E + g.offset[lvl], g, lvl, c2, same, p2);
+            r2 = pair_eval(p2, c2, tc2, ps2.hi);
+          }
+          row[col + lvl] = f2h(0.5f * r0 + 0.25f * (r1 + r2));
+        }
+        col += L;
+        continue;
+      }
       for (int lvl = 0; lvl < L; ++lvl) {
         const float r0 = hash_t_level(fd, plane, lvl, tc0, q0);
         const float r1 = has_fwd ? hash_t_level(fd, plane, lvl, tc1, q1) : r0;
@@ -254,6 +285,8 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
   // one sample: the three frames' lookups from the staged table, blended
   auto eval = [&](const float xa[3], const float xb[3]) -> half_t {
     float r[3];
+    PairCorners pc0;  // frame 0's corner entries: reused by a warped frame whose point lies in the same cell
+    Cell<2> c0;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
       r[e] = 0.0f;
@@ -263,37 +296,20 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
         r[e] = hash_t_level(fd, plane, lvl, tc[e], q);
         continue;
       }
-      Cell<2> c = locate<2>(q, scale);
-      float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+      const Cell<2> c = locate<2>(q, scale);
+      PairCorners pc = pc0;
+      const bool same = e > 0 && c.cell[0] == c0.cell[0] && c.cell[1] == c0.cell[1];
 #pragma unroll
       for (int cn = 0; cn < 4; ++cn) {
         uint32_t gv[2];
-        const float w = corner<2>(c, cn, gv);
-        const uint32_t idx = grid_index<2>(gv, res, size, hashed);
-        const uint4 rab = lds_tab[idx];
-        const half_t* ha = reinterpret_cast<const half_t*>(&rab);
-#pragma unroll
-        for (int f = 0; f < 4; f += 2) {  // packed fp32: two features per instruction
-          const float2_t ra = float2_t{a[f], a[f + 1]} + float2_t{h2f(ha[f]), h2f(ha[f + 1])} * w;
-          a[f] = ra[0];
-          a[f + 1] = ra[1];
-        }
-        if (two) {
-#pragma unroll
-          for (int f = 0; f < 4; f += 2) {
-            const float2_t rb = float2_t{b[f], b[f + 1]} + float2_t{h2f(ha[4 + f]), h2f(ha[5 + f])} * w;
-            b[f] = rb[0];
-            b[f + 1] = rb[1];
-          }
-        }
+        (void)corner<2>(c, cn, gv);
+        if (!same) pc.e[cn] = lds_tab[grid_index<2>(gv, res, size, hashed)];
       }
-      if (two) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) r[e] += tc[e].basis[f] * (tc[e].sp.w1 * h2f(f2h(a[f])) + tc[e].sp.w2 * h2f(f2h(b[f])));
-      } else {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) r[e] += tc[e].basis[f] * h2f(f2h(a[f]));
+      if (e == 0) {
+        pc0 = pc;
+        c0 = c;
       }
+      r[e] = pair_eval(pc, c, tc[e], false);  // the staged entry = {slice i1, slice i2}; a single slice sits in the low half
     }
     const float r1 = has_e[1] ? r[1] : r[0], r2 = has_e[2] ? r[2] : r[0];
     return f2h(0.5f * r[0] + 0.25f * (r1 + r2));
