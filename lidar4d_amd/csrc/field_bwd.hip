@@ -15,7 +15,7 @@
 //   2. planes_dyn (one pass): one LDS row per (scale, time plane, frame) -- the time rows and their weights are the
 //      same for every sample, so only the spatial axis is accumulated (int32) and the flush applies the row weights;
 //      also the coordinate adjoint of the two warped lookups = d(flow).
-//   3. planes_static (passes over <=128 KB row bands of each plane): int32 accumulation from gvs.
+//   3. planes_static (passes over <=64 KB row bands of each plane): int32 accumulation from gvs.
 //   4. dynhash (passes over (plane, level, entry range)): the 2 slices x 4 features of an entry all receive
 //      basis[f] * w_slice * H[entry], so only the scalar H is accumulated (int64), then expanded.
 #include "field_dev.h"
@@ -182,8 +182,11 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 // plane instead of four taps), and the coordinate adjoint of a warped lookup is sum_c gv_c (row[x1] - row[x0])_c from the
 // same two texels -- 144 instead of 480 texel loads per sample in a kernel that is bound by their latency.
 #define TFRAMES 3
+#ifndef PDYN_THREADS
+#define PDYN_THREADS 512
+#endif
 template <bool ROWS>
-__global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
+__global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
                                                             int64_t P, int64_t chunk, const half_t* __restrict__ dX,
                                                             int in_pad, float pscale, const float* __restrict__ stats,
@@ -354,7 +357,7 @@ __global__ void __launch_bounds__(512) planes_dyn_lds_kernel(FieldDesc fd, float
 // ------------------------------------------------------------------------------------------------
 // 3. static planes: passes over row bands
 // ------------------------------------------------------------------------------------------------
-#define MAX_TASKS 112
+#define MAX_TASKS 160
 struct BandTasks {
   int n;
   short s[MAX_TASKS], j[MAX_TASKS], row0[MAX_TASKS], nrows[MAX_TASKS];
@@ -623,11 +626,11 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     if (plane_rows) {
       L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, stream, d, pr, tinfo, plane_rows);
       (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      L4D_LAUNCH((planes_dyn_lds_kernel<true>), dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
+      L4D_LAUNCH((planes_dyn_lds_kernel<true>), dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
                  P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr);
     } else {
       (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      L4D_LAUNCH((planes_dyn_lds_kernel<false>), dim3(n_chunks), dim3(512), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
+      L4D_LAUNCH((planes_dyn_lds_kernel<false>), dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
                  P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr);
     }
   }
@@ -640,7 +643,10 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     for (int s = 0; s < d.planes.n_scales; ++s)
       for (int j = 0; j < 3; ++j) {
         const int W = d.planes.res[s][CA[j]], H = d.planes.res[s][CB[j]];
-        int rows = std::max(1, (128 * 1024) / (W * 8 * 4));
+#ifndef PLANES_BAND_KB
+#define PLANES_BAND_KB 64  // two workgroups per CU: measured 2.37 -> 2.07 ms against 128 KB bands (32 KB: 2.80)
+#endif
+        int rows = std::max(1, (PLANES_BAND_KB * 1024) / (W * 8 * 4));
         rows = std::min(rows, H);
         for (int r0 = 0; r0 < H; r0 += rows) {
           if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many plane bands"); return 1; }
@@ -658,7 +664,10 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     HashTasks t;
     t.n = 0;
     int hoff = 0, hoff_plane[3];
-    const int max_entries = (128 * 1024) / 8;
+#ifndef DYNHASH_LDS_KB
+#define DYNHASH_LDS_KB 64  // two workgroups per CU: measured 2.10 -> 1.85 ms against 128 KB parts
+#endif
+    const int max_entries = (DYNHASH_LDS_KB * 1024) / 8;
     for (int p = 0; p < 3; ++p) {
       hoff_plane[p] = hoff;
       for (int l = 0; l < d.hd[p].n_levels; ++l) {
@@ -672,8 +681,8 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       }
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
-    (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), 128 * 1024, stream, d, t, xsoa, P, chunk, gdynT, stats, Hbuf);
+    (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DYNHASH_LDS_KB * 1024);
+    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), DYNHASH_LDS_KB * 1024, stream, d, t, xsoa, P, chunk, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);

@@ -10,11 +10,9 @@ run() {  # name, env...
   python - "$O/bench_$name.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-print("  ms/step %.2f" % d["ms_per_step"], " ".join("%s=%.2f" % (r["kernel"][:22], r["ms_per_step"]) for r in d["roofline_kernels"] if r["kernel"].startswith("bin_pass")))
+keep = ("planes_static", "planes_dyn", "field_bwd_prep", "dynhash_lds")
+print("  ms/step %.2f" % d["ms_per_step"], " ".join("%s=%.2f" % (r["kernel"][:22], r["ms_per_step"]) for r in d["roofline_kernels"] if r["kernel"].startswith(keep)))
 PY
 }
 run default X=1
-run b512_s10 L4D_LIB=$PWD/tools/abl/lib_bins512.so L4D_BS_SHIFT4=10
-run b512_s10_s11 L4D_LIB=$PWD/tools/abl/lib_bins512.so L4D_BS_SHIFT4=10 L4D_BS_SHIFT2=11
-run b512_s11 L4D_LIB=$PWD/tools/abl/lib_bins512.so L4D_BS_SHIFT4=11
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+for V in pdyn768; do run $V L4D_LIB=$PWD/tools/abl/lib_$V.so; done
