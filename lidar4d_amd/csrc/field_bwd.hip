@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 // same two texels -- 144 instead of 480 texel loads per sample in a kernel that is bound by their latency.
 #define TFRAMES 3
 #ifndef PDYN_THREADS
-#define PDYN_THREADS 512
+#define PDYN_THREADS 768  // 12 waves on the one workgroup a CU can hold (138 KB of LDS; 155 VGPRs allow 3 per SIMD): 3.00 -> 2.73 ms against 512
 #endif
 template <bool ROWS>
 __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
