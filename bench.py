@@ -95,7 +95,9 @@ def kernel_models(model, P, M):
     lds_alg = 2 * 3 * (2 * L * 4 * 8)                                            # xz, yz stacks x 3 frames
     X = 2 * in_pad
     m = {}
-    enc = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P, gathers=(L * 8 + 3 * L * 4) * P,
+    # gathers always issued: static grid 8 corners + current-frame xy stack 4 corners per level; the two warped frames' 4 + 4 are
+    # issued only where the warped point leaves the current point's cell (all reused while the flow is zero, as at initialisation)
+    enc = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P, gathers=(L * 8 + L * 4) * P,
                note="planes + static hash + xy dynamic hash gathers (time planes via per-call 1-D rows, both time slices of a corner "
                     "in one 16-B load); row staged in LDS, written once")
     m["density_encode_fwd_kernel<true, true>"] = enc
@@ -410,7 +412,7 @@ def _run(args):
                 row.update(bound=mod["bound"], bytes_per_launch=mod["bytes"], modelled_launches_per_step=len(big) / args.profile_steps,
                            modelled_launch_ms=round(avg_ms, 4), achieved=round(ach, 1), peak=peaks[mod["bound"]], unit="GB/s",
                            frac=round(ach / peaks[mod["bound"]], 4), traffic=pmc_lookup(traffic, name), note=mod["note"])
-                if "gathers" in mod:  # hash-entry gathers (one lane = one table entry; plane taps are coherent and not counted)
+                if "gathers" in mod:  # hash-entry gathers that are always issued (one lane = one table entry; coherent plane taps not counted)
                     gl = mod["gathers"] / (avg_ms * 1e-3) / 1e9
                     row["hash_gathers_G_per_s"] = round(gl, 1)
                     row["frac_of_measured_random_gather_rate"] = round(gl / GATHER_PEAK_G, 4)
