@@ -110,7 +110,7 @@ def kernel_models(model, P, M):
     fl = lambda pad, nh: 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
     it_s, nf = in_pad // 16, model.flow_net.n_hidden
     # sigma network: x + y + saved activations; backward also writes dx
-    m[f"mlp_fwd_kernel<{it_s}, {nh_s}>"] = dict(bound="hbm", bytes=(X + 32 + nh_s * 128) * P, flops=fl(in_pad, nh_s) * P, note="x + y + saved activations")
+    m[f"mlp_fwd_kernel<{it_s}, {nh_s}>"] = dict(bound="hbm", bytes=(X + 32 + 4 + nh_s * 128) * P, flops=fl(in_pad, nh_s) * P, note="x + y + sigma (exp epilogue) + saved activations")
     m[f"mlp_bwd_kernel<{it_s}, {nh_s}, 0, {it_s}, true>"] = dict(bound="hbm", bytes=(X + nh_s * 128 + 32 + X) * P, flops=2 * fl(in_pad, nh_s) * P,
                                                                note="x + activations + dy read, dx written (algorithmic flops: dX + dW)")
     # flow network: activations are recomputed in the backward, not stored
@@ -119,10 +119,10 @@ def kernel_models(model, P, M):
                                                          note="x + dy read, dx written; activations recomputed (algorithmic flops: fwd + dX + dW)")
     # attribute networks on the work list: rows assembled in the kernel (index + sigma-net output row), geo-feature gradient only
     it_a = a_pad // 16
-    m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true, false>"] = dict(bound="hbm", bytes=(4 + 32 + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M,
-                                                             note="idx + h row in (direction encoding per ray: cache resident), y + activations out")
-    m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true, true>"] = dict(bound="hbm", bytes=(4 + 32 + 32 + nh_a * 128 + 2 * a_pad) * M, flops=fl(a_pad, nh_a) * M,
-                                                            note="the same + the assembled rows stored once for both networks' backward")
+    m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true, false, 2>"] = dict(bound="hbm", bytes=(4 + 32 + 8 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M,
+                                                                note="idx + h row in (direction encoding per ray: cache resident), sigmoid epilogue (dense + compact value) + activations out")
+    m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true, true, 2>"] = dict(bound="hbm", bytes=(4 + 32 + 8 + nh_a * 128 + 2 * a_pad) * M, flops=fl(a_pad, nh_a) * M,
+                                                               note="the same + the assembled rows stored once for both networks' backward")
     m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, false, false, 4>"] = dict(bound="hbm", bytes=(2 * a_pad + nh_a * 128 + 32 + 64) * M,
                                                                                 flops=2 * fl(a_pad, nh_a) * M, note="stored rows + activations + dy in, 32 gradient columns out")
     m[f"mlp_fwd_kernel<{it_a}, {nh_a}>"] = dict(bound="hbm", bytes=(2 * a_pad + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M, note="materialised input rows")

@@ -135,6 +135,10 @@ int l4d_freq_fwd(const float* x, int64_t P, int32_t n_dims, int32_t n_freq, void
  *          on the device, e.g. the weights>1e-4 compaction); buffers keep their P-row strides */
 int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad, int32_t n_hidden,
                 const void* weights, void* y, void* act, void* stream);
+/* l4d_mlp_fwd with the density activation as epilogue: additionally sigma[row] = exp(y[row][0]) (fp32; trunc_exp's
+ * forward, activation.py:6-20).  Same (in_pad, n_hidden) support as l4d_mlp_fwd. */
+int l4d_mlp_fwd_sigma(const void* x, int64_t P, int32_t in_pad, int32_t n_hidden, const void* weights, void* y, void* act,
+                      float* sigma, void* stream);
 /* dy [P,16] fp16 (already multiplied by the caller's loss scale); dx [P, in_pad] fp16 or null;
  * grad_w fp32, same layout as weights, ACCUMULATED with 1/loss_scale applied.
  * act: the forward's saved activations, or null = recompute them from x inside the kernel (saves 128 B/row/layer of HBM
@@ -193,10 +197,13 @@ int l4d_attr_gather_bwd(const int32_t* idx, const int32_t* count, int64_t cap, c
  * assembled rows in physical order for l4d_attr_mlp_bwd (one network of the pair stores them, both read them).
  * l4d_attr_mlp_bwd: x_rows as stored by the forward; dx_tail [cap, in_pad - 64] fp16 <- the input gradient's columns 64 ..
  * in_pad - 1 in physical order (the direction encoding has no trainable input): feed it to l4d_attr_gather_bwd with
- * in_pad = in_pad - 64, n_enc = n_enc - 64, h_layout = 1. */
+ * in_pad = in_pad - 64, n_enc = n_enc - 64, h_layout = 1.
+ * Sigmoid epilogue (lidar4d.py:210-219): with attr_dense [P, 2] fp32 (pre-zeroed) and attr_compact [cap, 2] fp32 given,
+ * s = fp16(sigmoid(y[:, 0])) goes to attr_dense[idx[j]][channel] and attr_compact[j][channel] (channel 0 = ray-drop, 1 =
+ * intensity) and y is not stored (may be null): replaces l4d_attr_scatter. */
 int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
                      const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* weights, void* y, void* act,
-                     void* x_rows_out, void* stream);
+                     void* x_rows_out, float* attr_dense, float* attr_compact, int32_t channel, void* stream);
 int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_t cap, int32_t n_enc, int32_t n_geo, int32_t in_pad,
                      int32_t n_hidden, const void* act, const void* dy, const void* weights, void* dx_tail, float* grad_w,
                      float inv_loss_scale, void* stream);

@@ -109,10 +109,20 @@ __device__ __forceinline__ uint4 attr_chunk(const AttrSrc& s, int64_t p, int k0)
 // weight layout (fp16): W1 [64, in_pad], (NH-1) x [64, 64], Wo [16, 64]
 // GATHER: input rows assembled from AttrSrc; WRITE_X: the assembled rows (physical column order) are also stored to xout
 // [cap, IN_PAD] for a backward pass that reads them as a plain matrix.
-template <int IN_TILES, int NH, bool GATHER = false, bool WRITE_X = false>
+// EPI: activation epilogue on output column 0 ({none, trunc_exp@col0, sigmoid}):
+//   0  with epi0 given: epi0[row] = exp(y0)     -- the density activation (activation.py:6-20), fp32, y still stored
+//   2  s = fp16(sigmoid(y0)); epi0[2 * sample + epi_ch] = s (dense [P, 2] image of lidar4d.py:216-219), epi1[2 * row + epi_ch] = s
+//      (compact copy for the backward); y itself is not stored (nothing reads it)
+struct MlpEpi {
+  float* epi0;
+  float* epi1;
+  int ch;
+};
+template <int IN_TILES, int NH, bool GATHER = false, bool WRITE_X = false, int EPI = 0>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__ x, int64_t cap, const int32_t* __restrict__ n_rows,
                                                      const half_t* __restrict__ weights, half_t* __restrict__ y,
-                                                     half_t* __restrict__ act, AttrSrc src, half_t* __restrict__ xout = nullptr) {
+                                                     half_t* __restrict__ act, AttrSrc src, half_t* __restrict__ xout = nullptr,
+                                                     MlpEpi epi = MlpEpi{nullptr, nullptr, 0}) {
   // cap = rows the buffers were sized for (stride of the act planes); P = rows actually present
   const int64_t P = n_rows ? min((int64_t)*n_rows, cap) : cap;
   constexpr int IN_PAD = IN_TILES * 16;
@@ -198,7 +208,13 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__
       h4 ov;
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov[r] = f2h(clamp_h(o[r]));
-      *reinterpret_cast<h4*>(y + row * 16 + 4 * g) = ov;
+      if (EPI != 2) *reinterpret_cast<h4*>(y + row * 16 + 4 * g) = ov;
+      if (EPI != 2 && epi.epi0 && g == 0) epi.epi0[row] = expf(h2f(ov[0]));
+      if (EPI == 2 && g == 0) {
+        const float sgm = h2f(f2h(1.0f / (1.0f + expf(-h2f(ov[0])))));
+        epi.epi0[psrc * 2 + epi.ch] = sgm;
+        epi.epi1[row * 2 + epi.ch] = sgm;
+      }
     }
   }
 }
@@ -605,17 +621,18 @@ static int grid_for(int64_t tiles) {
 #define FOR_EACH_CFG(X) X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3) X(4, 1) X(4, 2) X(4, 3) X(6, 1) X(6, 2) X(6, 3) X(8, 1) X(8, 2) X(8, 3)
 #define FOR_EACH_WIDE_CFG(X) X(10, 1) X(10, 2) X(10, 3) X(11, 1) X(11, 2) X(11, 3) X(12, 1) X(12, 2) X(12, 3)
 
-extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad, int32_t n_hidden,
-                           const void* weights, void* y, void* act, void* stream) {
+static int mlp_fwd_dispatch(const char* who, const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad, int32_t n_hidden,
+                            const void* weights, void* y, void* act, float* sigma, void* stream) {
   if (P == 0) return 0;
   const int in_tiles = in_pad / 16;
   const int grid = grid_for((P + 15) / 16);
   bool done = false;
-#define X(IT, NHH)                                                                                                   \
-  if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
-    L4D_LAUNCH((mlp_fwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, P, \
-                       n_rows, (const half_t*)weights, (half_t*)y, (half_t*)act, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                \
-    done = true;                                                                                                     \
+#define X(IT, NHH)                                                                                                            \
+  if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                                       \
+    L4D_LAUNCH((mlp_fwd_kernel<IT, NHH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, P, n_rows,         \
+               (const half_t*)weights, (half_t*)y, (half_t*)act, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1}, (half_t*)nullptr, \
+               MlpEpi{sigma, nullptr, 0});                                                                                    \
+    done = true;                                                                                                              \
   }
   FOR_EACH_CFG(X)
   FOR_EACH_WIDE_CFG(X)
@@ -624,8 +641,23 @@ extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int3
     l4d_set_error(1, "l4d_mlp_fwd: unsupported (in_pad, n_hidden); in_pad in {16,32,64,96,128,160,176,192}, n_hidden in 1..3");
     return 1;
   }
-  L4D_LAUNCH_CHECK("l4d_mlp_fwd");
+  L4D_LAUNCH_CHECK(who);
   return 0;
+}
+
+extern "C" int l4d_mlp_fwd(const void* x, int64_t P, const int32_t* n_rows, int32_t in_pad, int32_t n_hidden,
+                           const void* weights, void* y, void* act, void* stream) {
+  return mlp_fwd_dispatch("l4d_mlp_fwd", x, P, n_rows, in_pad, n_hidden, weights, y, act, nullptr, stream);
+}
+
+// l4d_mlp_fwd with the density activation as epilogue: sigma[row] = exp(y[row][0]) (trunc_exp's forward, activation.py:6-20)
+extern "C" int l4d_mlp_fwd_sigma(const void* x, int64_t P, int32_t in_pad, int32_t n_hidden, const void* weights, void* y,
+                                 void* act, float* sigma, void* stream) {
+  if (!sigma) {
+    l4d_set_error(1, "l4d_mlp_fwd_sigma: sigma is null");
+    return 1;
+  }
+  return mlp_fwd_dispatch("l4d_mlp_fwd_sigma", x, P, nullptr, in_pad, n_hidden, weights, y, act, sigma, stream);
 }
 
 extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64_t P, const int32_t* n_rows, int32_t in_pad,
@@ -692,22 +724,29 @@ static int attr_src(const int32_t* idx, int32_t T, const void* dir_enc, int32_t 
 
 extern "C" int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc, int32_t n_enc,
                                 const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* weights, void* y,
-                                void* act, void* x_rows_out, void* stream) {
+                                void* act, void* x_rows_out, float* attr_dense, float* attr_compact, int32_t channel, void* stream) {
   if (cap == 0) return 0;
   AttrSrc src;
   if (attr_src(idx, T, dir_enc, n_enc, h, n_geo, in_pad, src, "l4d_attr_mlp_fwd: needs in_pad 96, 64 <= n_enc <= 80 (multiple of 8), n_geo = 15")) return 1;
   const int grid = grid_for((cap + 15) / 16);
+  if ((attr_dense == nullptr) != (attr_compact == nullptr) || (!attr_dense && !y) || channel < 0 || channel > 1) {
+    l4d_set_error(1, "l4d_attr_mlp_fwd: pass y, or both attr_dense and attr_compact (sigmoid epilogue) with channel 0 / 1");
+    return 1;
+  }
+  const MlpEpi epi{attr_dense, attr_compact, channel};
+#define LAUNCH_F(NHH, WX, EP)                                                                                          \
+  L4D_LAUNCH((mlp_fwd_kernel<6, NHH, true, WX, EP>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)nullptr, cap, \
+             count, (const half_t*)weights, (half_t*)y, (half_t*)act, src, (half_t*)x_rows_out, epi)
 #define X(NHH)                                                                                                         \
   if (n_hidden == NHH) {                                                                                               \
-    if (x_rows_out)                                                                                                    \
-      L4D_LAUNCH((mlp_fwd_kernel<6, NHH, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)nullptr, cap, \
-                 count, (const half_t*)weights, (half_t*)y, (half_t*)act, src, (half_t*)x_rows_out);                   \
-    else                                                                                                               \
-      L4D_LAUNCH((mlp_fwd_kernel<6, NHH, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half_t*)nullptr, cap, \
-                 count, (const half_t*)weights, (half_t*)y, (half_t*)act, src, (half_t*)nullptr);                      \
+    if (x_rows_out && attr_dense) LAUNCH_F(NHH, true, 2);                                                              \
+    else if (x_rows_out) LAUNCH_F(NHH, true, 0);                                                                       \
+    else if (attr_dense) LAUNCH_F(NHH, false, 2);                                                                      \
+    else LAUNCH_F(NHH, false, 0);                                                                                      \
   }
   X(1) X(2) X(3)
 #undef X
+#undef LAUNCH_F
   if (n_hidden < 1 || n_hidden > 3) { l4d_set_error(1, "l4d_attr_mlp_fwd: n_hidden in 1..3"); return 1; }
   L4D_LAUNCH_CHECK("l4d_attr_mlp_fwd");
   return 0;

@@ -118,9 +118,9 @@ class RenderFn(torch.autograd.Function):
         # density (lidar4d.py:139-188)
         fd = _field_desc(model)
         X = ops.density_encode_fwd(fd, xt, flow16, tinfo, model.sigma_net.in_pad)
-        h, act_s = ops.mlp_fwd(X, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,
-                               save_act=train and not ops.mlp_recompute_supported(X.shape[1], model.sigma_net.n_hidden_layers))
-        sigma = ops.sigma_from_h(h)
+        # density network with its activation (trunc_exp, activation.py:6-20) as epilogue
+        h, act_s, sigma = ops.mlp_fwd_sigma(X, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,
+                                            save_act=train and not ops.mlp_recompute_supported(X.shape[1], model.sigma_net.n_hidden_layers))
 
         # compositing + mask compaction (renderer.py:98-110)
         weights, wsum, depth, _, idx, count = ops.composite_fwd(sigma, z_vals, sample_dist, model.density_scale,
@@ -130,19 +130,20 @@ class RenderFn(torch.autograd.Function):
         denc = ops.freq_fwd(((rays_d + 1) / 2).contiguous(), model.view_encoder.n_frequencies)
         an = model.intensity_net
         gathered = ops.attr_mlp_supported(an.in_pad, denc.shape[1], model.geo_feat_dim)
-        if gathered:  # the networks assemble their input rows themselves; the first one stores them for the backward pass
+        attr = torch.zeros(P, 2, dtype=torch.float32, device=dev)
+        attr_c = torch.empty(P, 2, dtype=torch.float32, device=dev)
+        if gathered:  # the networks assemble their input rows themselves (the first one stores them for the backward pass) and
+            # apply the sigmoid + scatter into the dense [P, 2] image as their epilogue (lidar4d.py:210-219)
             XA = torch.empty(P, an.in_pad, dtype=torch.float16, device=dev) if train else None
-            yR, actR = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.raydrop_net.params),
-                                        an.n_hidden_layers, save_act=train, x_rows_out=XA)
-            yI, actI = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.intensity_net.params),
-                                        an.n_hidden_layers, save_act=train)
+            _, actR = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.raydrop_net.params),
+                                       an.n_hidden_layers, save_act=train, x_rows_out=XA, attr_dense=attr, attr_compact=attr_c, channel=0)
+            _, actI = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.intensity_net.params),
+                                       an.n_hidden_layers, save_act=train, attr_dense=attr, attr_compact=attr_c, channel=1)
         else:
             XA = ops.attr_gather(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad)
             yR, actR = ops.mlp_fwd(XA, store.half(model.raydrop_net.params), an.n_hidden_layers, save_act=train, n_rows=count)
             yI, actI = ops.mlp_fwd(XA, store.half(model.intensity_net.params), an.n_hidden_layers, save_act=train, n_rows=count)
-        attr = torch.zeros(P, 2, dtype=torch.float32, device=dev)
-        attr_c = torch.empty(P, 2, dtype=torch.float32, device=dev)
-        ops.attr_scatter(idx, count, P, yR, yI, attr, attr_c)
+            ops.attr_scatter(idx, count, P, yR, yI, attr, attr_c)
         image = ops.composite_image(weights, attr, 2)
 
         if train:

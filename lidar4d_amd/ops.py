@@ -284,16 +284,30 @@ def attr_mlp_supported(in_pad, n_enc, n_geo):
     return in_pad == 96 and n_enc % 8 == 0 and n_enc // 16 == 4 and n_enc + 16 <= in_pad and n_geo == 15
 
 
-def attr_mlp_fwd(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, weights16, n_hidden, save_act=True, x_rows_out=None):
+def attr_mlp_fwd(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, weights16, n_hidden, save_act=True, x_rows_out=None,
+                 attr_dense=None, attr_compact=None, channel=0):
     """Attribute network on the compacted work list, input rows assembled in the kernel -> y [cap,16] (+ act).
-    x_rows_out: [cap, in_pad] fp16 that receives the assembled rows (physical column order) for attr_mlp_bwd."""
+    x_rows_out: [cap, in_pad] fp16 that receives the assembled rows (physical column order) for attr_mlp_bwd.
+    attr_dense [P,2] / attr_compact [cap,2] fp32: sigmoid epilogue into column ``channel`` (then y is not produced: None)."""
     _chk(idx, torch.int32, "idx"), _chk(count, torch.int32, "count"), _chk(dir_enc16, torch.float16, "dir_enc")
     _chk(h16, torch.float16, "h"), _chk(weights16, torch.float16, "weights"), _chk(x_rows_out, torch.float16, "x_rows_out")
-    y = torch.empty(cap, 16, dtype=torch.float16, device=h16.device)
+    _chk(attr_dense, torch.float32, "attr_dense"), _chk(attr_compact, torch.float32, "attr_compact")
+    y = torch.empty(cap, 16, dtype=torch.float16, device=h16.device) if attr_dense is None else None
     act = torch.empty(n_hidden, cap, 64, dtype=torch.float16, device=h16.device) if save_act else None
     call("l4d_attr_mlp_fwd", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad, n_hidden,
-         _p(weights16), _p(y), _p(act), _p(x_rows_out), _stream())
+         _p(weights16), _p(y), _p(act), _p(x_rows_out), _p(attr_dense), _p(attr_compact), int(channel), _stream())
     return y, act
+
+
+def mlp_fwd_sigma(x16, weights16, n_hidden, save_act=True):
+    """mlp_fwd + the density activation as epilogue -> (y [P,16] fp16, act, sigma [P] fp32 = exp(y[:, 0]))."""
+    _chk(x16, torch.float16, "x"), _chk(weights16, torch.float16, "weights")
+    P, in_pad = x16.shape
+    y = torch.empty(P, 16, dtype=torch.float16, device=x16.device)
+    act = torch.empty(n_hidden, P, 64, dtype=torch.float16, device=x16.device) if save_act else None
+    sigma = torch.empty(P, dtype=torch.float32, device=x16.device)
+    call("l4d_mlp_fwd_sigma", _p(x16), P, in_pad, n_hidden, _p(weights16), _p(y), _p(act), _p(sigma), _stream())
+    return y, act, sigma
 
 
 def attr_mlp_bwd(x_rows, count, n_enc, n_geo, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale):

@@ -45,6 +45,7 @@ int main(void) {
       (fn_t)&l4d_mark_time_slices,
       (fn_t)&l4d_mlp_bwd,
       (fn_t)&l4d_mlp_fwd,
+      (fn_t)&l4d_mlp_fwd_sigma,
       (fn_t)&l4d_pano_to_lidar,
       (fn_t)&l4d_pano_to_lidar_workspace,
       (fn_t)&l4d_planes_bwd,

@@ -330,6 +330,15 @@ def test_attr_mlp_gathered_equals_materialised():
             d = (a - b).abs()
             assert float(d.max()) <= 2 ** -9 * max(float(b.abs().max()), 1e-6) and float((d > 0).float().mean()) < 0.05, (what, float(d.max()), float((d > 0).float().mean()))
         near(y0[:M], y1[:M], "y"), near(act0[:, :M], act1[:, :M], "act")
+        # sigmoid epilogue == l4d_attr_scatter on the stored outputs, bit for bit (same fp16 output, same rounding points)
+        a0, c0 = torch.zeros(P, 2, device=DEV), torch.zeros(P, 2, device=DEV)
+        ops.attr_scatter(idx, count, P, y1, y1, a0, c0)
+        a1, c1 = torch.zeros(P, 2, device=DEV), torch.zeros(P, 2, device=DEV)
+        for ch in (0, 1):
+            ye, _ = ops.attr_mlp_fwd(idx, count, P, T, denc, h, n_geo, in_pad, w, n_hidden, save_act=False,
+                                     attr_dense=a1, attr_compact=c1, channel=ch)
+            assert ye is None
+        assert torch.equal(a0, a1) and torch.equal(c0[:M], c1[:M]) and float(a1.abs().max()) > 0
         dy = torch.zeros(P, 16, dtype=torch.float16, device=DEV)
         dy[:, 0] = det_uniform((P,), "gady", -1, 1).half().to(DEV)
         g0, g1 = torch.zeros(w.numel(), device=DEV), torch.zeros(w.numel(), device=DEV)
@@ -348,3 +357,15 @@ def test_attr_mlp_gathered_equals_materialised():
     zero = torch.zeros(1, dtype=torch.int32, device=DEV)
     y, _ = ops.attr_mlp_fwd(idx, zero, P, T, denc, h, n_geo, in_pad, w, 2, save_act=False)
     assert y.shape == (P, 16)
+
+
+def test_mlp_fwd_sigma_epilogue():
+    """l4d_mlp_fwd_sigma == l4d_mlp_fwd followed by l4d_sigma_from_h, bit for bit, on every width the model configs use."""
+    from lidar4d_amd import ops
+    for in_pad, n_hidden, P in ((128, 1, 4099), (176, 2, 515), (64, 1, 33), (32, 2, 1000)):
+        x = det_uniform((P, in_pad), f"sx{in_pad}", -1, 1).half().to(DEV)
+        w = det_uniform((64 * in_pad + (n_hidden - 1) * 64 * 64 + 16 * 64,), f"sw{in_pad}", -0.3, 0.3).half().to(DEV)
+        y0, act0 = ops.mlp_fwd(x, w, n_hidden, save_act=True)
+        y1, act1, sigma = ops.mlp_fwd_sigma(x, w, n_hidden, save_act=True)
+        assert torch.equal(y0, y1) and torch.equal(act0, act1)
+        assert torch.equal(sigma, ops.sigma_from_h(y0)) and float(sigma.min()) > 0
