@@ -67,11 +67,9 @@ __device__ __forceinline__ float pair_eval(const PairCorners& pc, const Cell<2>&
     const float w = corner<2>(c, k, gv);
     const half_t* h = reinterpret_cast<const half_t*>(&pc.e[k]);
 #pragma unroll
-    for (int f = 0; f < 4; f += 2) {
-      const float2_t ra = float2_t{a[f], a[f + 1]} + float2_t{h2f(h[f]), h2f(h[f + 1])} * w;
-      const float2_t rb = float2_t{b[f], b[f + 1]} + float2_t{h2f(h[4 + f]), h2f(h[5 + f])} * w;
-      a[f] = ra[0]; a[f + 1] = ra[1];
-      b[f] = rb[0]; b[f + 1] = rb[1];
+    for (int f = 0; f < 4; ++f) {
+      a[f] = fmix(h[f], w, a[f]);
+      b[f] = fmix(h[4 + f], w, b[f]);
     }
   }
   float r = 0.0f;
@@ -114,11 +112,9 @@ __device__ __forceinline__ float hash_t_level(const FieldDesc& fd, int plane, in
       const uint4 raw = tab[grid_index<2>(gv, g.res[lvl], g.size[lvl], hashed)];
       const half_t* h = reinterpret_cast<const half_t*>(&raw);
 #pragma unroll
-      for (int f = 0; f < 4; f += 2) {  // same order and roundings as level_lookup: acc + v * w per corner
-        const float2_t ra = float2_t{a[f], a[f + 1]} + float2_t{h2f(h[f]), h2f(h[f + 1])} * w;
-        const float2_t rb = float2_t{b[f], b[f + 1]} + float2_t{h2f(h[4 + f]), h2f(h[5 + f])} * w;
-        a[f] = ra[0]; a[f + 1] = ra[1];
-        b[f] = rb[0]; b[f + 1] = rb[1];
+      for (int f = 0; f < 4; ++f) {  // same order and roundings as level_lookup: fmix per corner
+        a[f] = fmix(h[f], w, a[f]);
+        b[f] = fmix(h[4 + f], w, b[f]);
       }
     }
     float r = 0.0f;

@@ -244,8 +244,13 @@ struct BwdFrags {
 // GATHER: x rows come from AttrSrc; DX_LO: dx is produced only for the column tiles DX_LO .. COL_HI - 1 and stored compactly
 // as [rows, (COL_HI - DX_LO) * 16] (the attribute networks need the gradient of their geo_feat columns only: the direction
 // encoding has no trainable input).
+// MLP_BWD_NARROW_WAVES: waves per SIMD the 16-wide (flow) network's backward is compiled for.  Its accumulators are small, but
+// the compiler keeps the LDS weight fragments in registers across the tile loop as long as it has any (446 of 512).
+#ifndef MLP_BWD_NARROW_WAVES
+#define MLP_BWD_NARROW_WAVES 1
+#endif
 template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST, bool RECOMP = false, bool GATHER = false, int DX_LO = COL_LO>
-__global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
+__global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1)) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
                                                      const half_t* __restrict__ dy, int64_t cap,
                                                      const int32_t* __restrict__ n_rows,
                                                      const half_t* __restrict__ weights, half_t* __restrict__ dx,
@@ -317,7 +322,71 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
     for (int b = 0; b < NCOL; ++b) dW1[a][b] = f4{0, 0, 0, 0};
 
   const int64_t n_macro = (P + 31) / 32;
-  for (int64_t mtile = (int64_t)blockIdx.x * 4 + wave; mtile < n_macro; mtile += (int64_t)gridDim.x * 4) {
+  // Inputs of one macro tile (32 rows): x rows, dy rows and -- unless recomputed -- the hidden activations, as loaded.  They
+  // are fetched ONE TILE AHEAD: with the single wavefront per SIMD this kernel's accumulators leave room for, nothing else
+  // hides the HBM latency of a tile's loads (measured: 12,000 clocks per tile for 5,000 clocks of MFMA + VALU work).
+  constexpr int NACT = RECOMP ? 0 : NH;
+  constexpr bool PREFETCH = !(NH >= 3 && COL_HI - COL_LO >= 8);  // the widest 3-hidden-layer variant has no register left for it
+  struct TileIn {
+    uint4 x[2][KS_IN];
+    uint4 dy[2];
+    uint4 h[NACT > 0 ? NACT : 1][2][2];
+  };
+  // load_tile only ISSUES loads (no instruction may touch the destination registers before the tile is consumed, or the
+  // compiler has to wait for the data right here); finish_tile zeroes what does not exist, one iteration later.
+  auto load_tile = [&](int64_t mtile, TileIn& t) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int64_t row = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
+      const int64_t rc = row < P ? row : 0;  // rows past the end read row 0 and are zeroed by finish_tile (P > 0 inside the loop)
+      const int64_t ps = GATHER ? (src.idx ? (int64_t)src.idx[rc] : rc) : rc;
+#pragma unroll
+      for (int ks = 0; ks < KS_IN; ++ks) {
+        const int k0 = 32 * ks + 8 * g;
+        if (k0 < IN_PAD) t.x[a][ks] = GATHER ? attr_chunk(src, ps, k0) : *reinterpret_cast<const uint4*>(x + rc * IN_PAD + k0);
+        else t.x[a][ks] = make_uint4(0, 0, 0, 0);
+      }
+      t.dy[a] = *reinterpret_cast<const uint4*>(dy + rc * 16 + 8 * (g & 1));
+#pragma unroll
+      for (int l = 0; l < NACT; ++l)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          t.h[l][a][ks] = *reinterpret_cast<const uint4*>(act + (int64_t)l * cap * HID + rc * HID + 32 * ks + 8 * g);
+    }
+  };
+  auto finish_tile = [&](int64_t mtile, TileIn& t) {
+    const bool partial = (mtile + 1) * 32 > P;  // wave-uniform: only the last tile
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const bool okr = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3) < P;
+      if (g >= 2 || (partial && !okr)) t.dy[a] = make_uint4(0, 0, 0, 0);  // k = 16 .. 31 of the output contraction do not exist
+      if (partial && !okr) {
+#pragma unroll
+        for (int ks = 0; ks < KS_IN; ++ks) t.x[a][ks] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int l = 0; l < NACT; ++l)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) t.h[l][a][ks] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  const int64_t tile_stride = (int64_t)gridDim.x * 4;
+  int64_t mtile = (int64_t)blockIdx.x * 4 + wave;
+  TileIn cur;
+  if (PREFETCH && mtile < n_macro) load_tile(mtile, cur);
+  for (; mtile < n_macro; mtile += tile_stride) {
+    // the weight fragments are re-read from LDS in every tile: hoisted out of the loop they end up parked in AGPRs and cost 4
+    // v_accvgpr_read per use instead of one ds_read_b128
+    asm volatile("" ::: "memory");
+    TileIn nxt;
+    if (PREFETCH) {
+      finish_tile(mtile, cur);
+      load_tile(min(mtile + tile_stride, n_macro - 1), nxt);  // past the end: the last tile once more, never used
+    } else {
+      load_tile(mtile, cur);
+      finish_tile(mtile, cur);
+    }
+    asm volatile("" ::: "memory");  // keeps the prefetch up here: the scheduler may not sink the loads to their use below
     int64_t rows[2];
     bool ok[2];
 #pragma unroll
@@ -325,9 +394,6 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       rows[a] = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
       ok[a] = rows[a] < P;
     }
-    // (GATHER) the work-list entries are looked up right where the rows are loaded: keeping them live across the whole
-    // tile body costs registers this kernel does not have
-    auto src_row = [&](int a) -> int64_t { return ok[a] ? (src.idx ? (int64_t)src.idx[rows[a]] : rows[a]) : 0; };
     // ---- (RECOMP) forward chain from x: hidden activations of every layer, chain layout [layer][a][ks] ----
     h8 xf[2][KS_IN];
     h8 hrec[RECOMP ? NH : 1][2][2];
@@ -336,10 +402,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
       for (int a = 0; a < 2; ++a) {
 #pragma unroll
         for (int ks = 0; ks < KS_IN; ++ks) {
-          const int k0 = 32 * ks + 8 * g;
-          uint4 u = make_uint4(0, 0, 0, 0);
-          if (ok[a] && k0 < IN_PAD) u = GATHER ? attr_chunk(src, src_row(a), k0) : *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
-          xf[a][ks] = *reinterpret_cast<h8*>(&u);
+          xf[a][ks] = *reinterpret_cast<h8*>(&cur.x[a][ks]);
         }
         f4 acc[4];
 #pragma unroll
@@ -370,9 +433,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
     h8 dyT;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      uint4 u = make_uint4(0, 0, 0, 0);
-      if (ok[a] && g < 2) u = *reinterpret_cast<const uint4*>(dy + rows[a] * 16 + 8 * g);
-      dzf[a][0] = *reinterpret_cast<h8*>(&u);
+      dzf[a][0] = *reinterpret_cast<h8*>(&cur.dy[a]);
     }
     {
       f4 t0 = MFMA(dzf[0][0], I0, (f4{0, 0, 0, 0}));
@@ -391,15 +452,10 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) hf[a][ks] = hrec[NH - 1][a][ks];
     } else {
-      const half_t* a_l = act + (int64_t)(NH - 1) * cap * HID;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          uint4 u = make_uint4(0, 0, 0, 0);
-          if (ok[a]) u = *reinterpret_cast<const uint4*>(a_l + rows[a] * HID + 32 * ks + 8 * g);
-          hf[a][ks] = *reinterpret_cast<h8*>(&u);
-        }
+        for (int ks = 0; ks < 2; ++ks) hf[a][ks] = *reinterpret_cast<h8*>(&cur.h[NACT > 0 ? NH - 1 : 0][a][ks]);
     }
     h8 hT[4];
 #pragma unroll
@@ -454,7 +510,6 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
 #pragma unroll
     for (int li = 0; li < NH - 1; ++li) {
       const int layer = NH - li;  // current dZ belongs to hidden layer `layer`; its input is H_{layer-1}
-      const half_t* a_l = act + (int64_t)(layer - 2) * cap * HID;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -462,9 +517,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
           if (RECOMP) {
             hf[a][ks] = hrec[RECOMP ? layer - 2 : 0][a][ks];
           } else {
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (ok[a]) u = *reinterpret_cast<const uint4*>(a_l + rows[a] * HID + 32 * ks + 8 * g);
-            hf[a][ks] = *reinterpret_cast<h8*>(&u);
+            hf[a][ks] = *reinterpret_cast<h8*>(&cur.h[NACT > 0 ? layer - 2 : 0][a][ks]);
           }
         }
 #pragma unroll
@@ -528,16 +581,9 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
     {
       if (!RECOMP) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const int64_t ps = GATHER ? src_row(a) : 0;
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int ks = 0; ks < KS_IN; ++ks) {
-            const int k0 = 32 * ks + 8 * g;
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (ok[a] && k0 < IN_PAD) u = GATHER ? attr_chunk(src, ps, k0) : *reinterpret_cast<const uint4*>(x + rows[a] * IN_PAD + k0);
-            xf[a][ks] = *reinterpret_cast<h8*>(&u);
-          }
-        }
+          for (int ks = 0; ks < KS_IN; ++ks) xf[a][ks] = *reinterpret_cast<h8*>(&cur.x[a][ks]);
       }
 #pragma unroll
       for (int nt = COL_LO; nt < COL_HI; ++nt) {
@@ -571,6 +617,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_kernel(const half_t* __restrict__
           }
       }
     }
+    if (PREFETCH) cur = nxt;
   }
 
   // ---- flush dW (fp32 atomics; one add per element per wave) ----------------------------------

@@ -11,7 +11,8 @@ mkdir -p ../../tools/abl/obj_$name
 objs=""
 for src in hashgrid planes mlp render optim fused field_bwd binscatter chamfer convert; do
   if [[ " $* " == *" $src.hip "* ]]; then
-    /opt/rocm/bin/hipcc $FLAGS $defs -c $src.hip -o ../../tools/abl/obj_$name/$src.o
+    extra=""; [[ $src == mlp && "$defs" != *NO_VGPR_FORM* ]] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+    /opt/rocm/bin/hipcc $FLAGS $extra $defs -c $src.hip -o ../../tools/abl/obj_$name/$src.o
     objs="$objs ../../tools/abl/obj_$name/$src.o"
   else
     objs="$objs $src.o"
