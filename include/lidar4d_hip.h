@@ -207,6 +207,12 @@ int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_t cap, int3
 int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_t cap, int32_t n_enc, int32_t n_geo, int32_t in_pad,
                      int32_t n_hidden, const void* act, const void* dy, const void* weights, void* dx_tail, float* grad_w,
                      float inv_loss_scale, void* stream);
+/* The same backward with the rows assembled from (idx, dir_enc, h) as in the forward, a tile ahead of their use: nothing is
+ * stored by the forward (x_rows_out null).  n_hidden 1 or 2 (three hidden layers: use the stored-rows form). */
+int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc,
+                              int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* act,
+                              const void* dy, const void* weights, void* dx_tail, float* grad_w, float inv_loss_scale,
+                              void* stream);
 /* sigma = trunc_exp(h[:,0]) (model/activation.py:6-20) on the sigma net's fp16 output h [P,16], and its
  * adjoint dh[:,0] = d_sigma * exp(clamp(h0,-15,15)) * loss_scale (fp16) */
 int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* stream);

@@ -93,12 +93,19 @@ struct AttrSrc {
   int T, n_enc;
   int cperm;            // = n_enc when gathering, -1 otherwise (col_map)
 };
-// PHYSICAL columns k0 .. k0 + 7 of the row of sample p (k0 a multiple of 8; column order: col_map with cperm = n_enc)
-__device__ __forceinline__ uint4 attr_chunk(const AttrSrc& s, int64_t p, int k0) {
-  if (k0 + 8 <= s.n_enc) return *reinterpret_cast<const uint4*>(s.denc + (p / s.T) * s.n_enc + k0);
+// PHYSICAL columns k0 .. k0 + 7 of the row of sample p (k0 a multiple of 8; column order: col_map with cperm = n_enc), in two
+// steps so that the load can be issued a tile ahead with nothing touching its destination: attr_chunk_ptr = where the 16
+// bytes come from (always a valid address, no branch), attr_chunk_fix = what is patched once they have arrived.
+__device__ __forceinline__ const uint4* attr_chunk_ptr(const AttrSrc& s, int64_t p, int k0) {
   const int q = (k0 - s.n_enc) >> 3;
+  const half_t* enc = s.denc + (int64_t)((uint32_t)p / (uint32_t)s.T) * s.n_enc + min(k0, s.n_enc - 8);  // p < 2^31 (checked at launch)
+  const half_t* geo = s.h + p * 16 + 8 * (q & 1);  // q >= 2: any valid 16 bytes, replaced by ones below
+  return reinterpret_cast<const uint4*>(k0 + 8 <= s.n_enc ? enc : geo);
+}
+__device__ __forceinline__ uint4 attr_chunk_fix(const AttrSrc& s, int k0, uint4 u) {
+  const int q = (k0 - s.n_enc) >> 3;
+  if (k0 + 8 <= s.n_enc) return u;
   if (q >= 2) return make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);  // ones
-  uint4 u = *reinterpret_cast<const uint4*>(s.h + p * 16 + 8 * q);
   if (q == 0) u.x = (u.x & 0xFFFF0000u) | 0x3C00u;  // [1.0, g0 .. g6]: the sigma logit's slot carries the constant
   return u;
 }
@@ -153,19 +160,66 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__
   auto FR = [&](int f) -> h8 { uint4 u = frags[f][lane]; return *reinterpret_cast<h8*>(&u); };
 
   const int64_t n_tiles = (P + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+  // PREFETCH: a tile's input rows are fetched one tile ahead and its work-list entry two tiles ahead (the row loads of a
+  // gathered tile depend on it): the loads of tile t + 1 fly while tile t is computed.  Tiles / rows past the end re-read
+  // valid rows (clamped) and are never stored.
+  const int64_t tile_stride = (int64_t)gridDim.x * 4;
+  auto tile_row = [&](int64_t tile) -> int64_t {  // this lane's row of `tile`, clamped
+    const int64_t row = min(tile, n_tiles - 1) * 16 + i;
+    return row < P ? row : 0;
+  };
+  // work-list entry of the row: loaded without a branch (no work list: any readable word, ignored by tile_src) so that no join
+  // makes the compiler wait for it where it is issued
+  const int32_t* entries = GATHER ? (src.idx ? src.idx : reinterpret_cast<const int32_t*>(src.h)) : nullptr;
+  auto load_entry_of = [&](int64_t tile) -> int32_t { return GATHER ? entries[tile_row(tile)] : 0; };
+  auto tile_src = [&](int64_t tile, int32_t entry) -> int64_t {  // source sample of the row
+    return (GATHER && src.idx) ? (int64_t)entry : tile_row(tile);
+  };
+  auto load_rows = [&](int64_t ps, uint4 xr[KS_IN]) {  // ps = tile_src(tile)
+#pragma unroll
+    for (int ks = 0; ks < KS_IN; ++ks) {
+      const int k0 = 32 * ks + 8 * g;
+      if (k0 < IN_PAD) xr[ks] = GATHER ? *attr_chunk_ptr(src, ps, k0) : *reinterpret_cast<const uint4*>(x + ps * IN_PAD + k0);
+      else xr[ks] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  // (only the gathered variants: a plain row matrix is streamed by four wavefronts per SIMD that hide each other's latency,
+  // measured 0.96 -> 1.05 ms with the prefetch; the gathered ones have the dependent work-list load in front: 1.91 -> 1.78)
+  constexpr bool PREFETCH = GATHER;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  int64_t ps_cur = 0;
+  int32_t entry_nxt = 0;
+  uint4 xc[KS_IN];
+  if (PREFETCH && tile < n_tiles) {
+    ps_cur = tile_src(tile, load_entry_of(tile));
+    entry_nxt = load_entry_of(tile + tile_stride);
+    load_rows(ps_cur, xc);
+  }
+  for (; tile < n_tiles; tile += tile_stride) {
+    int64_t ps_nxt = 0;
+    int32_t entry_nn = 0;
+    uint4 xn[KS_IN];
+    if (PREFETCH) {
+      asm volatile("" ::: "memory");
+      ps_nxt = tile_src(tile + tile_stride, entry_nxt);
+      load_rows(ps_nxt, xn);
+      entry_nn = load_entry_of(tile + 2 * tile_stride);
+      asm volatile("" ::: "memory");  // the prefetch stays up here
+    } else {
+      ps_cur = tile_src(tile, load_entry_of(tile));
+      load_rows(ps_cur, xc);
+    }
     const int64_t row = tile * 16 + i;
     const bool ok = row < P;
-    const int64_t psrc = (GATHER && ok) ? (src.idx ? (int64_t)src.idx[row] : row) : 0;
+    const int64_t psrc = ps_cur;
     // input fragments
     h8 xb[KS_IN];
 #pragma unroll
     for (int ks = 0; ks < KS_IN; ++ks) {
       const int k0 = 32 * ks + 8 * g;
-      uint4 u = make_uint4(0, 0, 0, 0);
-      if (ok && k0 < IN_PAD) u = GATHER ? attr_chunk(src, psrc, k0) : *reinterpret_cast<const uint4*>(x + row * IN_PAD + k0);
-      xb[ks] = *reinterpret_cast<h8*>(&u);
-      if (WRITE_X && ok && k0 < IN_PAD) *reinterpret_cast<uint4*>(xout + row * IN_PAD + k0) = u;
+      if (GATHER && k0 < IN_PAD) xc[ks] = attr_chunk_fix(src, k0, xc[ks]);
+      xb[ks] = *reinterpret_cast<h8*>(&xc[ks]);
+      if (WRITE_X && ok && k0 < IN_PAD) *reinterpret_cast<uint4*>(xout + row * IN_PAD + k0) = xc[ks];
     }
     // layer 1
     f4 acc[4];
@@ -215,6 +269,12 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(const half_t* __restrict__
         epi.epi0[psrc * 2 + epi.ch] = sgm;
         epi.epi1[row * 2 + epi.ch] = sgm;
       }
+    }
+    if (PREFETCH) {
+#pragma unroll
+      for (int ks = 0; ks < KS_IN; ++ks) xc[ks] = xn[ks];
+      ps_cur = ps_nxt;
+      entry_nxt = entry_nn;
     }
   }
 }
@@ -334,16 +394,25 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
   };
   // load_tile only ISSUES loads (no instruction may touch the destination registers before the tile is consumed, or the
   // compiler has to wait for the data right here); finish_tile zeroes what does not exist, one iteration later.
-  auto load_tile = [&](int64_t mtile, TileIn& t) {
+  // (GATHER) the work-list entries of a tile's rows are loaded a further tile ahead: the row loads depend on them
+  const int32_t* entries = GATHER ? (src.idx ? src.idx : reinterpret_cast<const int32_t*>(src.h)) : nullptr;
+  auto tile_row = [&](int64_t mtile, int a) -> int64_t {
+    const int64_t row = min(mtile, n_macro - 1) * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
+    return row < P ? row : 0;  // rows past the end read row 0 and are zeroed by finish_tile (P > 0 inside the loop)
+  };
+  auto load_entries = [&](int64_t mtile, int32_t e[2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) e[a] = GATHER ? entries[tile_row(mtile, a)] : 0;
+  };
+  auto load_tile = [&](int64_t mtile, const int32_t e[2], TileIn& t) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const int64_t row = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
-      const int64_t rc = row < P ? row : 0;  // rows past the end read row 0 and are zeroed by finish_tile (P > 0 inside the loop)
-      const int64_t ps = GATHER ? (src.idx ? (int64_t)src.idx[rc] : rc) : rc;
+      const int64_t rc = tile_row(mtile, a);
+      const int64_t ps = (GATHER && src.idx) ? (int64_t)e[a] : rc;
 #pragma unroll
       for (int ks = 0; ks < KS_IN; ++ks) {
         const int k0 = 32 * ks + 8 * g;
-        if (k0 < IN_PAD) t.x[a][ks] = GATHER ? attr_chunk(src, ps, k0) : *reinterpret_cast<const uint4*>(x + rc * IN_PAD + k0);
+        if (k0 < IN_PAD) t.x[a][ks] = GATHER ? *attr_chunk_ptr(src, ps, k0) : *reinterpret_cast<const uint4*>(x + rc * IN_PAD + k0);
         else t.x[a][ks] = make_uint4(0, 0, 0, 0);
       }
       t.dy[a] = *reinterpret_cast<const uint4*>(dy + rc * 16 + 8 * (g & 1));
@@ -360,6 +429,11 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
     for (int a = 0; a < 2; ++a) {
       const bool okr = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3) < P;
       if (g >= 2 || (partial && !okr)) t.dy[a] = make_uint4(0, 0, 0, 0);  // k = 16 .. 31 of the output contraction do not exist
+      if (GATHER) {
+#pragma unroll
+        for (int ks = 0; ks < KS_IN; ++ks)
+          if (32 * ks + 8 * g < IN_PAD) t.x[a][ks] = attr_chunk_fix(src, 32 * ks + 8 * g, t.x[a][ks]);
+      }
       if (partial && !okr) {
 #pragma unroll
         for (int ks = 0; ks < KS_IN; ++ks) t.x[a][ks] = make_uint4(0, 0, 0, 0);
@@ -373,17 +447,27 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
   const int64_t tile_stride = (int64_t)gridDim.x * 4;
   int64_t mtile = (int64_t)blockIdx.x * 4 + wave;
   TileIn cur;
-  if (PREFETCH && mtile < n_macro) load_tile(mtile, cur);
+  int32_t ent_nxt[2] = {0, 0};
+  if (PREFETCH && mtile < n_macro) {
+    int32_t e0[2];
+    load_entries(mtile, e0);
+    load_entries(mtile + tile_stride, ent_nxt);
+    load_tile(mtile, e0, cur);
+  }
   for (; mtile < n_macro; mtile += tile_stride) {
     // the weight fragments are re-read from LDS in every tile: hoisted out of the loop they end up parked in AGPRs and cost 4
     // v_accvgpr_read per use instead of one ds_read_b128
     asm volatile("" ::: "memory");
     TileIn nxt;
+    int32_t ent_nn[2] = {0, 0};
     if (PREFETCH) {
       finish_tile(mtile, cur);
-      load_tile(min(mtile + tile_stride, n_macro - 1), nxt);  // past the end: the last tile once more, never used
+      load_tile(mtile + tile_stride, ent_nxt, nxt);  // past the end: the last tile once more, never used
+      load_entries(mtile + 2 * tile_stride, ent_nn);
     } else {
-      load_tile(mtile, cur);
+      int32_t e0[2];
+      load_entries(mtile, e0);
+      load_tile(mtile, e0, cur);
       finish_tile(mtile, cur);
     }
     asm volatile("" ::: "memory");  // keeps the prefetch up here: the scheduler may not sink the loads to their use below
@@ -617,7 +701,11 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
           }
       }
     }
-    if (PREFETCH) cur = nxt;
+    if (PREFETCH) {
+      cur = nxt;
+      ent_nxt[0] = ent_nn[0];
+      ent_nxt[1] = ent_nn[1];
+    }
   }
 
   // ---- flush dW (fp32 atomics; one add per element per wave) ----------------------------------
@@ -773,6 +861,10 @@ extern "C" int l4d_attr_mlp_fwd(const int32_t* idx, const int32_t* count, int64_
                                 const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* weights, void* y,
                                 void* act, void* x_rows_out, float* attr_dense, float* attr_compact, int32_t channel, void* stream) {
   if (cap == 0) return 0;
+  if (cap >= (int64_t)1 << 31) {
+    l4d_set_error(1, "l4d_attr_mlp_fwd: more than 2^31 - 1 samples");
+    return 1;
+  }
   AttrSrc src;
   if (attr_src(idx, T, dir_enc, n_enc, h, n_geo, in_pad, src, "l4d_attr_mlp_fwd: needs in_pad 96, 64 <= n_enc <= 80 (multiple of 8), n_geo = 15")) return 1;
   const int grid = grid_for((cap + 15) / 16);
@@ -807,8 +899,7 @@ extern "C" int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_
   if (attr_src(nullptr, 1, nullptr, n_enc, nullptr, n_geo, in_pad, src, "l4d_attr_mlp_bwd: needs in_pad 96, 64 <= n_enc <= 80 (multiple of 8), n_geo = 15")) return 1;
   int grid = grid_for((cap + 31) / 32);
   if (grid > 512) grid = 512;
-  // the rows l4d_attr_mlp_fwd stored (physical column order: src.cperm permutes the weight columns); a version that
-  // assembles the rows here as well was measured slower: this kernel has no register to spare (3.65 vs 2.0 ms per launch)
+  // the rows l4d_attr_mlp_fwd stored (physical column order: src.cperm permutes the weight columns)
 #define X(NHH)                                                                                                          \
   if (n_hidden == NHH)                                                                                                  \
     L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, false, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,    \
@@ -818,5 +909,35 @@ extern "C" int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_
 #undef X
   if (n_hidden < 1 || n_hidden > 3) { l4d_set_error(1, "l4d_attr_mlp_bwd: n_hidden in 1..3"); return 1; }
   L4D_LAUNCH_CHECK("l4d_attr_mlp_bwd");
+  return 0;
+}
+
+// l4d_attr_mlp_bwd with the input rows assembled here as well (work list + direction encoding + sigma-network rows, as in
+// l4d_attr_mlp_fwd) instead of read from a stored [cap, in_pad] copy: the forward then stores no rows at all.
+extern "C" int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc,
+                                         int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden,
+                                         const void* act, const void* dy, const void* weights, void* dx_tail, float* grad_w,
+                                         float inv_loss_scale, void* stream) {
+  if (cap == 0) return 0;
+  if (cap >= (int64_t)1 << 31) {
+    l4d_set_error(1, "l4d_attr_mlp_bwd_gathered: more than 2^31 - 1 samples");
+    return 1;
+  }
+  AttrSrc src;
+  if (attr_src(idx, T, dir_enc, n_enc, h, n_geo, in_pad, src, "l4d_attr_mlp_bwd_gathered: needs in_pad 96, 64 <= n_enc <= 80 (multiple of 8), n_geo = 15")) return 1;
+  if (n_hidden < 1 || n_hidden > 2) {  // three hidden layers: no register left for the gather (use the stored-rows entry point)
+    l4d_set_error(1, "l4d_attr_mlp_bwd_gathered: n_hidden in 1..2");
+    return 1;
+  }
+  int grid = grid_for((cap + 31) / 32);
+  if (grid > 512) grid = 512;
+#define X(NHH)                                                                                                          \
+  if (n_hidden == NHH)                                                                                                  \
+    L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, true, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,     \
+               (const half_t*)nullptr, (const half_t*)act, (const half_t*)dy, cap, count, (const half_t*)weights,       \
+               (half_t*)dx_tail, grad_w, inv_loss_scale, src);
+  X(1) X(2)
+#undef X
+  L4D_LAUNCH_CHECK("l4d_attr_mlp_bwd_gathered");
   return 0;
 }

@@ -132,9 +132,11 @@ class RenderFn(torch.autograd.Function):
         gathered = ops.attr_mlp_supported(an.in_pad, denc.shape[1], model.geo_feat_dim)
         attr = torch.zeros(P, 2, dtype=torch.float32, device=dev)
         attr_c = torch.empty(P, 2, dtype=torch.float32, device=dev)
-        if gathered:  # the networks assemble their input rows themselves (the first one stores them for the backward pass) and
-            # apply the sigmoid + scatter into the dense [P, 2] image as their epilogue (lidar4d.py:210-219)
-            XA = torch.empty(P, an.in_pad, dtype=torch.float16, device=dev) if train else None
+        if gathered:  # the networks assemble their input rows themselves, forward and backward (three hidden layers: the first
+            # one stores them for the backward pass), and apply the sigmoid + scatter into the dense [P, 2] image as their
+            # epilogue (lidar4d.py:210-219)
+            keep_rows = train and not ops.attr_mlp_bwd_gathered_supported(an.n_hidden_layers)
+            XA = torch.empty(P, an.in_pad, dtype=torch.float16, device=dev) if keep_rows else None
             _, actR = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.raydrop_net.params),
                                        an.n_hidden_layers, save_act=train, x_rows_out=XA, attr_dense=attr, attr_compact=attr_c, channel=0)
             _, actI = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.intensity_net.params),
@@ -179,7 +181,12 @@ class RenderFn(torch.autograd.Function):
         ops.attr_scatter_bwd(idx, count, P, d_attr, attr_c, ls, dyR, dyI)
         dh = torch.zeros(P, 16, dtype=torch.float16, device=dev)
         n_enc = model.view_encoder.n_output_dims
-        if ctx.gathered:  # rows in the forward's physical column order; only the input gradient's tail (geo_feat tiles) is produced
+        if ctx.gathered and XA is None:  # rows assembled again; only the input gradient's tail (geo_feat tiles) is produced
+            dxaR, dxaI = (ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, a_, dy_, store.half(net.params),
+                                                    an.n_hidden_layers, store.grad_view(net.params), inv)
+                          for net, a_, dy_ in ((model.raydrop_net, actR, dyR), (model.intensity_net, actI, dyI)))
+            ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad - 64, n_enc - 64, model.geo_feat_dim, dh, h_layout=True)
+        elif ctx.gathered:  # rows in the forward's physical column order
             dxaR = ops.attr_mlp_bwd(XA, count, n_enc, model.geo_feat_dim, actR, dyR, store.half(model.raydrop_net.params),
                                     an.n_hidden_layers, store.grad_view(model.raydrop_net.params), inv)
             dxaI = ops.attr_mlp_bwd(XA, count, n_enc, model.geo_feat_dim, actI, dyI, store.half(model.intensity_net.params),

@@ -323,6 +323,21 @@ def attr_mlp_bwd(x_rows, count, n_enc, n_geo, act, dy16, weights16, n_hidden, gr
     return dx
 
 
+def attr_mlp_bwd_gathered_supported(n_hidden):
+    return n_hidden <= 2
+
+
+def attr_mlp_bwd_gathered(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale):
+    """attr_mlp_bwd with the rows assembled in the kernel again (nothing stored by the forward).  -> dx_tail [cap, in_pad - 64]."""
+    _chk(idx, torch.int32, "idx"), _chk(count, torch.int32, "count"), _chk(dir_enc16, torch.float16, "dir_enc")
+    _chk(h16, torch.float16, "h"), _chk(act, torch.float16, "act"), _chk(dy16, torch.float16, "dy")
+    _chk(weights16, torch.float16, "weights"), _chk(grad_w, torch.float32, "grad_w")
+    dx = torch.empty(cap, in_pad - 64, dtype=torch.float16, device=h16.device)
+    call("l4d_attr_mlp_bwd_gathered", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad,
+         n_hidden, _p(act), _p(dy16), _p(weights16), _p(dx), _p(grad_w), float(inv_loss_scale), _stream())
+    return dx
+
+
 def attr_scatter(idx, count, cap, y_raydrop, y_intensity, attr_dense, attr_compact):
     call("l4d_attr_scatter", _p(idx), _p(count), cap, _p(y_raydrop), _p(y_intensity), _p(attr_dense), _p(attr_compact),
          _stream())

@@ -14,6 +14,7 @@ int main(void) {
       (fn_t)&l4d_attr_gather,
       (fn_t)&l4d_attr_gather_bwd,
       (fn_t)&l4d_attr_mlp_bwd,
+      (fn_t)&l4d_attr_mlp_bwd_gathered,
       (fn_t)&l4d_attr_mlp_fwd,
       (fn_t)&l4d_attr_scatter,
       (fn_t)&l4d_attr_scatter_bwd,

@@ -346,6 +346,11 @@ def test_attr_mlp_gathered_equals_materialised():
         dx1 = ops.attr_mlp_bwd(xr, count, denc.shape[1], n_geo, act1, dy, w, n_hidden, g1, 1.0 / 128)
         # dx_tail's physical columns: [64 .. 71 | junk (d/d ones), g0 .. g14 | 88 .. 95]
         assert dx1.shape == (P, 32)
+        # rows assembled in the backward as well: the same operands as the stored rows -> same dx; dW up to atomics order
+        g2 = torch.zeros(w.numel(), device=DEV)
+        dx2 = ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, n_geo, in_pad, act1, dy, w, n_hidden, g2, 1.0 / 128)
+        assert torch.equal(dx1[:M], dx2[:M])
+        assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max())
         near(dx0[:M, 64:72], dx1[:M, :8], "dx tile head"), near(dx0[:M, 72:87], dx1[:M, 9:24], "d geo")
         assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max()) and float(g0.abs().max()) > 0
         dh0, dh1 = torch.zeros(P, 16, dtype=torch.float16, device=DEV), torch.zeros(P, 16, dtype=torch.float16, device=DEV)
