@@ -127,6 +127,9 @@ def kernel_models(model, P, M):
                                                                                 flops=2 * fl(a_pad, nh_a) * M, note="stored rows + activations + dy in, 32 gradient columns out")
     m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, false, true, 4>"] = dict(bound="hbm", bytes=(4 + 32 + nh_a * 128 + 32 + 64) * M,
                                                                                flops=2 * fl(a_pad, nh_a) * M, note="idx + h row (rows assembled again) + activations + dy in, 32 gradient columns out")
+    m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, false, true, 4, true>"] = dict(
+        bound="hbm", bytes=(4 + 32 + 8 + 8 + nh_a * 128 + 48) * M, flops=2 * fl(a_pad, nh_a) * M,
+        note="idx + h row + the two sigmoid-adjoint factors + activations in; geo-feature gradient into dh (stored by the first network, read + stored by the second)")
     m[f"mlp_fwd_kernel<{it_a}, {nh_a}>"] = dict(bound="hbm", bytes=(2 * a_pad + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M, note="materialised input rows")
     m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true>"] = dict(bound="hbm", bytes=(4 * a_pad + nh_a * 128 + 32) * M, flops=2 * fl(a_pad, nh_a) * M, note="materialised input rows")
     rec = 8 * 12  # one 12-byte record per corner (upper bound: equal-cell runs along a ray are merged first)

@@ -208,11 +208,17 @@ int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_t cap, int3
                      int32_t n_hidden, const void* act, const void* dy, const void* weights, void* dx_tail, float* grad_w,
                      float inv_loss_scale, void* stream);
 /* The same backward with the rows assembled from (idx, dir_enc, h) as in the forward, a tile ahead of their use: nothing is
- * stored by the forward (x_rows_out null).  n_hidden 1 or 2 (three hidden layers: use the stored-rows form). */
+ * stored by the forward (x_rows_out null).  n_hidden 1 or 2 (three hidden layers: use the stored-rows form).
+ * With d_attr given (dy / dx_tail then unused, may be null) the streaming steps either side of the network run inside the
+ * kernel (lidar4d.py:210-219 backwards): dy[j][0] = d_attr[idx[j]][channel] * s (1 - s) * loss_scale with
+ * s = attr_compact[j][channel] (replaces l4d_attr_scatter_bwd), and the geo-feature gradient goes straight to
+ * dh[idx[j]][1 .. 15] (fp16 [samples, 16], pre-zeroed; stored when dh_accumulate = 0, added to what the other network of the
+ * pair stored when 1; replaces l4d_attr_gather_bwd). */
 int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc,
                               int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* act,
                               const void* dy, const void* weights, void* dx_tail, float* grad_w, float inv_loss_scale,
-                              void* stream);
+                              const float* d_attr, const float* attr_compact, int32_t channel, float loss_scale, void* dh,
+                              int32_t dh_accumulate, void* stream);
 /* sigma = trunc_exp(h[:,0]) (model/activation.py:6-20) on the sigma net's fp16 output h [P,16], and its
  * adjoint dh[:,0] = d_sigma * exp(clamp(h0,-15,15)) * loss_scale (fp16) */
 int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* stream);

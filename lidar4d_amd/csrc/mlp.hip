@@ -309,12 +309,27 @@ struct BwdFrags {
 #ifndef MLP_BWD_NARROW_WAVES
 #define MLP_BWD_NARROW_WAVES 1
 #endif
-template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST, bool RECOMP = false, bool GATHER = false, int DX_LO = COL_LO>
+// ATTR_EPI (attribute networks, with GATHER): the two streaming steps around the network live in the kernel --
+//   in:  dy[row][0] = d_attr[sample][ch] * s (1 - s) * loss_scale with s = attr_compact[row][ch] (adjoint of the sigmoid +
+//        scatter, lidar4d.py:210-219), other columns 0, instead of a [rows, 16] matrix that is 15/16 zeros;
+//   out: the geo-feature columns of dX go to dh[sample][0 .. 15] (the sigma network's output gradient; column 0 is written
+//        later by the density activation's adjoint) -- stored by the first network, added by the second -- instead of two
+//        [rows, 32] matrices and a gather kernel that sums them.
+struct AttrBwdEpi {
+  const float* d_attr;   // [samples, 2]
+  const float* attr_c;   // [rows, 2]
+  half_t* dh;            // [samples, 16]
+  int ch, accumulate;
+  float loss_scale;
+};
+template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST, bool RECOMP = false, bool GATHER = false, int DX_LO = COL_LO,
+          bool ATTR_EPI = false>
 __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1)) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
                                                      const half_t* __restrict__ dy, int64_t cap,
                                                      const int32_t* __restrict__ n_rows,
                                                      const half_t* __restrict__ weights, half_t* __restrict__ dx,
-                                                     float* __restrict__ grad_w, float inv_scale, AttrSrc src) {
+                                                     float* __restrict__ grad_w, float inv_scale, AttrSrc src,
+                                                     AttrBwdEpi aepi = AttrBwdEpi{nullptr, nullptr, nullptr, 0, 0, 0.0f}) {
   const int64_t P = n_rows ? min((int64_t)*n_rows, cap) : cap;
   using L = BwdFrags<IN_TILES, NH>;
   constexpr int IN_PAD = IN_TILES * 16;
@@ -391,6 +406,7 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
     uint4 x[2][KS_IN];
     uint4 dy[2];
     uint4 h[NACT > 0 ? NACT : 1][2][2];
+    uint2 dh_old[2];  // (ATTR_EPI, accumulate) this lane's 4-column piece of dh[sample]: what the other network stored
   };
   // load_tile only ISSUES loads (no instruction may touch the destination registers before the tile is consumed, or the
   // compiler has to wait for the data right here); finish_tile zeroes what does not exist, one iteration later.
@@ -415,7 +431,14 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
         if (k0 < IN_PAD) t.x[a][ks] = GATHER ? *attr_chunk_ptr(src, ps, k0) : *reinterpret_cast<const uint4*>(x + rc * IN_PAD + k0);
         else t.x[a][ks] = make_uint4(0, 0, 0, 0);
       }
-      t.dy[a] = *reinterpret_cast<const uint4*>(dy + rc * 16 + 8 * (g & 1));
+      if (ATTR_EPI) {  // the two factors of dy[row][0], as loaded; finish_tile multiplies them
+        t.dy[a].x = __float_as_uint(aepi.d_attr[ps * 2 + aepi.ch]);
+        t.dy[a].y = __float_as_uint(aepi.attr_c[rc * 2 + aepi.ch]);
+        // of the 4-column pieces 16 mt + 4 g of dX exactly one per lane falls into columns n_enc .. n_enc + 15
+        if (aepi.accumulate) t.dh_old[a] = *reinterpret_cast<const uint2*>(aepi.dh + ps * 16 + ((4 * g - src.n_enc) & 15));
+      } else {
+        t.dy[a] = *reinterpret_cast<const uint4*>(dy + rc * 16 + 8 * (g & 1));
+      }
 #pragma unroll
       for (int l = 0; l < NACT; ++l)
 #pragma unroll
@@ -428,6 +451,11 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const bool okr = mtile * 32 + 8 * (i >> 2) + 4 * a + (i & 3) < P;
+      if (ATTR_EPI) {
+        const float sg = __uint_as_float(t.dy[a].y);
+        const half_t v = f2h_grad(__uint_as_float(t.dy[a].x) * sg * (1.0f - sg) * aepi.loss_scale);
+        t.dy[a] = make_uint4(g == 0 ? (uint32_t)__builtin_bit_cast(unsigned short, v) : 0u, 0u, 0u, 0u);
+      }
       if (g >= 2 || (partial && !okr)) t.dy[a] = make_uint4(0, 0, 0, 0);  // k = 16 .. 31 of the output contraction do not exist
       if (GATHER) {
 #pragma unroll
@@ -447,12 +475,11 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
   const int64_t tile_stride = (int64_t)gridDim.x * 4;
   int64_t mtile = (int64_t)blockIdx.x * 4 + wave;
   TileIn cur;
-  int32_t ent_nxt[2] = {0, 0};
+  int32_t ent_cur[2] = {0, 0}, ent_nxt[2] = {0, 0};  // work-list entries of the rows in `cur` / of the next tile's rows
   if (PREFETCH && mtile < n_macro) {
-    int32_t e0[2];
-    load_entries(mtile, e0);
+    load_entries(mtile, ent_cur);
     load_entries(mtile + tile_stride, ent_nxt);
-    load_tile(mtile, e0, cur);
+    load_tile(mtile, ent_cur, cur);
   }
   for (; mtile < n_macro; mtile += tile_stride) {
     // the weight fragments are re-read from LDS in every tile: hoisted out of the loop they end up parked in AGPRs and cost 4
@@ -465,9 +492,8 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
       load_tile(mtile + tile_stride, ent_nxt, nxt);  // past the end: the last tile once more, never used
       load_entries(mtile + 2 * tile_stride, ent_nn);
     } else {
-      int32_t e0[2];
-      load_entries(mtile, e0);
-      load_tile(mtile, e0, cur);
+      load_entries(mtile, ent_cur);
+      load_tile(mtile, ent_cur, cur);
       finish_tile(mtile, cur);
     }
     asm volatile("" ::: "memory");  // keeps the prefetch up here: the scheduler may not sink the loads to their use below
@@ -683,7 +709,7 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) dW1[mt][nt - COL_LO] = MFMA(dzT[mt], xT, dW1[mt][nt - COL_LO]);
       }
-      if (dx) {
+      if (dx || ATTR_EPI) {
         constexpr int DX_PITCH = DX_LO == COL_LO ? IN_PAD : (COL_HI - DX_LO) * 16;  // full rows, or only the tiles from DX_LO on
         constexpr int DX_T0 = DX_LO == COL_LO ? 0 : DX_LO;
 #pragma unroll
@@ -696,15 +722,35 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
               h4 ov;
 #pragma unroll
               for (int r = 0; r < 4; ++r) ov[r] = f2h_grad(c[r]);
-              *reinterpret_cast<h4*>(dx + rows[a] * DX_PITCH + 16 * (mt - DX_T0) + 4 * g) = ov;
+              if (ATTR_EPI) {
+                // physical columns n_enc .. n_enc + 15 = [1.0 | g0 .. g14] = the sigma network's output row: this 4-column piece
+                // lands at dh[sample][piece - n_enc] (column 0, the constant's slot, stays 0)
+                const int c0 = 16 * mt + 4 * g - src.n_enc;
+                if (c0 >= 0 && c0 < 16) {
+                  const int64_t ps = src.idx ? (int64_t)ent_cur[a] : rows[a];
+                  h4* d = reinterpret_cast<h4*>(aepi.dh + ps * 16 + c0);
+                  if (aepi.accumulate) {
+                    const h4 old = *reinterpret_cast<const h4*>(&cur.dh_old[a]);  // fetched with the tile (c0 == (4 g - n_enc) & 15)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = f2h_grad(h2f(old[r]) + h2f(ov[r]));
+                  }
+                  if (c0 == 0) ov[0] = (half_t)0.0f;
+                  *d = ov;
+                }
+              } else {
+                *reinterpret_cast<h4*>(dx + rows[a] * DX_PITCH + 16 * (mt - DX_T0) + 4 * g) = ov;
+              }
             }
           }
       }
     }
     if (PREFETCH) {
       cur = nxt;
-      ent_nxt[0] = ent_nn[0];
-      ent_nxt[1] = ent_nn[1];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        ent_cur[a] = ent_nxt[a];
+        ent_nxt[a] = ent_nn[a];
+      }
     }
   }
 
@@ -917,7 +963,8 @@ extern "C" int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_
 extern "C" int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc,
                                          int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden,
                                          const void* act, const void* dy, const void* weights, void* dx_tail, float* grad_w,
-                                         float inv_loss_scale, void* stream) {
+                                         float inv_loss_scale, const float* d_attr, const float* attr_compact, int32_t channel,
+                                         float loss_scale, void* dh, int32_t dh_accumulate, void* stream) {
   if (cap == 0) return 0;
   if (cap >= (int64_t)1 << 31) {
     l4d_set_error(1, "l4d_attr_mlp_bwd_gathered: more than 2^31 - 1 samples");
@@ -929,13 +976,25 @@ extern "C" int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* coun
     l4d_set_error(1, "l4d_attr_mlp_bwd_gathered: n_hidden in 1..2");
     return 1;
   }
+  const bool epi = d_attr != nullptr;
+  if (epi ? (!attr_compact || !dh || channel < 0 || channel > 1) : (!dy || !dx_tail)) {
+    l4d_set_error(1, "l4d_attr_mlp_bwd_gathered: pass (dy, dx_tail), or (d_attr, attr_compact, channel 0 / 1, loss_scale, dh)");
+    return 1;
+  }
   int grid = grid_for((cap + 31) / 32);
   if (grid > 512) grid = 512;
-#define X(NHH)                                                                                                          \
-  if (n_hidden == NHH)                                                                                                  \
-    L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, true, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,     \
-               (const half_t*)nullptr, (const half_t*)act, (const half_t*)dy, cap, count, (const half_t*)weights,       \
-               (half_t*)dx_tail, grad_w, inv_loss_scale, src);
+  const AttrBwdEpi ae{d_attr, attr_compact, (half_t*)dh, channel, dh_accumulate, loss_scale};
+#define X(NHH)                                                                                                               \
+  if (n_hidden == NHH) {                                                                                                     \
+    if (epi)                                                                                                                 \
+      L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, true, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,  \
+                 (const half_t*)nullptr, (const half_t*)act, (const half_t*)nullptr, cap, count, (const half_t*)weights,     \
+                 (half_t*)nullptr, grad_w, inv_loss_scale, src, ae);                                                         \
+    else                                                                                                                     \
+      L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, true, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
+                 (const half_t*)nullptr, (const half_t*)act, (const half_t*)dy, cap, count, (const half_t*)weights,          \
+                 (half_t*)dx_tail, grad_w, inv_loss_scale, src, ae);                                                         \
+  }
   X(1) X(2)
 #undef X
   L4D_LAUNCH_CHECK("l4d_attr_mlp_bwd_gathered");

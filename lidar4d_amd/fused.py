@@ -176,28 +176,31 @@ class RenderFn(torch.autograd.Function):
                                             model.active_sensor, c(d_depth), c(d_wsum), c(d_image), c(d_weights))
         # attribute networks
         an = model.intensity_net
-        dyR = torch.empty(P, 16, dtype=torch.float16, device=dev)
-        dyI = torch.empty(P, 16, dtype=torch.float16, device=dev)
-        ops.attr_scatter_bwd(idx, count, P, d_attr, attr_c, ls, dyR, dyI)
         dh = torch.zeros(P, 16, dtype=torch.float16, device=dev)
         n_enc = model.view_encoder.n_output_dims
-        if ctx.gathered and XA is None:  # rows assembled again; only the input gradient's tail (geo_feat tiles) is produced
-            dxaR, dxaI = (ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, a_, dy_, store.half(net.params),
-                                                    an.n_hidden_layers, store.grad_view(net.params), inv)
-                          for net, a_, dy_ in ((model.raydrop_net, actR, dyR), (model.intensity_net, actI, dyI)))
-            ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad - 64, n_enc - 64, model.geo_feat_dim, dh, h_layout=True)
-        elif ctx.gathered:  # rows in the forward's physical column order
-            dxaR = ops.attr_mlp_bwd(XA, count, n_enc, model.geo_feat_dim, actR, dyR, store.half(model.raydrop_net.params),
-                                    an.n_hidden_layers, store.grad_view(model.raydrop_net.params), inv)
-            dxaI = ops.attr_mlp_bwd(XA, count, n_enc, model.geo_feat_dim, actI, dyI, store.half(model.intensity_net.params),
-                                    an.n_hidden_layers, store.grad_view(model.intensity_net.params), inv)
-            ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad - 64, n_enc - 64, model.geo_feat_dim, dh, h_layout=True)
+        if ctx.gathered and XA is None:
+            # rows assembled again; the sigmoid-scatter adjoint in front of each network and the sum + scatter of the two
+            # geo-feature gradients behind them run inside the kernels (first network stores into dh, second adds)
+            for ch, (net, a_) in enumerate(((model.raydrop_net, actR), (model.intensity_net, actI))):
+                ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, a_, None, store.half(net.params),
+                                          an.n_hidden_layers, store.grad_view(net.params), inv, d_attr=d_attr, attr_compact=attr_c,
+                                          channel=ch, loss_scale=ls, dh16=dh, accumulate=ch == 1)
         else:
-            dxaR = ops.mlp_bwd(XA, actR, dyR, store.half(model.raydrop_net.params), an.n_hidden_layers,
-                               store.grad_view(model.raydrop_net.params), inv, n_rows=count)
-            dxaI = ops.mlp_bwd(XA, actI, dyI, store.half(model.intensity_net.params), an.n_hidden_layers,
-                               store.grad_view(model.intensity_net.params), inv, n_rows=count)
-            ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad, n_enc, model.geo_feat_dim, dh)
+            dyR = torch.empty(P, 16, dtype=torch.float16, device=dev)
+            dyI = torch.empty(P, 16, dtype=torch.float16, device=dev)
+            ops.attr_scatter_bwd(idx, count, P, d_attr, attr_c, ls, dyR, dyI)
+            if ctx.gathered:  # rows in the forward's physical column order (three hidden layers)
+                dxaR = ops.attr_mlp_bwd(XA, count, n_enc, model.geo_feat_dim, actR, dyR, store.half(model.raydrop_net.params),
+                                        an.n_hidden_layers, store.grad_view(model.raydrop_net.params), inv)
+                dxaI = ops.attr_mlp_bwd(XA, count, n_enc, model.geo_feat_dim, actI, dyI, store.half(model.intensity_net.params),
+                                        an.n_hidden_layers, store.grad_view(model.intensity_net.params), inv)
+                ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad - 64, n_enc - 64, model.geo_feat_dim, dh, h_layout=True)
+            else:
+                dxaR = ops.mlp_bwd(XA, actR, dyR, store.half(model.raydrop_net.params), an.n_hidden_layers,
+                                   store.grad_view(model.raydrop_net.params), inv, n_rows=count)
+                dxaI = ops.mlp_bwd(XA, actI, dyI, store.half(model.intensity_net.params), an.n_hidden_layers,
+                                   store.grad_view(model.intensity_net.params), inv, n_rows=count)
+                ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad, n_enc, model.geo_feat_dim, dh)
         ops.sigma_bwd(h, d_sigma.view(-1), ls, dh)
         # sigma network
         dX = ops.mlp_bwd(X, act_s, dh, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,

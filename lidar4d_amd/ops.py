@@ -327,14 +327,19 @@ def attr_mlp_bwd_gathered_supported(n_hidden):
     return n_hidden <= 2
 
 
-def attr_mlp_bwd_gathered(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale):
-    """attr_mlp_bwd with the rows assembled in the kernel again (nothing stored by the forward).  -> dx_tail [cap, in_pad - 64]."""
+def attr_mlp_bwd_gathered(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale,
+                          d_attr=None, attr_compact=None, channel=0, loss_scale=1.0, dh16=None, accumulate=False):
+    """attr_mlp_bwd with the rows assembled in the kernel again (nothing stored by the forward).
+    dy16 given -> returns dx_tail [cap, in_pad - 64].  d_attr [P,2] / attr_compact [cap,2] / dh16 [P,16] given (dy16 None) ->
+    the sigmoid-scatter adjoint is derived in the kernel and the geo-feature gradient is stored in / added to dh16; returns None."""
     _chk(idx, torch.int32, "idx"), _chk(count, torch.int32, "count"), _chk(dir_enc16, torch.float16, "dir_enc")
     _chk(h16, torch.float16, "h"), _chk(act, torch.float16, "act"), _chk(dy16, torch.float16, "dy")
     _chk(weights16, torch.float16, "weights"), _chk(grad_w, torch.float32, "grad_w")
-    dx = torch.empty(cap, in_pad - 64, dtype=torch.float16, device=h16.device)
+    _chk(d_attr, torch.float32, "d_attr"), _chk(attr_compact, torch.float32, "attr_compact"), _chk(dh16, torch.float16, "dh")
+    dx = torch.empty(cap, in_pad - 64, dtype=torch.float16, device=h16.device) if d_attr is None else None
     call("l4d_attr_mlp_bwd_gathered", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad,
-         n_hidden, _p(act), _p(dy16), _p(weights16), _p(dx), _p(grad_w), float(inv_loss_scale), _stream())
+         n_hidden, _p(act), _p(dy16), _p(weights16), _p(dx), _p(grad_w), float(inv_loss_scale), _p(d_attr), _p(attr_compact),
+         int(channel), float(loss_scale), _p(dh16), int(bool(accumulate)), _stream())
     return dx
 
 

@@ -351,6 +351,24 @@ def test_attr_mlp_gathered_equals_materialised():
         dx2 = ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, n_geo, in_pad, act1, dy, w, n_hidden, g2, 1.0 / 128)
         assert torch.equal(dx1[:M], dx2[:M])
         assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max())
+        # ... and with the sigmoid-scatter adjoint in front / the sum + scatter into dh behind it inside the kernel:
+        # == l4d_attr_scatter_bwd -> two backward launches -> l4d_attr_gather_bwd, bit for bit
+        d_attr = det_uniform((P, 2), "gada", -1, 1).to(DEV)
+        dyR, dyI = torch.empty(P, 16, dtype=torch.float16, device=DEV), torch.empty(P, 16, dtype=torch.float16, device=DEV)
+        ops.attr_scatter_bwd(idx, count, P, d_attr, c1, 128.0, dyR, dyI)
+        gR, gI = torch.zeros(w.numel(), device=DEV), torch.zeros(w.numel(), device=DEV)
+        dR = ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, n_geo, in_pad, act1, dyR, w, n_hidden, gR, 1.0 / 128)
+        dI = ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, n_geo, in_pad, act1, dyI, w, n_hidden, gI, 1.0 / 128)
+        dh_ref = torch.zeros(P, 16, dtype=torch.float16, device=DEV)
+        ops.attr_gather_bwd(idx, count, P, dR, dI, in_pad - 64, denc.shape[1] - 64, n_geo, dh_ref, h_layout=True)
+        dh_epi = torch.zeros(P, 16, dtype=torch.float16, device=DEV)
+        gR2, gI2 = torch.zeros(w.numel(), device=DEV), torch.zeros(w.numel(), device=DEV)
+        for ch, gw in ((0, gR2), (1, gI2)):
+            assert ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, n_geo, in_pad, act1, None, w, n_hidden, gw, 1.0 / 128,
+                                             d_attr=d_attr, attr_compact=c1, channel=ch, loss_scale=128.0, dh16=dh_epi,
+                                             accumulate=ch == 1) is None
+        assert torch.equal(dh_epi, dh_ref) and float(dh_ref.abs().max()) > 0
+        assert float((gR - gR2).abs().max()) <= 1e-5 * float(gR.abs().max()) and float((gI - gI2).abs().max()) <= 1e-5 * float(gI.abs().max())
         near(dx0[:M, 64:72], dx1[:M, :8], "dx tile head"), near(dx0[:M, 72:87], dx1[:M, 9:24], "d geo")
         assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max()) and float(g0.abs().max()) > 0
         dh0, dh1 = torch.zeros(P, 16, dtype=torch.float16, device=DEV), torch.zeros(P, 16, dtype=torch.float16, device=DEV)
