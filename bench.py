@@ -266,6 +266,7 @@ def parse_args():
     ap.add_argument("--flow", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sort-rays", action="store_true", help="serve the random pixels of a batch in 8x8-pixel-block order (locality experiment; measured slower)")
     ap.add_argument("--urf", action="store_true", help="add the line-of-sight loss (runner.py:255-276, opt.urf_loss)")
+    ap.add_argument("--graph-staged", action="store_true", help="inference workloads: replay one captured hipGraph per chunk of the staged render (measured: no gain, a 4096-ray chunk is 3.4 ms of kernels)")
     ap.add_argument("--no-ema", action="store_true", help="no parameter EMA (the reference's default keeps one, --ema_decay 0.95, updated once per epoch)")
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the per-kernel timing pass (0: no roofline block)")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of each secondary measurement (0: skip them)")
@@ -342,6 +343,7 @@ def _run(args):
         from lidar4d_amd.data import KITTI360_FOV
         from lidar4d_amd.metrics import PointsMeter
         model.eval()
+        model.graph_staged = args.graph_staged  # the 32 chunks of a frame replay one captured hipGraph (renderer.py)
         meter = PointsMeter(scale=KITTI360_SCALE, intrinsics=KITTI360_FOV)
         frames = [data.frame((rank + world * k) % data.num_frames) for k in range(4)]  # resident before the timed region
         counter = [0]

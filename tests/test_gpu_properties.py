@@ -91,6 +91,25 @@ def test_render_invariants_full_size(big):
     assert idx.unique().numel() == cnt
     # staged (4 chunks of 4096 rays, renderer.py:159-177) == unstaged
     assert torch.equal(st["depth_lidar"], out["depth_lidar"]) and torch.equal(st["image_lidar"], out["image_lidar"])
+    # ... and == staged with the chunks replayed from one captured hipGraph (first chunk eager, second captured, the rest
+    # replayed); another frame reuses the graph (the time stays on the device); changed parameters drop it
+    model.graph_staged = True
+    try:
+        with torch.no_grad():
+            sg = model.render(b["rays_o_lidar"], b["rays_d_lidar"], b["time"], staged=True, max_ray_batch=4096, num_steps=T, perturb=False)
+            assert model._chunk_graph["key"] is not None
+            assert torch.equal(sg["depth_lidar"], out["depth_lidar"]) and torch.equal(sg["image_lidar"], out["image_lidar"])
+            b2 = data.batch_for(33)
+            ref2 = model.render(b2["rays_o_lidar"], b2["rays_d_lidar"], b2["time"], staged=False, num_steps=T, perturb=False)
+            sg2 = model.render(b2["rays_o_lidar"], b2["rays_d_lidar"], b2["time"], staged=True, max_ray_batch=4096, num_steps=T, perturb=False)
+            assert torch.equal(sg2["depth_lidar"], ref2["depth_lidar"]) and torch.equal(sg2["image_lidar"], ref2["image_lidar"])
+            key = model._chunk_graph["key"]
+            model.sigma_net.params.mul_(1.0)  # same values, new version: the fp16 copies will be rebuilt -> graph dropped
+            sg3 = model.render(b2["rays_o_lidar"], b2["rays_d_lidar"], b2["time"], staged=True, max_ray_batch=4096, num_steps=T, perturb=False)
+            assert model._chunk_graph["key"] != key
+            assert torch.equal(sg3["depth_lidar"], ref2["depth_lidar"]) and torch.equal(sg3["image_lidar"], ref2["image_lidar"])
+    finally:
+        model.graph_staged = False
 
 
 def test_backward_deterministic_and_finite(big):
