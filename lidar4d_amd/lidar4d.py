@@ -91,9 +91,11 @@ class LiDAR4D(LiDAR_Renderer):
             super().zero_grad(set_to_none=set_to_none)
 
     # -- fused path ------------------------------------------------------------------------------------------
-    def run(self, rays_o, rays_d, time, num_steps=768, perturb=False, noise=None, **kwargs):
+    def run(self, rays_o, rays_d, time, num_steps=768, perturb=False, noise=None, time_host=None, **kwargs):
         """renderer.py:44-140.  ``noise`` ([N, num_steps] in [0,1)) replaces the internal torch.rand when given
-        (parity tests feed the oracle's noise)."""
+        (parity tests feed the oracle's noise).  ``time_host``: the value of ``time`` as a python float when the caller
+        has it (the training loop does): spares the one device read-back of a training step -- the host-side copy of
+        hash_field.py:79-85's slice choice below, which would otherwise wait for the whole previous step to drain."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
@@ -112,7 +114,8 @@ class LiDAR4D(LiDAR_Renderer):
         self._host_slice_pair = None
         if train and self.reference_grad_none:  # hash_field.py:79-85 on the host, fp32 like the reference's tensor math
             n_slices = self.hash_encoder.hash_dynamic[0].time_resolution
-            idx = np.float32(float(time.reshape(-1)[0]) if torch.is_tensor(time) else float(time)) * np.float32(n_slices - 1)
+            t_host = time_host if time_host is not None else (float(time.reshape(-1)[0]) if torch.is_tensor(time) else float(time))
+            idx = np.float32(t_host) * np.float32(n_slices - 1)
             self._host_slice_pair = (int(np.floor(idx)), int(np.ceil(idx)))
         depth, image, wsum, weights, z_vals, idx, count = RenderFn.apply(self, rays_o, rays_d, t_dev, noise, num_steps,
                                                                         train, *params)

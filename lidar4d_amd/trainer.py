@@ -582,7 +582,7 @@ class Trainer:
         data = data if data is not None else self.dataset.batch()
         self.opt.zero_grad()
         out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
-                                num_steps=self.num_steps)
+                                num_steps=self.num_steps, time_host=data.get("time_host"))
         loss = self.compute_loss(data, out)
         (self.scaler.scale(loss) if self.scaler is not None else loss).backward()  # runner.py:506
         st = self.model._store
