@@ -792,6 +792,23 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// Workgroups of a backward launch: every wavefront ends with a flush of its whole dW (atomics on the same few thousand
+// addresses from every wavefront of the grid), so no more workgroups than fill the chip: one per CU where the accumulators
+// leave one wavefront per SIMD (everything but the narrowest single-hidden-layer networks), two otherwise.  Measured at C3
+// (256 CUs): 256 workgroups 5.57 ms of backward kernels, 512 5.69, 384 7.17 (a round and a half).  L4D_MLP_BWD_GRID overrides.
+static int bwd_grid_cap(int in_pad, int n_hidden) {
+  static int n_cu = 0, forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("L4D_MLP_BWD_GRID");
+    forced = (e && atoi(e) >= 64 && atoi(e) <= 4096) ? atoi(e) : 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+      n_cu = 256;
+  }
+  if (forced) return forced;
+  return (n_hidden >= 2 || in_pad >= 64) ? n_cu : 2 * n_cu;
+}
+
 static int grid_for(int64_t tiles) {
   int64_t blocks = (tiles + 3) / 4;
   if (blocks > 2048) blocks = 2048;  // 256 CUs x 8; waves grid-stride over the rest
@@ -847,7 +864,7 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (P == 0) return 0;
   const int in_tiles = in_pad / 16;
   int grid = grid_for((P + 31) / 32);
-  if (grid > 512) grid = 512;  // each wave flushes a full dW with atomics: keep the wave count bounded
+  if (grid > bwd_grid_cap(in_pad, n_hidden)) grid = bwd_grid_cap(in_pad, n_hidden);
   bool done = false;
   // act == null: the hidden activations are recomputed from x inside the kernel (narrow inputs only: the flow network)
 #define X(IT, NHH)                                                                                                   \
@@ -944,7 +961,7 @@ extern "C" int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_
   AttrSrc src;
   if (attr_src(nullptr, 1, nullptr, n_enc, nullptr, n_geo, in_pad, src, "l4d_attr_mlp_bwd: needs in_pad 96, 64 <= n_enc <= 80 (multiple of 8), n_geo = 15")) return 1;
   int grid = grid_for((cap + 31) / 32);
-  if (grid > 512) grid = 512;
+  if (grid > bwd_grid_cap(in_pad, n_hidden)) grid = bwd_grid_cap(in_pad, n_hidden);
   // the rows l4d_attr_mlp_fwd stored (physical column order: src.cperm permutes the weight columns)
 #define X(NHH)                                                                                                          \
   if (n_hidden == NHH)                                                                                                  \
@@ -982,7 +999,7 @@ extern "C" int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* coun
     return 1;
   }
   int grid = grid_for((cap + 31) / 32);
-  if (grid > 512) grid = 512;
+  if (grid > bwd_grid_cap(in_pad, n_hidden)) grid = bwd_grid_cap(in_pad, n_hidden);
   const AttrBwdEpi ae{d_attr, attr_compact, (half_t*)dh, channel, dh_accumulate, loss_scale};
 #define X(NHH)                                                                                                               \
   if (n_hidden == NHH) {                                                                                                     \
