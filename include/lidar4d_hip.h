@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define L4D_MAX_LEVELS 16
-#define L4D_ABI_VERSION 1
+#define L4D_ABI_VERSION 2
 
 /* Multi-resolution hash grid geometry (tiny-cuda-nn "HashGrid" encoding).
  * Filled by host code (lidar4d_amd/gridmeta.py) exactly as tiny-cuda-nn's host code derives it. */
@@ -54,6 +54,22 @@ const char* l4d_last_error(void);
 int l4d_profile_enable(int32_t on);
 int l4d_profile_count(void);
 int l4d_profile_get(int32_t i, const char** name /*host out*/, float* ms /*host out*/);
+
+/* Side streams.  Entry points that launch several independent kernels (l4d_density_encode_fwd / _bwd) fork them onto
+ * library-owned side streams of the launch stream and join them back before they return (event record + wait only: no host
+ * synchronisation, capturable into a hipGraph).  No reference counterpart (PyTorch runs the path on one stream).
+ *   l4d_streams_config(mask)  bit 0: forward encode (the xz / yz LDS evaluation next to the plane columns), bit 1: field
+ *                             adjoint (sorted scatter | time planes | static planes + dynamic hash).  Default 3
+ *                             (environment L4D_STREAMS overrides); 0 = everything on the launch stream.
+ *   l4d_streams_mask()        current setting
+ *   l4d_streams_join(stream)  `stream` waits for all outstanding side-stream work
+ *   l4d_side_fork(from, i) / l4d_side_join(into, i): side stream i (0..2) continues from the end of `from` and is returned
+ *                             (null on failure) / `into` waits for it -- for callers that overlap their own launches. */
+int l4d_streams_config(int32_t mask);
+int l4d_streams_mask(void);
+int l4d_streams_join(void* stream);
+void* l4d_side_fork(void* from, int32_t i);
+int l4d_side_join(void* into, int32_t i);
 
 /* ---- tcnn.Encoding(HashGrid) : model/hash_field.py:107-117, model/flow_field.py:67-77 -------
  * x        [P, x_stride] fp32; the grid's n_dims coordinates are columns cols[0..n_dims-1] (host)
@@ -276,13 +292,16 @@ int l4d_density_encode_fwd(const l4d_field_desc* f /*host*/, const float* xt, co
  * (= 1/loss_scale); dflow16 [P,16] fp16 stays in dX's scaled domain.  plane_abs_max: device fp32 = max |plane
  * parameter| (bounds the fixed-point LDS accumulators); samples_per_ray: T when the P rows are rays x T samples in
  * ray-major order (enables skipping whole wavefronts per plane band), 0 if unknown; workspace: l4d_density_encode_bwd_workspace() bytes of
- * device scratch.  Several launches: see lidar4d_amd/csrc/field_bwd.hip. */
+ * device scratch.  Several launches: see lidar4d_amd/csrc/field_bwd.hip.  With side streams enabled (l4d_streams_config bit 1)
+ * the independent parts run concurrently; dflow16 is always produced on `stream`.  defer_join = 1: return without joining the
+ * side streams -- the caller may queue the consumers of dflow16 on `stream` at once and must call l4d_streams_join(stream)
+ * before reading any parameter gradient or releasing `workspace`. */
 int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f /*host*/, int64_t P);
 int l4d_density_encode_bwd(const l4d_field_desc* f /*host*/, const l4d_field_grads* g /*host*/, const float* xt,
                            const void* flow16, const float* tinfo, int64_t P, const void* dX, int32_t in_pad,
                            float param_scale, const float* plane_abs_max, int32_t samples_per_ray, void* workspace,
                            void* dflow16, float* plane_rows /*null, or l4d_plane_rows_workspace() bytes: see the forward*/,
-                           void* stream);
+                           int32_t defer_join, void* stream);
 
 /* ---- chamfer_3DDist : utils/chamfer3D/chamfer3D.cu:11-194, dist_chamfer_3D.py:31-83 (SURVEY 8f "next" row 1) ----
  * xyz1 [b,n,3], xyz2 [b,m,3] fp32 -> dist1 [b,n], dist2 [b,m] (squared distance to the nearest point of the other

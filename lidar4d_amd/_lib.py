@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("L4D_LIB", os.path.join(_HERE, "liblidar4d_hip.so"))  
 L4D_MAX_LEVELS = 16
 L4D_MAX_TIME_SLICES = 8
 L4D_MAX_PLANE_SCALES = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GridDesc(C.Structure):
@@ -92,7 +92,7 @@ SIGNATURES = {
     "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P, P, P],
     "l4d_plane_rows_workspace": [FD],
     "l4d_density_encode_fwd_workspace": [FD, I64],
-    "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P, P],
+    "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P, I32, P],
     "l4d_density_encode_bwd_workspace": [FD, I64],
     "l4d_field_width": [FD],
     "l4d_dyn_pairs_build": [PP, I32, I64, P, P],
@@ -112,6 +112,11 @@ SIGNATURES = {
     "l4d_profile_enable": [I32],
     "l4d_profile_count": [],
     "l4d_profile_get": [I32, P, P],
+    "l4d_streams_config": [I32],
+    "l4d_streams_mask": [],
+    "l4d_streams_join": [P],
+    "l4d_side_fork": [P, I32],      # returns the side stream (void*)
+    "l4d_side_join": [P, I32],
 }
 
 _lib = None
@@ -138,7 +143,7 @@ def lib():
     for name, args in SIGNATURES.items():
         fn = getattr(l, name)
         fn.argtypes = args
-        fn.restype = C.c_int64 if name.endswith("_workspace") else C.c_int
+        fn.restype = C.c_int64 if name.endswith("_workspace") else (C.c_void_p if name == "l4d_side_fork" else C.c_int)
     _lib = l
     return l
 

@@ -58,3 +58,78 @@ extern "C" int l4d_profile_get(int i, const char** name, float* ms) {
   *name = g_prof[i].name;
   return 0;
 }
+
+// ---- side streams: independent kernels of one call run concurrently -----------------------------------------------------
+// A training step is a chain of kernels that each fill the chip but are bound by DIFFERENT resources (gather issue rate, VALU,
+// LDS atomics, HBM streaming), and many of them do not depend on each other: the hash part of the field encode does not need
+// the LDS evaluation of the xz / yz stacks until its last columns, the sorted scatter of the static grid does not need the
+// plane adjoints ...  Such kernels are forked onto side streams of the launch stream (event record + wait: capturable into a
+// hipGraph like any other stream dependency) and joined back before anything reads their results.
+//   l4d_streams_config(mask)   bit 0: field encode forward, bit 1: field adjoint (l4d_density_encode_bwd's defer_join leaves the
+//                              join to the caller, who overlaps the flow field's backward with the side streams)
+//   l4d_streams_join(stream)   the launch stream waits for everything outstanding on the side streams
+#include <stdlib.h>
+#define L4D_N_SIDE 3
+#define L4D_N_EVENTS 32
+static hipStream_t g_side[L4D_N_SIDE];
+static hipEvent_t g_events[L4D_N_EVENTS];
+static bool g_side_ready = false, g_side_busy[L4D_N_SIDE] = {false, false, false};
+static int g_event_next = 0, g_streams_mask = -1;
+
+extern "C" int l4d_streams_mask(void) {
+  if (g_streams_mask < 0) {
+    const char* e = getenv("L4D_STREAMS");
+    g_streams_mask = e ? atoi(e) : 3;
+  }
+  return g_streams_mask;
+}
+extern "C" int l4d_streams_config(int32_t mask) {
+  g_streams_mask = mask;
+  return 0;
+}
+static int side_init() {
+  if (g_side_ready) return 0;
+  for (int i = 0; i < L4D_N_SIDE; ++i) {
+    hipError_t e = hipStreamCreateWithFlags(&g_side[i], hipStreamNonBlocking);
+    if (e != hipSuccess) { l4d_set_error((int)e, "side stream"); return (int)e; }
+  }
+  for (int i = 0; i < L4D_N_EVENTS; ++i) {
+    hipError_t e = hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming);
+    if (e != hipSuccess) { l4d_set_error((int)e, "side event"); return (int)e; }
+  }
+  g_side_ready = true;
+  return 0;
+}
+static hipEvent_t next_event() {
+  hipEvent_t ev = g_events[g_event_next];
+  g_event_next = (g_event_next + 1) % L4D_N_EVENTS;
+  return ev;
+}
+// side stream i continues from the current end of `from` (main stream or another side stream); returns it (null on failure)
+extern "C" void* l4d_side_fork(void* from, int32_t i) {
+  if (i < 0 || i >= L4D_N_SIDE || side_init()) return nullptr;
+  hipEvent_t ev = next_event();
+  if (hipEventRecord(ev, (hipStream_t)from) != hipSuccess || hipStreamWaitEvent(g_side[i], ev, 0) != hipSuccess) {
+    l4d_set_error(1, "l4d_side_fork");
+    return nullptr;
+  }
+  g_side_busy[i] = true;
+  return (void*)g_side[i];
+}
+// `into` waits for side stream i
+extern "C" int l4d_side_join(void* into, int32_t i) {
+  if (i < 0 || i >= L4D_N_SIDE || !g_side_ready || !g_side_busy[i]) return 0;
+  hipEvent_t ev = next_event();
+  hipError_t e = hipEventRecord(ev, g_side[i]);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)into, ev, 0);
+  if (e != hipSuccess) { l4d_set_error((int)e, "l4d_side_join"); return (int)e; }
+  g_side_busy[i] = false;
+  return 0;
+}
+extern "C" int l4d_streams_join(void* stream) {
+  for (int i = 0; i < L4D_N_SIDE; ++i) {
+    int rc = l4d_side_join(stream, i);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -24,6 +24,10 @@ extern "C" void l4d_set_error(int code, const char* where);
 // Every kernel launch of the library goes through this macro: when profiling is switched on (l4d_profile_enable, used by
 // bench.py's per-kernel pass) a pair of HIP events is recorded around the launch ON THE LAUNCH STREAM, so the durations
 // bench.py reports are per KERNEL (same names as rocprofv3's kernel trace), also for entry points that launch several.
+// side streams (capi.cpp): l4d_side_fork(from, i) -> stream i continuing from `from`; l4d_side_join(into, i)
+extern "C" int l4d_streams_mask(void);
+extern "C" void* l4d_side_fork(void* from, int32_t i);
+extern "C" int l4d_side_join(void* into, int32_t i);
 extern "C" int l4d_prof_begin(const char* kernel, void* stream);
 extern "C" void l4d_prof_end(int idx, void* stream);
 #define L4D_LAUNCH(kernel, grid, block, lds, stream, ...)                    \

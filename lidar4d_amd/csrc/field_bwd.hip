@@ -570,9 +570,15 @@ extern "C" int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f, int
 extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_grads* g, const float* xt, const void* flow16,
                                       const float* tinfo, int64_t P, const void* dX, int32_t in_pad, float param_scale,
                                       const float* plane_abs_max, int32_t samples_per_ray, void* workspace, void* dflow16,
-                                      float* plane_rows, void* stream_) {
+                                      float* plane_rows, int32_t defer_join, void* stream_) {
   if (P == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
+  // Independent parts of the adjoint on side streams (l4d_streams_config bit 1): the sorted scatter of the static grid
+  // (HBM-streaming + LDS ranking) needs dX only; the static-plane and dynamic-hash adjoints (LDS atomics) need the prep
+  // kernel's outputs; the time planes (VALU-bound) stay on the launch stream -- they produce d(flow), which the caller's flow
+  // network backward waits for.  The kernels are bound by different units and share the chip instead of queueing.
+  const bool forked = (l4d_streams_mask() & 2) && P >= (1 << 18);
+  hipStream_t s_bins = stream, s_lds = stream;
   FieldDesc d;
   if (make_field(f, d)) return 1;
   FieldGrads fg;
@@ -593,6 +599,17 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   if (e == hipSuccess) e = hipMemcpyAsync(stats + ST_VMAX, plane_abs_max, sizeof(float), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
 
+  // static 3-D hash grid: sorted scatter of dX[:, 2*nS*8 + lvl*4 ..] (binscatter.hip)
+  {
+    if (forked) {
+      s_bins = (hipStream_t)l4d_side_fork(stream_, 1);
+      if (!s_bins) return 1;
+    }
+    const int cols3[3] = {0, 1, 2};
+    int rc = bs_scatter(d.hs, 3, 4, xt, P, 4, cols3, (const half_t*)dX, in_pad, 2 * d.planes.n_scales * 8, 1.0f, fg.hs_table,
+                        param_scale, ws + w.bins, s_bins);
+    if (rc) return rc;
+  }
   {
     const int colsA = 2 * d.planes.n_scales * 8, colD = colsA + d.hs.n_levels * 4;
     const int staged = (colD % 8 == 0 && L3 % 8 == 0) ? 1 : 0;  // 16-byte pieces
@@ -601,14 +618,11 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
                (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, staged, xsoa);
   }
 
-  // static 3-D hash grid: sorted scatter of dX[:, 2*nS*8 + lvl*4 ..] (binscatter.hip)
-  {
-    const int cols3[3] = {0, 1, 2};
-    int rc = bs_scatter(d.hs, 3, 4, xt, P, 4, cols3, (const half_t*)dX, in_pad, 2 * d.planes.n_scales * 8, 1.0f, fg.hs_table,
-                        param_scale, ws + w.bins, stream);
-    if (rc) return rc;
-  }
 
+  if (forked) {  // after the prep kernel
+    s_lds = (hipStream_t)l4d_side_fork(stream_, 2);
+    if (!s_lds) return 1;
+  }
   // chunking: one chunk per workgroup column; few enough chunks that the flush traffic stays small
   int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, 8192)));
   const int64_t chunk = ceil_div64(P, n_chunks);
@@ -656,7 +670,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
         }
       }
     (void)hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    L4D_LAUNCH(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, stream, d, t, fg.planes_cl, xsoa, P, chunk,
+    L4D_LAUNCH(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, s_lds, d, t, fg.planes_cl, xsoa, P, chunk,
                        wave_skip, gvs, param_scale, stats);
   }
   // dynamic hash
@@ -682,14 +696,19 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
     (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DYNHASH_LDS_KB * 1024);
-    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), DYNHASH_LDS_KB * 1024, stream, d, t, xsoa, P, chunk, gdynT, stats, Hbuf);
+    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), DYNHASH_LDS_KB * 1024, s_lds, d, t, xsoa, P, chunk, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);
-      L4D_LAUNCH(dynhash_expand_kernel, dim3((max_size + 255) / 256, d.hd[p].n_levels), dim3(256), 0, stream, d, fg, tinfo,
+      L4D_LAUNCH(dynhash_expand_kernel, dim3((max_size + 255) / 256, d.hd[p].n_levels), dim3(256), 0, s_lds, d, fg, tinfo,
                          Hbuf, p, hoff_plane[p], param_scale);
     }
   }
   L4D_LAUNCH_CHECK("l4d_density_encode_bwd");
+  if (forked && !defer_join) {
+    int rc = l4d_side_join(stream_, 1);
+    if (!rc) rc = l4d_side_join(stream_, 2);
+    if (rc) return rc;
+  }
   return 0;
 }

@@ -67,8 +67,16 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 #ifndef ENC_WAVES_PER_EU
 #define ENC_WAVES_PER_EU 2
 #endif
-template <bool USE_HDT, bool ROWS>
-__global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
+#define ENC_SPLIT_MIN_POINTS (1 << 18)  // below this the extra launch and the re-read of xt / flow cost more than the overlap buys
+#ifndef ENC_WAVES_PER_EU_HASH
+#define ENC_WAVES_PER_EU_HASH 4
+#endif
+// PART: 0 = the whole row in one kernel; 1 = the plane columns [0, 2 nS C) only; 2 = everything behind them (hash grids, ones).
+// The split (l4d_density_encode_fwd with side streams) exists for two reasons: the plane part does not need the xz / yz columns
+// that dynhash_fwd_lds_kernel produces, so the two run CONCURRENTLY (texel-bandwidth-bound next to VALU / LDS-bound), and the
+// hash part alone needs half the registers, i.e. twice the wavefronts to hide its L2-missing gathers behind.
+template <bool USE_HDT, bool ROWS, int PART = 0>
+__global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
                                                                         const float* __restrict__ tinfo, int64_t P,
                                                                         const half_t* __restrict__ hdT,
@@ -102,7 +110,7 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
   const int nS = fd.planes.n_scales;
 
   // ---- hex-planes (planes_field.py:87-141; blend lidar4d.py:175) ----
-  for (int s = 0; s < nS; ++s) {
+  for (int s = 0; PART != 2 && s < nS; ++s) {
     float ps[C], d0[C], d1[C], d2[C];
     planes_group<C>(fd, s, x0, false, ps);
     if (ROWS) {
@@ -129,9 +137,12 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
       if (grow < P) *reinterpret_cast<uint4*>(X + grow * in_pad + c0 + c * 8) = *reinterpret_cast<const uint4*>(wstage + r * ENC_PITCH + c * 8);
     }
   };
-  __syncthreads();
-  copy_out(0, colsA);
-  __syncthreads();
+  if (PART != 2) {
+    __syncthreads();
+    copy_out(0, colsA);
+    if (PART == 1) return;
+    __syncthreads();
+  }
   row -= colsA;  // the second part is staged from column 0 again
   int col = colsA;
 
@@ -431,6 +442,14 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     l4d_set_error(1, "l4d_density_encode_fwd: in_pad too small for the field width (or not a multiple of 8)");
     return 1;
   }
+  hipStream_t main_s = (hipStream_t)stream;
+  // side stream: the LDS evaluation of the xz / yz stacks runs next to the plane part of the encode (l4d_streams_config bit 0)
+  const bool split = hd_scratch && (l4d_streams_mask() & 1) && P >= ENC_SPLIT_MIN_POINTS;
+  hipStream_t dh_s = main_s;
+  if (split) {
+    dh_s = (hipStream_t)l4d_side_fork(stream, 0);
+    if (!dh_s) return 1;
+  }
   if (hd_scratch) {
     if (d.hd[1].size[d.hd[1].n_levels - 1] > DH_MAX_ENTRIES || d.hd[2].size[d.hd[2].n_levels - 1] > DH_MAX_ENTRIES) {
       l4d_set_error(1, "l4d_density_encode_fwd: xz/yz slice tables exceed the LDS staging size; pass hd_scratch = null");
@@ -442,23 +461,29 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     (void)hipFuncSetAttribute((const void*)dynhash_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DH_MAX_ENTRIES * 8);
     const int64_t n_dyn = d.hd[0].n_levels + d.hd[1].n_levels + d.hd[2].n_levels;
     float* coords9 = (float*)((char*)hd_scratch + (n_dyn * P * 2 + 255) / 256 * 256);
-    L4D_LAUNCH(warp_coords_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, xt, (const half_t*)flow16, P, coords9);
+    L4D_LAUNCH(warp_coords_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, dh_s, xt, (const half_t*)flow16, P, coords9);
     L4D_LAUNCH(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
-               2 * DH_MAX_ENTRIES * 8, (hipStream_t)stream, d, coords9, tinfo, P, chunk, (half_t*)hd_scratch);
+               2 * DH_MAX_ENTRIES * 8, dh_s, d, coords9, tinfo, P, chunk, (half_t*)hd_scratch);
   }
   const PlaneRows pr = make_plane_rows(d, plane_rows);
   if (plane_rows)  // tinfo[0..2] = t, t1, t2: frames without a neighbour get a row nobody reads
-    L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, (hipStream_t)stream, d, pr, tinfo, plane_rows);
+    L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, main_s, d, pr, tinfo, plane_rows);
   const dim3 egrid((unsigned)xcd_grid(ceil_div64(P, ENC_THREADS)));
   const int colsA = 2 * d.planes.n_scales * 8;
   const int enc_lds = ENC_THREADS * (std::max(colsA, in_pad - colsA) + 8) * 2;
-#define ENC_LAUNCH(HDT, ROWS)                                                                                               \
-  L4D_LAUNCH((density_encode_fwd_kernel<HDT, ROWS>), egrid, dim3(ENC_THREADS), enc_lds, (hipStream_t)stream, d, xt,         \
+#define ENC_LAUNCH(HDT, ROWS, PART)                                                                                         \
+  L4D_LAUNCH((density_encode_fwd_kernel<HDT, ROWS, PART>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,                \
              (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr)
-  if (hd_scratch && plane_rows) ENC_LAUNCH(true, true);
-  else if (hd_scratch) ENC_LAUNCH(true, false);
-  else if (plane_rows) ENC_LAUNCH(false, true);
-  else ENC_LAUNCH(false, false);
+  if (split) {  // plane columns while the side stream evaluates the xz / yz stacks, then the hash columns
+    if (plane_rows) ENC_LAUNCH(true, true, 1);
+    else ENC_LAUNCH(true, false, 1);
+    if (l4d_side_join(stream, 0)) return 1;
+    if (plane_rows) ENC_LAUNCH(true, true, 2);
+    else ENC_LAUNCH(true, false, 2);
+  } else if (hd_scratch && plane_rows) ENC_LAUNCH(true, true, 0);
+  else if (hd_scratch) ENC_LAUNCH(true, false, 0);
+  else if (plane_rows) ENC_LAUNCH(false, true, 0);
+  else ENC_LAUNCH(false, false, 0);
 #undef ENC_LAUNCH
   L4D_LAUNCH_CHECK("l4d_density_encode_fwd");
   return 0;

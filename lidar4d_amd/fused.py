@@ -150,6 +150,9 @@ class RenderFn(torch.autograd.Function):
 
         if train:
             ctx.model, ctx.T, ctx.sample_dist, ctx.gathered = model, T, sample_dist, gathered
+            # the slice pair of THIS forward (LiDAR4D.run sets it per call; a later forward -- gradient accumulation, a no-grad
+            # render -- must not change what this node's backward sees)
+            ctx.slice_pair = getattr(model, "_host_slice_pair", None)
             ctx.save_for_backward(t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count,
                                   XA, actR, actI, attr, attr_c, denc)
         ctx.mark_non_differentiable(z_vals, idx, count)
@@ -210,19 +213,31 @@ class RenderFn(torch.autograd.Function):
         gcl = torch.zeros(pe.layout.numel, dtype=torch.float32, device=dev)
         fd = _field_desc(model)
         vmax = pe._arena().abs().max().reshape(1)
-        dflow16 = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv, vmax, samples_per_ray=T)
-        # channel-last gradient arena -> added onto the planes' [1, C, H, W] gradient views, one launch
-        ops.planes_relayout(pe.layout, [store.grad_view(p).view(p.shape) for p in pe._flat_planes()], gcl, to_channel_last=False,
-                            accumulate=True)
-        # every gradient except the flow field's is final now: a data-parallel trainer starts reducing them here
         hook = getattr(model, "_grads_ready_hook", None)
-        if hook is not None:
-            hook()
+        # Side streams (csrc/capi.cpp): the static grid's sorted scatter and the static-plane / dynamic-hash adjoints run next to
+        # the time-plane adjoint, and -- single GPU: no reducer waiting for them -- also next to the flow field's backward below,
+        # which only needs d(flow).  A data-parallel trainer joins first: it starts reducing those gradients right away.
+        defer = hook is None and bool(ops.streams_mask() & 2)
+        res = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv, vmax, samples_per_ray=T, defer_join=defer)
+        dflow16, keep = res if defer else (res, None)
+
+        def planes_done():  # channel-last gradient arena -> added onto the planes' [1, C, H, W] gradient views, one launch
+            ops.planes_relayout(pe.layout, [store.grad_view(p).view(p.shape) for p in pe._flat_planes()], gcl, to_channel_last=False,
+                                accumulate=True)
+        if not defer:
+            planes_done()
+            # every gradient except the flow field's is final now: a data-parallel trainer starts reducing them here
+            if hook is not None:
+                hook()
         # flow network + grid
         fn = model.flow_net
         dxf = ops.mlp_bwd(xf, act_f, dflow16, _flow_w16(model), fn.n_hidden, _flow_wgrad(model), inv)
         ops.hashgrid_t_bwd(fn.grid_enc.meta, xt, (0, 1, 2), 1, t_dev, dxf, [store.grad_view(fn.grid_enc.params)], inv)
-        pair = getattr(model, "_host_slice_pair", None)
+        if defer:
+            ops.streams_join()  # the launch stream waits for the side streams: from here on every gradient is final in stream order
+            del keep
+            planes_done()
+        pair = ctx.slice_pair
         if pair is not None:  # reference semantics for a torch optimiser: untouched slices keep .grad = None (LiDAR4D.run)
             for hd in model.hash_encoder.hash_dynamic:
                 for s, enc in enumerate(hd.hash_t):

@@ -395,9 +395,11 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
 
 
 def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_scale, plane_abs_max, samples_per_ray=0,
-                       dflow16=None):
+                       dflow16=None, defer_join=False):
     """Adjoint of density_encode_fwd (several launches, lidar4d_amd/csrc/field_bwd.hip).  plane_abs_max: 1-element fp32
-    device tensor, max |plane parameter| (bound for the fixed-point LDS accumulators)."""
+    device tensor, max |plane parameter| (bound for the fixed-point LDS accumulators).
+    defer_join: return (dflow16, keepalive) with the library's side streams still running; the caller queues the consumers of
+    dflow16, then calls ``streams_join()`` and only then drops ``keepalive`` (the workspace the side streams write)."""
     _chk(dX, torch.float16, "dX"), _chk(plane_abs_max, torch.float32, "plane_abs_max")
     P, in_pad = dX.shape
     if dflow16 is None:
@@ -408,8 +410,32 @@ def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_sca
     if P >= PLANE_ROWS_MIN_POINTS:
         rows = torch.empty(_lib.lib().l4d_plane_rows_workspace(C.byref(field_desc)) // 4, dtype=torch.float32, device=dX.device)
     call("l4d_density_encode_bwd", C.byref(field_desc), C.byref(field_grads), _p(xt), _p(flow16), _p(tinfo), P, _p(dX),
-         in_pad, float(param_scale), _p(plane_abs_max), int(samples_per_ray), _p(ws), _p(dflow16), _p(rows), _stream())
+         in_pad, float(param_scale), _p(plane_abs_max), int(samples_per_ray), _p(ws), _p(dflow16), _p(rows), int(bool(defer_join)),
+         _stream())
+    if defer_join:
+        return dflow16, (ws, rows)
     return dflow16
+
+
+def streams_join():
+    """The current stream waits for everything outstanding on the library's side streams (l4d_streams_join)."""
+    call("l4d_streams_join", _stream())
+
+
+def side_fork(i):
+    """Library side stream i (0..2) as a torch stream that continues from the current stream's end (l4d_side_fork)."""
+    h = _lib.lib().l4d_side_fork(_stream(), int(i))
+    if not h:
+        raise _lib.HipExtensionError("l4d_side_fork failed: " + _lib.lib().l4d_last_error().decode())
+    return torch.cuda.ExternalStream(h)
+
+
+def side_join(i):
+    call("l4d_side_join", _stream(), int(i))
+
+
+def streams_mask():
+    return int(_lib.lib().l4d_streams_mask())
 
 
 # ---- optimiser / casts -------------------------------------------------------------------------------

@@ -114,7 +114,7 @@ class _MLPFn(torch.autograd.Function):
         P = x16.shape[0]
         s = mod.loss_scale
         dy16 = torch.zeros(P, 16, dtype=torch.float16, device=dy.device)
-        dy16[:, : mod.n_output_dims] = (dy.float() * s).clamp(-65504, 65504)
+        dy16[:, : mod.n_output_dims] = dy.float() * s  # not saturated: an overflow becomes inf and reaches the scaler (csrc/common.h f2h_grad)
         grad = torch.zeros_like(mod.params)
         dx16 = ops.mlp_bwd(x16, act, dy16, mod._half_params(), mod.n_hidden_layers, grad, 1.0 / s)
         dx = (dx16[:, : mod.n_input_dims].float() / s).to(ctx.x_dtype)

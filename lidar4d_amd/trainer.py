@@ -331,7 +331,7 @@ class FlatAdam:
         st = self.store
         lr = self.lr()
         self.step_count += 1
-        f16 = st.flat16 if st.flat16 is not None else st.refresh16()
+        f16 = st.refresh16()  # no-op while current; after load_state_dict / EMA copy_to the gated-off ranges would otherwise stay stale
         if self.steps.device != st.flat.device:
             self.steps = self.steps.to(st.flat.device)
         ops.adam_step_ranges(st.flat, st.flat_grad, self.exp_avg, self.exp_avg_sq, f16, self.ranges, lr, st.gates,

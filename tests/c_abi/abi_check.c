@@ -59,8 +59,13 @@ int main(void) {
       (fn_t)&l4d_sample_rays,
       (fn_t)&l4d_sample_rays_xt,
       (fn_t)&l4d_scaler_update,
+      (fn_t)&l4d_side_fork,
+      (fn_t)&l4d_side_join,
       (fn_t)&l4d_sigma_bwd,
       (fn_t)&l4d_sigma_from_h,
+      (fn_t)&l4d_streams_config,
+      (fn_t)&l4d_streams_join,
+      (fn_t)&l4d_streams_mask,
       (fn_t)&l4d_time_setup,
       (fn_t)&l4d_version,
   };

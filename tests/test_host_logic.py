@@ -387,7 +387,7 @@ def test_ctypes_signatures_match_header_prototypes():
     from lidar4d_amd import _lib
     header = open(os.path.join(ROOT, "include", "lidar4d_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
-    protos = dict(re.findall(r"\b(?:int|int64_t)\s+(l4d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S))
+    protos = dict(re.findall(r"\b(?:int|int64_t|void\s*\*)\s*(l4d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S))
 
     def kind(arg):
         arg = arg.strip()
