@@ -268,6 +268,7 @@ def parse_args():
     ap.add_argument("--urf", action="store_true", help="add the line-of-sight loss (runner.py:255-276, opt.urf_loss)")
     ap.add_argument("--graph-staged", action="store_true", help="inference workloads: replay one captured hipGraph per chunk of the staged render (measured: no gain, a 4096-ray chunk is 3.4 ms of kernels)")
     ap.add_argument("--no-ema", action="store_true", help="no parameter EMA (the reference's default keeps one, --ema_decay 0.95, updated once per epoch)")
+    ap.add_argument("--no-graph", action="store_true", help="training workloads: eager launches instead of one hipGraph replay per step (Trainer.train_step_graphed)")
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the per-kernel timing pass (0: no roofline block)")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of each secondary measurement (0: skip them)")
     ap.add_argument("--trained-steps", type=int, default=200, help="further training steps before the trained-state measurement")
@@ -356,15 +357,52 @@ def _run(args):
             meter.update(pred_depth, gt[..., 2] * gt[..., 0])
     else:
         step = trainer.train_step
+    step_mode = "eager launches"
 
     def barrier():
         if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not inference and not args.no_graph and os.environ.get("L4D_NO_GRAPH") != "1" and trainer.graphs_supported():
+        # One hipGraph per frame index, captured BEFORE the warm-up (a capture costs an eager step + the capture itself); the
+        # training state those steps changed is put back afterwards, so the timed region starts where the eager loop would.
+        opt, st = trainer.opt, model._store
+        keep = {"flat": st.flat.detach().clone(), "m": opt.exp_avg.clone(), "v": opt.exp_avg_sq.clone(), "steps": opt.steps.clone(),
+                "scaler": trainer.scaler.state.clone() if trainer.scaler is not None else None, "step_count": opt.step_count,
+                "local_step": trainer.local_step, "ema": (trainer.ema.shadow.clone(), trainer.ema.num_updates) if trainer.ema is not None else None}
+        try:
+            t0 = time.perf_counter()
+            for k in range(data.num_frames):
+                trainer.train_step_graphed(k)
+            torch.cuda.synchronize()
+            capture_s = time.perf_counter() - t0
+            from lidar4d_amd.params import bump_epoch
+            with torch.no_grad():
+                st.flat.copy_(keep["flat"]), opt.exp_avg.copy_(keep["m"]), opt.exp_avg_sq.copy_(keep["v"]), opt.steps.copy_(keep["steps"])
+                if keep["scaler"] is not None:
+                    trainer.scaler.state.copy_(keep["scaler"])
+                opt.sched.copy_(torch.tensor([float(keep["step_count"]), 1.0]))
+                if keep["ema"] is not None:
+                    trainer.ema.shadow.copy_(keep["ema"][0])
+                    trainer.ema.num_updates = keep["ema"][1]
+            opt.step_count, trainer.local_step = keep["step_count"], keep["local_step"]
+            bump_epoch()
+            st.refresh16()
+            step = trainer.train_step_graphed
+            step_mode = f"one hipGraph replay per step (a graph per frame index, {data.num_frames} captured in {capture_s:.1f} s before the warm-up; state restored)"
+        except Exception as e:  # the bench line must still be produced: fall back to eager launches
+            step_mode = "eager launches (graph capture failed: %s)" % repr(e)[:200]
+            sys.stderr.write("graph capture failed: %r\n" % (e,))
+        del keep
+    steps_before = int(trainer.opt.steps[0]) if not inference else 0
     for _ in range(args.warmup):
         step()
+    steps_mid = int(trainer.opt.steps[0]) if not inference else 0
     dt = timed(step, args.steps, barrier)
+    # GradScaler: steps the device skipped (non-finite gradients while the scale backs off) are cheaper than real ones
+    skipped = (args.steps - (int(trainer.opt.steps[0]) - steps_mid)) if not inference else None
+    skipped_warmup = (args.warmup - (steps_mid - steps_before)) if not inference else None
     if world > 1 or force_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -375,11 +413,17 @@ def _run(args):
     roofline, roofline_kernels, mfma, per_step = None, None, None, {}
     if args.profile_steps > 0:
         # every rank runs the extra steps (they contain the gradient all-reduce); only rank 0 records events
+        # eager launches (a graph replay does not pass the library's launch sites) with the side streams off: every kernel
+        # is timed alone on the chip, which is what its roofline fraction refers to
+        mask_was = ops.streams_mask()
+        _lib.lib().l4d_streams_config(0)
+        prof_step = step if inference else trainer.train_step
         if rank == 0:
             _lib.profile_start()
         for _ in range(args.profile_steps):
-            step()
+            prof_step()
         barrier()
+        _lib.lib().l4d_streams_config(mask_was)
     if rank == 0 and args.profile_steps > 0:
         kernels = {}
         for name, ms in _lib.profile_stop():
@@ -489,8 +533,8 @@ def _run(args):
         if use_chamfer or use_flow:
             trainer.chamfer = trainer.flow = False
             for _ in range(2):
-                step()
-            dtv = timed(step, args.variant_steps, barrier)
+                trainer.train_step()
+            dtv = timed(trainer.train_step, args.variant_steps, barrier)  # eager launches (the captured graphs hold the full step)
             variants["three_loss_step"] = {"step": "L1 depth + MSE raydrop + MSE intensity only (no ray chamfer, no scene-flow loss)", "steps": args.variant_steps,
                                            "ms_per_step": dtv / args.variant_steps * 1e3, "rays_per_s": n_rays * args.variant_steps / dtv}
             trainer.chamfer, trainer.flow = use_chamfer, use_flow
@@ -531,7 +575,9 @@ def _run(args):
                                f"the reference's training step (runner.py:166-253,474-551): forward + backward + GradScaler check/skip/update + Adam; losses {losses}; "
                                + ("no parameter EMA" if args.no_ema else "parameter EMA once per epoch of 51 steps (runner.py:534-535)"),
                        "state": "random init (tiny-cuda-nn default U(-1e-4, 1e-4) tables): every sample passes the weights > 1e-4 mask, the attribute networks run on all of them",
-                       "loss_scale_after_timed_region": scale_after},
+                       "loss_scale_after_timed_region": scale_after, "skipped_steps_in_timed_region": skipped,
+                       "skipped_steps_in_warmup": skipped_warmup, "step_mode": step_mode,
+                       "side_streams_mask": ops.streams_mask()},
             "roofline": roofline,
             "roofline_kernels": roofline_kernels,
             "mfma": mfma,

@@ -343,11 +343,15 @@ int l4d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  *   scaler  device fp32[4] or null: [0] loss scale, [1] growth tracker, [2] != 0 -> skip every range, [3] 1 / loss scale
  *           (multiplied into the gradient together with grad_scale)
  *   steps   device int32[n_ranges]: per-range step counts, incremented here for the ranges that are updated; the bias
- *           corrections 1 - beta^t are derived from them on the device. */
+ *           corrections 1 - beta^t are derived from them on the device.
+ *   sched   device fp32[2] or null: the reference's LambdaLR (main_lidar4d.py:303-305) on the device -- [0] iterations so
+ *           far (incremented here on every call, skipped step or not), [1] this step's factor 0.1 ** min([0] / sched_iters, 1),
+ *           multiplied into lr[r]; with it a captured step (hipGraph) has no argument that changes between replays. */
 int l4d_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16 /*or null*/,
                          int32_t n_ranges, const int64_t* off /*host*/, const int64_t* len /*host*/, const float* lr /*host*/,
                          const int32_t* gate_idx /*host, or null*/, const float* gates, const float* scaler, int32_t* steps,
-                         float beta1, float beta2, float eps, float grad_scale, void* stream);
+                         float beta1, float beta2, float eps, float grad_scale, float* sched, float sched_iters,
+                         void* stream);
 /* GradScaler pieces (torch.cuda.amp.GradScaler as the reference uses it, runner.py:102,506-508), device-resident state
  * scaler_state fp32[4] as above.  check: sets state[2] = 1 if any of grad[0..n) is inf / nan (call after the gradient
  * all-reduce, before the Adam step).  update: halve the scale after a non-finite step, multiply it by growth_factor after

@@ -15,6 +15,18 @@
 //           adds the segment to the fp32 gradient table with plain stores -- each segment has exactly one owner.
 //
 // Non-hashed (dense, coarse) levels fall back to run-reduced global atomics.
+//
+// PAIR RECORDS.  The coherent-prime hash leaves the first coordinate unmultiplied (index = x ^ y p1 ^ z p2, masked), so the
+// two x-neighbours of a cell sit in entries i and i ^ m with m = x ^ (x + 1) = 2^(tz + 1) - 1 (tz = trailing ones of x): in
+// the same bin whenever tz + 1 <= shift, i.e. all but 2^-shift of the time.  On the fine levels -- no two samples of a wave
+// share a cell, nothing to merge -- one record therefore carries BOTH: key word = [bin-local index : 13 | tz : 4 | fx : 15],
+// payload = w_yz * g (fp16); pass 2 adds payload * (1 - fx) to entry i and payload * fx to entry i ^ m.  Half the records, half
+// the bytes written and read back, half the ranking work; the weights lose nothing (fx to 2^-15, the payload is rounded to
+// fp16 once, as before).  tz code 15 = a single record (merged runs of the coarse levels; the rare pair that straddles two
+// bins is split: its second half goes to the table with a global atomic).
+#define BS_CODE_SINGLE 15u
+#define BS_KEY_BITS 13
+#define BS_FX_ONE 32767.0f
 #include <algorithm>
 #include <cstdlib>
 
@@ -38,6 +50,15 @@
 template <int NV>
 struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
 
+template <int NV>
+__device__ __forceinline__ void pack_payload(const float v[NV], uint32_t out[(NV + 1) / 2]) {
+#pragma unroll
+  for (int q = 0; q < (NV + 1) / 2; ++q) {
+    const half2_t h = {f2h_grad(v[2 * q]), 2 * q + 1 < NV ? f2h_grad(v[2 * q + 1]) : (half_t)0.0f};
+    out[q] = __builtin_bit_cast(uint32_t, h);
+  }
+}
+
 template <int D, int NV>
 __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
                                                               BsCols cols, const half_t* __restrict__ g, int g_stride, int g_col,
@@ -50,7 +71,9 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   // LDS atomics onto every counter
   constexpr int NWAVES = BS_THREADS / 64;
   __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
-  __shared__ __attribute__((aligned(16))) uint32_t stage[BS_THREADS * NC * NW];
+  // at most NC / 2 records per lane on average: NC / 2 pair records, or NC single records per run with <= 32 runs per wave
+  constexpr int RPL = NC / 2;
+  __shared__ __attribute__((aligned(16))) uint32_t stage[BS_THREADS * RPL * NW];
   __shared__ uint32_t total_s;
   // One workgroup walks ALL levels of its tile of samples.  (Earlier: one workgroup per (tile, level), ordered level-fast
   // and XCD-aware so that the levels of a tile at least met in one L2.  Every such workgroup started with a cold,
@@ -71,16 +94,22 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   // halfs): read level by level -- 2 to 8 bytes out of a 256-byte-strided row per level phase -- every level pulled its own
   // 64-byte sector across the fabric (PMC: 5.4 GB fetched for 0.8 GB of values).  The level loop is not unrolled, so the
   // level's dwords are picked by a uniform index into a register VECTOR (an indexed array would live in scratch).
-  constexpr int GW = 16;
-  const bool g_in_regs = n_lv * NV <= 2 * GW && (g_stride * 2) % 16 == 0 && (g_col * 2) % 16 == 0;  // block-uniform
+  // Held 8 dwords (32 bytes of the row) at a time: the next 32 bytes are fetched while the last level of the current ones is
+  // ranked.  (All 64 bytes up front cost 8 more registers for the whole kernel, which now sits at the 128-register limit of its
+  // four wavefronts per SIMD.)
+  constexpr int GW = 8;
+  const bool g_in_regs = n_lv * NV <= 32 && (g_stride * 2) % 16 == 0 && (g_col * 2) % 16 == 0;  // block-uniform
   typedef uint32_t GwVec __attribute__((ext_vector_type(GW)));  // a vector, so that a uniform index becomes relative VGPR addressing
   GwVec gw;
+  auto gw_load = [&](int chunk) {  // dwords 8 chunk .. 8 chunk + 7 of the row's gradient columns
 #pragma unroll
-  for (int q = 0; q < GW / 4; ++q) {
-    uint4 u = make_uint4(0, 0, 0, 0);
-    if (g_in_regs && q * 8 < n_lv * NV) u = *reinterpret_cast<const uint4*>(grow + q * 8);
-    gw[4 * q + 0] = u.x; gw[4 * q + 1] = u.y; gw[4 * q + 2] = u.z; gw[4 * q + 3] = u.w;
-  }
+    for (int q = 0; q < GW / 4; ++q) {
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (g_in_regs && (chunk * 2 + q) * 8 < n_lv * NV) u = *reinterpret_cast<const uint4*>(grow + (chunk * 2 + q) * 8);
+      gw[4 * q + 0] = u.x; gw[4 * q + 1] = u.y; gw[4 * q + 2] = u.z; gw[4 * q + 3] = u.w;
+    }
+  };
+  gw_load(0);
   auto gw_pick = [&](int k) -> uint32_t { return gw[k & (GW - 1)]; };
   half_t gnext[NV];
   if (!g_in_regs) {
@@ -101,6 +130,9 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
     const half_t* hw = reinterpret_cast<const half_t*>(w);
 #pragma unroll
     for (int j = 0; j < NV; ++j) gnext[j] = hw[j];
+    // first dword of the next level (NV = 1: two levels per dword); at a 32-byte boundary the held dwords are all consumed
+    const int k_next = NV == 1 ? (lvl + 1) >> 1 : (lvl + 1) * (NV / 2);
+    if (lvl + 1 < n_lv && k_next % GW == 0 && (NV > 1 || ((lvl + 1) & 1) == 0)) gw_load(k_next / GW);
   }
   float gv[NV];
   bool any = false;
@@ -141,8 +173,50 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
     // key = running id that changes exactly where the cell changes (lanes without a gradient carry zeros: harmless)
     const unsigned long long brk = __ballot(!same);
     runs = row_runs((uint32_t)__popcll(brk & (~0ull >> (63 - lane))), &n_heads);
-    use_scan = n_heads <= 56;  // wave-uniform: otherwise there is nothing worth merging
+    use_scan = n_heads <= 32;  // wave-uniform: merged runs emit single records, at most NC per run = NC / 2 per lane
   }
+  const bool pairs = binned && !use_scan;  // wave-uniform
+  uint32_t fxq = 0u;  // keys[] carry the record's tz code in bits 24..27 from here on (entries per level <= 2^24: checked by the host side)
+  if (pairs) {
+    // one record per x-neighbour pair (corners 2q, 2q + 1): slots 0 .. NC/2 - 1 are used, the rest stay silent
+    fxq = (uint32_t)__float2int_rn(c.frac[0] * BS_FX_ONE);
+    const float fx = (float)fxq * (1.0f / BS_FX_ONE);
+#pragma unroll
+    for (int q = 0; q < NC / 2; ++q) {
+      uint32_t g0[D], g1[D];
+      const float w0 = corner<D>(c, 2 * q, g0);
+      (void)corner<D>(c, 2 * q + 1, g1);
+      float wyz = 1.0f;  // weight without the x factor
+#pragma unroll
+      for (int d = 1; d < D; ++d) wyz *= ((2 * q) >> d) & 1 ? c.frac[d] : 1.0f - c.frac[d];
+      (void)w0;
+      const uint32_t k0 = grid_index<D>(g0, desc.res[lvl], size, true), k1 = grid_index<D>(g1, desc.res[lvl], size, true);
+      const uint32_t m = k0 ^ k1;
+      const bool paired = (m & (m + 1u)) == 0u && m != 0u && (m >> shift) == 0u && __popc(m) <= (int)BS_CODE_SINGLE;
+      keys[q] = k0 | ((uint32_t)(__popc(m) - 1) << 24);
+      float* v = vals[q];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = wyz * gv[j];
+      bool nz = false;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) nz |= v[j] != 0.0f;
+      emit[q] = any && nz;
+      if (emit[q] && !paired) {  // straddles two bins (2^-shift of the pairs): this record keeps (1 - fx), the neighbour goes direct
+        float* o = out + ((size_t)desc.offset[lvl] + k1) * NV;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          if (v[j] != 0.0f) atomicAdd(o + j, v[j] * fx * out_scale);
+          v[j] *= 1.0f - fx;
+        }
+        keys[q] = k0 | (BS_CODE_SINGLE << 24);
+      }
+    }
+#pragma unroll
+    for (int q = NC / 2; q < NC; ++q) {
+      emit[q] = false;
+      keys[q] = 0u;
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     uint32_t gg[D];
@@ -165,6 +239,8 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
       for (int j = 0; j < NV; ++j) nz |= vals[k][j] != 0.0f;
       emit[k] = nz;
     }
+    if (binned) keys[k] |= BS_CODE_SINGLE << 24;
+  }
   }
   if (!binned) {  // dense / tiny level: run-reduced atomics straight into the output (block-uniform branch)
     float* o = out + (size_t)desc.offset[lvl] * NV;
@@ -183,7 +259,7 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   // rank inside the workgroup
   const int wave_id = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[wave_id][keys[k] >> shift], 1u) : 0u;
+  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[wave_id][(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   __syncthreads();
   if (threadIdx.x < BS_MAX_BINS) {  // exclusive prefix over the waves of each bin; hist[0][b] <- bin total
     uint32_t run = 0;
@@ -230,18 +306,18 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
 #pragma unroll
   for (int k = 0; k < NC; ++k)
     if (emit[k]) {
-      const uint32_t b = keys[k] >> shift;
+      const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
       const uint32_t r = boff[b] + hist[wave_id][b] + pos[k];
-      stage[r * NW] = keys[k];
-      half_t hv[2 * (NW - 1)];
+      const uint32_t code = keys[k] >> 24;
+      stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));
+      uint32_t pay[NW - 1];
+      pack_payload<NV>(vals[k], pay);
 #pragma unroll
-      for (int j = 0; j < 2 * (NW - 1); ++j) hv[j] = j < NV ? f2h_grad(vals[k][j]) : (half_t)0.0f;
-#pragma unroll
-      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = reinterpret_cast<uint32_t*>(hv)[q];
+      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = pay[q];
     }
   __syncthreads();
   const uint32_t total = total_s;
-  uint32_t* dst = bins + wg_slot * (uint64_t)(BS_THREADS * NC * NW);
+  uint32_t* dst = bins + wg_slot * (uint64_t)(BS_THREADS * RPL * NW);
   // already sorted by bin; 16 bytes per lane (the slot is 16-byte aligned and large enough for the rounded-up tail)
   const uint32_t n16 = (total * NW + 3) >> 2;
   for (uint32_t q = threadIdx.x; q < n16; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
@@ -275,12 +351,20 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   // then its records): small groups = many independent chains in flight, which is what hides that latency
   constexpr int NGRP = 1024 / BS_GROUP;
   const int grp = threadIdx.x / BS_GROUP, l16 = threadIdx.x % BS_GROUP;
-  auto add = [&](uint32_t key, const uint32_t* wd) {
+  auto add = [&](uint32_t w0, const uint32_t* wd) {  // w0: record key word (see PAIR RECORDS above)
     const half_t* hv = reinterpret_cast<const half_t*>(wd);
+    const uint32_t local = w0 & ((1u << BS_KEY_BITS) - 1u), code = (w0 >> BS_KEY_BITS) & 15u;
+    const bool single = code == BS_CODE_SINGLE;
+    const float f1 = single ? 0.0f : (float)(w0 >> (BS_KEY_BITS + 4)) * (1.0f / BS_FX_ONE);
+    const float s0 = (1.0f - f1) * fxs, s1 = f1 * fxs;
+    const uint32_t other = local ^ ((2u << code) - 1u);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const float v = h2f(hv[j]);
-      if (v != 0.0f) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(key - lo) * NV + j]), (unsigned long long)__float2ll_rn(v * fxs));
+      if (v != 0.0f) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[local * NV + j]), (unsigned long long)__float2ll_rn(v * s0));
+        if (!single) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[other * NV + j]), (unsigned long long)__float2ll_rn(v * s1));
+      }
     }
   };
   // BS_UNROLL runs (pass-1 workgroups) per group and iteration: their offset loads, and then the first record of each, are
@@ -295,13 +379,13 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
       const uint16_t* o = offs + slot * (BS_MAX_BINS + 1);
       s0[u] = o[b];
       s1[u] = w < n_wg ? (uint32_t)o[b + 1] : s0[u];  // past the end: an empty run
-      rec[u] = bins + slot * (uint64_t)(BS_THREADS * NC * NW);
+      rec[u] = bins + slot * (uint64_t)(BS_THREADS * (NC / 2) * NW);
     }
     uint32_t key0[BS_UNROLL], wd0[BS_UNROLL][NW - 1];
 #pragma unroll
     for (int u = 0; u < BS_UNROLL; ++u) {
       const uint32_t r = s0[u] + l16;
-      key0[u] = lo;
+      key0[u] = BS_CODE_SINGLE << BS_KEY_BITS;
 #pragma unroll
       for (int q = 0; q < NW - 1; ++q) wd0[u][q] = 0u;
       if (r < s1[u]) {
@@ -336,7 +420,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
 // histogram atomics.  L4D_BS_SHIFT4 / L4D_BS_SHIFT2 override (tuning).
 static int bs_shift(int NV) {
   const char* e = getenv(NV == 4 ? "L4D_BS_SHIFT4" : NV == 2 ? "L4D_BS_SHIFT2" : "L4D_BS_SHIFT1");
-  if (e && atoi(e) >= 9 && atoi(e) <= 13) return atoi(e);
+  if (e && atoi(e) >= 9 && atoi(e) <= BS_KEY_BITS) return atoi(e);
   return NV == 4 ? 11 : NV == 2 ? 12 : 13;
 }
 
@@ -345,7 +429,7 @@ BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
   pl.shift = bs_shift(NV);
   pl.rec_words = 1 + (NV + 1) / 2;
   pl.n_wg = ceil_div64(P, BS_THREADS);
-  const int64_t rec_per_wg = (int64_t)BS_THREADS << n_dims;
+  const int64_t rec_per_wg = (int64_t)BS_THREADS << (n_dims - 1);  // NC / 2 records per lane (pair records, bin_pass1_kernel)
   pl.off_max = 0;
   pl.off_offs = 256;
   pl.off_bins = (pl.off_offs + (int64_t)d.n_levels * pl.n_wg * (BS_MAX_BINS + 1) * 2 + 255) / 256 * 256;
@@ -365,6 +449,8 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   if (e != hipSuccess) { l4d_set_error((int)e, "bs_scatter memset"); return (int)e; }
   BsCols c;
   for (int d = 0; d < 3; ++d) c.c[d] = d < n_dims ? cols[d] : 0;
+  for (int l = 0; l < desc.n_levels; ++l)
+    if (desc.size[l] > (1u << 24)) { l4d_set_error(1, "bs_scatter: more than 2^24 entries per level"); return 1; }
   int max_bins = 1;
   for (int l = 0; l < desc.n_levels; ++l) max_bins = std::max<int>(max_bins, (int)(((int64_t)desc.size[l] + (1 << pl.shift) - 1) >> pl.shift));
   max_bins = std::min(max_bins, BS_MAX_BINS);

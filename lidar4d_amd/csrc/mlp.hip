@@ -806,6 +806,14 @@ static int bwd_grid_cap(int in_pad, int n_hidden) {
       n_cu = 256;
   }
   if (forced) return forced;
+  if (in_pad <= 32) {  // the 16-/32-wide (flow) network: small accumulators; L4D_MLP_BWD_GRID_NARROW = workgroups per CU (tuning)
+    static int narrow = -1;
+    if (narrow < 0) {
+      const char* e = getenv("L4D_MLP_BWD_GRID_NARROW");
+      narrow = (e && atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0;
+    }
+    if (narrow) return narrow * n_cu;
+  }
   return (n_hidden >= 2 || in_pad >= 64) ? n_cu : 2 * n_cu;
 }
 

@@ -82,17 +82,25 @@ __device__ __forceinline__ bool range_on(const AdamRanges& R, int r, const float
   return R.gate[r] < 0 || gates[R.gate[r]] != 0.0f;
 }
 
+// sched (optional, 2 floats on the device): [0] scheduler iterations so far, [1] the learning-rate factor of THIS step.  The
+// reference steps a LambdaLR every iteration, skipped or not (main_lidar4d.py:303-305: 0.1 ** min(it / iters, 1)); with the
+// schedule on the device a captured step (hipGraph) needs no kernel argument that changes from replay to replay.
 __global__ void adam_advance_kernel(AdamRanges R, const float* __restrict__ gates, const float* __restrict__ scaler,
-                                    int32_t* __restrict__ steps) {
+                                    int32_t* __restrict__ steps, float* __restrict__ sched, float sched_iters) {
   const int r = threadIdx.x;
   if (r < R.n && range_on(R, r, gates, scaler)) steps[r] += 1;
+  if (r == 0 && sched) {
+    const double it = (double)sched[0];
+    sched[1] = (float)pow(0.1, fmin(it / (double)sched_iters, 1.0));
+    sched[0] = (float)(it + 1.0);
+  }
 }
 
 __global__ void __launch_bounds__(256) adam_ranges_kernel(AdamRanges R, float* __restrict__ param, const float* __restrict__ grad,
                                                          float* __restrict__ m, float* __restrict__ v, half_t* __restrict__ p16,
                                                          const float* __restrict__ gates, const float* __restrict__ scaler,
                                                          const int32_t* __restrict__ steps, float b1, float b2, float eps,
-                                                         float grad_scale) {
+                                                         float grad_scale, const float* __restrict__ sched) {
   const int r = blockIdx.y;
   const int64_t n = R.len[r];
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -101,7 +109,8 @@ __global__ void __launch_bounds__(256) adam_ranges_kernel(AdamRanges R, float* _
   __shared__ float s_step, s_rs2;
   if (threadIdx.x == 0) {  // bias corrections as torch computes them (python doubles), from the range's own step count
     const double t = (double)steps[r];
-    s_step = (float)((double)R.lr[r] / (1.0 - pow((double)b1, t)));
+    const double lr = (double)R.lr[r] * (sched ? (double)sched[1] : 1.0);
+    s_step = (float)(lr / (1.0 - pow((double)b1, t)));
     s_rs2 = (float)sqrt(1.0 - pow((double)b2, t));
   }
   __syncthreads();
@@ -183,7 +192,8 @@ __global__ void mark_slices_kernel(const float* __restrict__ tinfo, int n_slices
 extern "C" int l4d_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16,
                                     int32_t n_ranges, const int64_t* off, const int64_t* len, const float* lr,
                                     const int32_t* gate_idx, const float* gates, const float* scaler, int32_t* steps,
-                                    float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                                    float beta1, float beta2, float eps, float grad_scale, float* sched, float sched_iters,
+                                    void* stream) {
   if (n_ranges == 0) return 0;
   if (n_ranges > ADAM_MAX_RANGES) { l4d_set_error(1, "l4d_adam_step_ranges: too many ranges"); return 1; }
   AdamRanges R;
@@ -201,10 +211,10 @@ extern "C" int l4d_adam_step_ranges(float* param, const float* grad, float* exp_
     return 1;
   }
   if (max_len == 0) return 0;
-  L4D_LAUNCH(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, R, gates, scaler, steps);
+  L4D_LAUNCH(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, R, gates, scaler, steps, sched, sched_iters);
   L4D_LAUNCH(adam_ranges_kernel, dim3((unsigned)ceil_div64(ceil_div64(max_len, 4), 256), n_ranges), dim3(256), 0,
                      (hipStream_t)stream, R, param, grad, exp_avg, exp_avg_sq, (half_t*)param_f16, gates, scaler, steps, beta1,
-                     beta2, eps, grad_scale);
+                     beta2, eps, grad_scale, (const float*)sched);
   L4D_LAUNCH_CHECK("l4d_adam_step_ranges");
   return 0;
 }

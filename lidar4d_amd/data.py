@@ -125,11 +125,18 @@ class SyntheticKitti360:
             self.images.append(img.to(device))
         self.poses = torch.stack(self.poses)
         self.images = torch.stack(self.images)
+        # frame times resident on the device: building the [1, 1] tensor per batch is a pageable host-to-device copy, which
+        # a captured training step (hipGraph, Trainer.train_step_graphed) cannot contain
+        self.times = torch.tensor([[k / (num_frames - 1)] for k in range(num_frames)], dtype=torch.float32, device=device).view(num_frames, 1, 1)
+
+    def next_frame(self):
+        """The frame of the next training step (host-side draw: no device sync)."""
+        return int(torch.randint(0, self.num_frames, [1], generator=self.frame_gen))
 
     def batch(self, frame=None):
         """Dict with the reference's keys for one training step (random frame unless given)."""
         if frame is None:
-            frame = int(torch.randint(0, self.num_frames, [1], generator=self.frame_gen))
+            frame = self.next_frame()
         return self.batch_for(frame)
 
     def frame(self, frame, W=None):
@@ -152,7 +159,7 @@ class SyntheticKitti360:
                               sort_pixels=self.sort_pixels and self.patch_size_lidar == 1)
         inds = rays["inds"]
         images = torch.gather(self.images[frame].view(1, -1, 3), 1, inds[..., None].expand(-1, -1, 3))
-        t = torch.tensor([[frame / (self.num_frames - 1)]], dtype=torch.float32, device=self.device)
+        t = self.times[frame]
         return {"rays_o_lidar": rays["rays_o"], "rays_d_lidar": rays["rays_d"], "time": t, "images_lidar": images,
                 "poses_lidar": pose, "H_lidar": self.H, "W_lidar": self.W, "index": [frame],
                 "time_host": frame / (self.num_frames - 1)}  # the same number on the host: no read-back for host-side decisions

@@ -4,6 +4,7 @@ Every wrapper checks device / dtype / contiguity, allocates nothing it was not a
 on the current torch stream.  Tensors must live on a HIP device: there is no CPU fallback.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -196,6 +197,8 @@ def mlp_recompute_supported(in_pad, n_hidden):
     them: narrow inputs (the flow network: 32-byte rows against 256 B of activations; measured forward 1.11 -> 0.33 ms,
     backward 1.64 -> 1.41 ms at 12.6 M rows).  For the 128-wide sigma network the same trade was measured neutral (forward
     0.91 -> 0.67 ms, backward 1.93 -> 2.13 ms) and wider / deeper shapes spill registers, so those keep their activations."""
+    if os.environ.get("L4D_MLP_STORE_ACT") == "1":  # tuning: store the activations after all
+        return False
     return in_pad <= 32 and 1 <= n_hidden <= 3
 
 
@@ -468,8 +471,10 @@ class AdamRanges:
 
 
 def adam_step_ranges(param, grad, exp_avg, exp_avg_sq, param16, ranges, lr, gates, scaler_state, steps, beta1, beta2, eps,
-                     grad_scale=1.0):
-    """One launch over all ranges; per-range step counters / gates / the scaler's skip flag live on the device."""
+                     grad_scale=1.0, sched=None, sched_iters=1.0):
+    """One launch over all ranges; per-range step counters / gates / the scaler's skip flag live on the device.
+    sched: device fp32[2] = [iterations so far, this step's factor]: the learning-rate schedule 0.1 ** min(it / sched_iters, 1)
+    evaluated on the device and multiplied into ``lr`` (pass the base rate then); None: ``lr`` is used as given."""
     for nm, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         _chk(t, torch.float32, nm)
     _chk(param16, torch.float16, "param16"), _chk(gates, torch.float32, "gates"), _chk(scaler_state, torch.float32, "scaler")
@@ -477,7 +482,7 @@ def adam_step_ranges(param, grad, exp_avg, exp_avg_sq, param16, ranges, lr, gate
     lrs = (C.c_float * ranges.n)(*[lr * m for m in ranges.lr_mults])
     call("l4d_adam_step_ranges", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param16), ranges.n, ranges._off,
          ranges._len, C.cast(lrs, C.c_void_p), ranges._gate, _p(gates), _p(scaler_state), _p(steps), float(beta1), float(beta2),
-         float(eps), float(grad_scale), _stream())
+         float(eps), float(grad_scale), _p(sched), float(sched_iters), _stream())
 
 
 def grad_nonfinite_check(grad, scaler_state):

@@ -259,6 +259,15 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(self.store.flat)
         self._build_ranges()
         self.steps = torch.zeros(self.ranges.n, dtype=torch.int32, device=self.store.flat.device)
+        self.sched = None  # device_schedule(): [iterations so far, this step's lr factor] on the device
+
+    def device_schedule(self):
+        """Evaluate the learning-rate schedule on the device from now on (l4d_adam_step_ranges ``sched``): the Adam launch then
+        has no argument that changes from step to step, which is what lets a whole training step be captured into a hipGraph
+        and replayed (Trainer.train_step_graphed).  ``step_count`` keeps counting on the host (checkpoints, logging)."""
+        if self.sched is None:
+            self.sched = torch.tensor([float(self.step_count), 1.0], dtype=torch.float32, device=self.store.flat.device)
+        return self.sched
 
     def _build_ranges(self):
         import re
@@ -334,9 +343,11 @@ class FlatAdam:
         f16 = st.refresh16()  # no-op while current; after load_state_dict / EMA copy_to the gated-off ranges would otherwise stay stale
         if self.steps.device != st.flat.device:
             self.steps = self.steps.to(st.flat.device)
+        if self.sched is not None:
+            lr = self.lr0  # the factor 0.1 ** min(it / iters, 1) is applied on the device
         ops.adam_step_ranges(st.flat, st.flat_grad, self.exp_avg, self.exp_avg_sq, f16, self.ranges, lr, st.gates,
                              None if scaler is None else scaler.state, self.steps, self.betas[0], self.betas[1], self.eps,
-                             grad_scale)
+                             grad_scale, sched=self.sched, sched_iters=float(self.iters))
         bump_epoch()          # parameters changed behind torch's version counters ...
         st.mark16_current()   # ... and the fp16 copies were refreshed by the same kernel
         self.model.planes_encoder._cl_key = None  # channel-last plane copy must be rebuilt
@@ -580,6 +591,55 @@ class Trainer:
 
     def train_step(self, data=None):
         data = data if data is not None else self.dataset.batch()
+        loss = self._step_device_work(data)
+        self._step_host_bookkeeping()
+        return loss
+
+    def _step_host_bookkeeping(self):
+        self.local_step += 1
+        if self.local_step % self.epoch_steps == 0:
+            self.end_epoch()
+
+    # -- the same step as ONE hipGraph per frame -------------------------------------------------------------------------
+    def graphs_supported(self):
+        """A step can be captured when nothing in it needs the host: single rank (the RCCL all-reduce is issued by torch's
+        process group), a dataset that draws its batch on the device (``batch_for`` + ``register`` of its generator), no
+        patch / line-of-sight terms with host-side schedules."""
+        return (self.reducer is None and not self.urf and hasattr(self.dataset, "batch_for") and hasattr(self.dataset, "next_frame")
+                and getattr(self.dataset, "patch_size_lidar", 1) == 1 and self.model._store.flat.is_cuda)
+
+    def train_step_graphed(self, frame=None):
+        """train_step as the replay of a hipGraph captured per frame index (the scene-flow loss walks that frame's point clouds, so
+        the launch sequence depends on the frame and on nothing else): batch draw (device RNG), forward, losses, backward,
+        GradScaler check / skip / update, Adam with the learning-rate schedule on the device -- about 630 launches per step
+        become one.  The first call for a frame runs one eager step (refreshes every host-side cache) and captures the next."""
+        if not self.graphs_supported():
+            raise RuntimeError("Trainer.train_step_graphed: this configuration needs the host inside a step (see graphs_supported)")
+        if frame is None:
+            frame = self.dataset.next_frame()
+        st = self.__dict__.setdefault("_step_graphs", {"pool": None, "graphs": {}})
+        self.opt.device_schedule()
+        rec = st["graphs"].get(frame)
+        if rec is None:
+            loss = self._step_device_work(self.dataset.batch_for(frame))  # eager: leaves every cache in its steady state
+            self.opt.step_count -= 1  # (the capture below is not executed: it must not count as an iteration on the host)
+            graph = torch.cuda.CUDAGraph()
+            gen = getattr(self.dataset, "gen", None)
+            if gen is not None and hasattr(graph, "register_generator_state"):
+                graph.register_generator_state(gen)
+            with torch.cuda.graph(graph, pool=st["pool"]):
+                loss_g = self._step_device_work(self.dataset.batch_for(frame))
+            if st["pool"] is None:
+                st["pool"] = graph.pool()
+            st["graphs"][frame] = {"graph": graph, "loss": loss_g}
+            self._step_host_bookkeeping()
+            return loss
+        rec["graph"].replay()
+        self.opt.step_count += 1
+        self._step_host_bookkeeping()
+        return rec["loss"]
+
+    def _step_device_work(self, data):
         self.opt.zero_grad()
         out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
                                 num_steps=self.num_steps, time_host=data.get("time_host"))
@@ -595,9 +655,6 @@ class Trainer:
         self.opt.step(scaler=self.scaler)        # runner.py:507 (skipped on the device if a gradient was non-finite)
         if self.scaler is not None:
             self.scaler.update()                 # runner.py:508
-        self.local_step += 1
-        if self.local_step % self.epoch_steps == 0:
-            self.end_epoch()
         return loss
 
     def end_epoch(self):

@@ -250,3 +250,81 @@ def test_ema_updates_once_per_epoch():
         tr.train_step(b)
     assert tr.ema.num_updates == 2
     assert Trainer(make(), data, num_steps=32, chamfer=False, flow=False, ema_decay=0.95).epoch_steps == data.num_frames
+
+
+def test_flow_loss_overflow_is_skipped_not_clipped():
+    """with the scene-flow loss on, an overflowing loss scale must reach the flow field's gradients as inf / nan
+    through ``model.flow()`` (flow_field.py backward no longer clamps to +-65504) so that the step is skipped and the scale
+    backs off -- not clipped silently while the scale keeps growing."""
+    from lidar4d_amd.trainer import Trainer
+    cfg, data, make = _setup(num_rays=128)
+    m = make()
+    tr = Trainer(m, data, num_steps=64, iters=100, chamfer=False, flow=True, init_scale=2.0 ** 40)
+    init = m._store.flat.clone()
+    scales = []
+    for it in range(6):
+        loss = tr.train_step(data.batch_for(20))
+        assert np.isfinite(float(loss))
+        scales.append(tr.scaler.get_scale())
+    assert scales == [2.0 ** (39 - i) for i in range(6)], scales   # every step overflowed and halved the scale
+    assert torch.equal(m._store.flat, init) and int(tr.opt.steps.max()) == 0
+    # the flow field's own gradient is what overflows here, not only the render path: loss = flow loss alone
+    tr.opt.zero_grad()
+    from lidar4d_amd.trainer import flow_loss
+    fl = flow_loss(m, tr.pc_list, tr.pc_ground_list, data.batch_for(20)["time"], data.num_frames, frame_idx=20)
+    (fl * 2.0 ** 40).backward()
+    g = m.flow_net.grid_enc.params.grad
+    assert not bool(torch.isfinite(g).all()), "an overflowing flow-loss gradient must surface as inf / nan, not as a clipped number"
+
+
+def test_graphed_step_replays_the_training_step():
+    """Trainer.train_step_graphed: one hipGraph per frame index holding the whole step (batch draw, forward, losses, backward,
+    scaler, Adam with the learning-rate schedule on the device).  Replays must keep training (parameters move, losses stay
+    finite), draw NEW rays every replay (device RNG state is part of the graph), advance the device-side schedule exactly like
+    the host-side LambdaLR, and leave the same kind of state an eager loop leaves."""
+    from lidar4d_amd.trainer import Trainer
+    cfg, data, make = _setup(num_rays=128)
+    m = make()
+    tr = Trainer(m, data, num_steps=64, iters=50, chamfer=True, flow=True, init_scale=2.0 ** 10)
+    assert tr.graphs_supported()
+    losses = []
+    for it in range(12):
+        frame = (20, 21)[it % 2]
+        before = m._store.flat.clone()
+        loss = tr.train_step_graphed(frame)
+        losses.append(float(loss))
+        assert np.isfinite(losses[-1])
+        assert not torch.equal(m._store.flat, before), f"step {it} did not move the parameters"
+    assert len(tr._step_graphs["graphs"]) == 2
+    # replays of the same frame's graph see different batches: the loss values differ from replay to replay
+    assert len({round(v, 9) for v in losses[2::2]}) > 1
+    assert tr.opt.step_count == 12
+    sched = tr.opt.sched.tolist()
+    assert sched[0] == 12.0
+    assert abs(sched[1] - 0.1 ** (11 / 50)) < 1e-6  # factor of the LAST step = 0.1 ** min(11 / iters, 1)
+    assert int(tr.opt.steps.max()) == 12  # no step was skipped at this scale
+    # an eager step still works afterwards (shared device state, host-side caches consistent)
+    before = m._store.flat.clone()
+    assert np.isfinite(float(tr.train_step(data.batch_for(22))))
+    assert not torch.equal(m._store.flat, before) and tr.opt.sched.tolist()[0] == 13.0
+
+
+def test_device_schedule_matches_host_schedule():
+    """FlatAdam with the schedule on the device (l4d_adam_step_ranges sched) against the host-computed learning rate: same
+    parameters after a few steps (one fp32 rounding of the rate apart)."""
+    from lidar4d_amd.trainer import Trainer
+    cfg, data, make = _setup(num_rays=128)
+    ma, mb = make(), make()
+    ta = Trainer(ma, data, num_steps=32, iters=10, chamfer=False, flow=False, init_scale=1.0)
+    tb = Trainer(mb, data, num_steps=32, iters=10, chamfer=False, flow=False, init_scale=1.0)
+    tb.opt.device_schedule()
+    torch.manual_seed(5)
+    batches = [data.batch_for(10 + k) for k in range(4)]
+    for b in batches:
+        torch.manual_seed(7)
+        ta.train_step(b)
+        torch.manual_seed(7)
+        tb.train_step(b)
+    d = (ma._store.flat - mb._store.flat).abs().max()
+    moved = (ma._store.flat - make()._store.flat.to(DEV)).abs().max()
+    assert float(moved) > 1e-4 and float(d) <= 1e-6 * max(1.0, float(ma._store.flat.abs().max())), (float(d), float(moved))
