@@ -346,7 +346,12 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   const int n_el = (int)min(1u << shift, size - lo) * NV;
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) acc[i] = 0;
   __syncthreads();
-  const float fxs = fx_scale((float)P * gmax * 1.01f, 61);
+  // Fixed point: every contribution is |v| <= gmax, scaled to 30 bits and converted with ONE v_cvt_i32_f32 (a float -> int64
+  // conversion is a dozen instructions on this ISA, eight of them per record: pass 2 was bound by exactly that), then
+  // sign-extended into the 64-bit accumulator -- 2^33 contributions per entry before it could overflow, quantisation 2^-26 of
+  // the level's largest gradient (the payload itself carries 11 bits).
+  // (a merged run of a coarse level sums up to 16 lanes of one DPP row: 16 gmax bounds every record)
+  const float fxs = fx_scale(gmax * 16.5f, 30);
   // groups of BS_GROUP lanes, one pass-1 workgroup's run each.  Every run costs a dependent pair of loads (its offsets,
   // then its records): small groups = many independent chains in flight, which is what hides that latency
   constexpr int NGRP = 1024 / BS_GROUP;
@@ -362,8 +367,8 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
     for (int j = 0; j < NV; ++j) {
       const float v = h2f(hv[j]);
       if (v != 0.0f) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[local * NV + j]), (unsigned long long)__float2ll_rn(v * s0));
-        if (!single) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[other * NV + j]), (unsigned long long)__float2ll_rn(v * s1));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[local * NV + j]), (unsigned long long)(long long)__float2int_rn(v * s0));
+        if (!single) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[other * NV + j]), (unsigned long long)(long long)__float2int_rn(v * s1));
       }
     }
   };

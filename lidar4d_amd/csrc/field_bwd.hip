@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
   }
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) lds_l[i] = 0;
   __syncthreads();
-  const float fxs = fx_scale((float)chunk * gmax * 1.01f, 61);
+  const float fxs = fx_scale(gmax * 1.01f, 30);  // per contribution 30 bits -> one v_cvt_i32_f32, sign-extended (binscatter.hip, pass 2)
   const int ca = plane == 2 ? 1 : 0, cb = plane == 0 ? 1 : 2;
   const float scale = g.scale[lvl];
   const uint32_t res = g.res[lvl], size = g.size[lvl];
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
       uint32_t gv[2];
       const float w = corner<2>(c, k, gv);
       const int idx = (int)grid_index<2>(gv, res, size, hashed) - lo;
-      if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)__float2ll_rn(go * w * fxs));
+      if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)(long long)__float2int_rn(go * w * fxs));
     }
   }
   __syncthreads();

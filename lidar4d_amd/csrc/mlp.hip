@@ -1009,9 +1009,19 @@ extern "C" int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* coun
   int grid = grid_for((cap + 31) / 32);
   if (grid > bwd_grid_cap(in_pad, n_hidden)) grid = bwd_grid_cap(in_pad, n_hidden);
   const AttrBwdEpi ae{d_attr, attr_compact, (half_t*)dh, channel, dh_accumulate, loss_scale};
+  // act == null: the hidden activations are recomputed from the assembled rows (the forward then stores nothing but its
+  // sigmoid outputs: 256 B per row and network less to write there and to read here, for 20 more MFMAs per 16 rows)
+  if (!act && !epi) {
+    l4d_set_error(1, "l4d_attr_mlp_bwd_gathered: act == null (recompute) is only built for the (d_attr, attr_compact, dh) form");
+    return 1;
+  }
 #define X(NHH)                                                                                                               \
   if (n_hidden == NHH) {                                                                                                     \
-    if (epi)                                                                                                                 \
+    if (epi && !act)                                                                                                         \
+      L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, true, true, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,   \
+                 (const half_t*)nullptr, (const half_t*)nullptr, (const half_t*)nullptr, cap, count, (const half_t*)weights, \
+                 (half_t*)nullptr, grad_w, inv_loss_scale, src, ae);                                                         \
+    else if (epi)                                                                                                            \
       L4D_LAUNCH((mlp_bwd_kernel<6, NHH, 0, 6, true, false, true, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,  \
                  (const half_t*)nullptr, (const half_t*)act, (const half_t*)nullptr, cap, count, (const half_t*)weights,     \
                  (half_t*)nullptr, grad_w, inv_loss_scale, src, ae);                                                         \

@@ -137,10 +137,11 @@ class RenderFn(torch.autograd.Function):
             # epilogue (lidar4d.py:210-219)
             keep_rows = train and not ops.attr_mlp_bwd_gathered_supported(an.n_hidden_layers)
             XA = torch.empty(P, an.in_pad, dtype=torch.float16, device=dev) if keep_rows else None
+            keep_act = train and (keep_rows or not ops.attr_mlp_recompute_supported(an.n_hidden_layers))  # else recomputed in the backward
             _, actR = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.raydrop_net.params),
-                                       an.n_hidden_layers, save_act=train, x_rows_out=XA, attr_dense=attr, attr_compact=attr_c, channel=0)
+                                       an.n_hidden_layers, save_act=keep_act, x_rows_out=XA, attr_dense=attr, attr_compact=attr_c, channel=0)
             _, actI = ops.attr_mlp_fwd(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.intensity_net.params),
-                                       an.n_hidden_layers, save_act=train, attr_dense=attr, attr_compact=attr_c, channel=1)
+                                       an.n_hidden_layers, save_act=keep_act, attr_dense=attr, attr_compact=attr_c, channel=1)
         else:
             XA = ops.attr_gather(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad)
             yR, actR = ops.mlp_fwd(XA, store.half(model.raydrop_net.params), an.n_hidden_layers, save_act=train, n_rows=count)

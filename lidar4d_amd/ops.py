@@ -330,6 +330,12 @@ def attr_mlp_bwd_gathered_supported(n_hidden):
     return n_hidden <= 2
 
 
+def attr_mlp_recompute_supported(n_hidden):
+    """Shapes for which l4d_attr_mlp_bwd_gathered recomputes the hidden activations (act = None): the forward then stores
+    nothing but the sigmoid outputs.  L4D_ATTR_RECOMP=0 switches it off (A/B)."""
+    return n_hidden <= 2 and os.environ.get("L4D_ATTR_RECOMP", "1") != "0"
+
+
 def attr_mlp_bwd_gathered(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale,
                           d_attr=None, attr_compact=None, channel=0, loss_scale=1.0, dh16=None, accumulate=False):
     """attr_mlp_bwd with the rows assembled in the kernel again (nothing stored by the forward).

@@ -619,21 +619,48 @@ class Trainer:
             frame = self.dataset.next_frame()
         st = self.__dict__.setdefault("_step_graphs", {"pool": None, "graphs": {}})
         self.opt.device_schedule()
+        # L4D_GRAPH_BATCH=outside: the batch is drawn by eager launches into static buffers before every replay (debugging aid;
+        # default: the draw is part of the graph, the dataset's device generator is registered with it)
+        outside = os.environ.get("L4D_GRAPH_BATCH", "inside") == "outside"
         rec = st["graphs"].get(frame)
         if rec is None:
-            loss = self._step_device_work(self.dataset.batch_for(frame))  # eager: leaves every cache in its steady state
-            self.opt.step_count -= 1  # (the capture below is not executed: it must not count as an iteration on the host)
-            graph = torch.cuda.CUDAGraph()
-            gen = getattr(self.dataset, "gen", None)
-            if gen is not None and hasattr(graph, "register_generator_state"):
-                graph.register_generator_state(gen)
-            with torch.cuda.graph(graph, pool=st["pool"]):
-                loss_g = self._step_device_work(self.dataset.batch_for(frame))
+            from . import _lib
+            # side streams stay out of a capture (L4D_GRAPH_STREAMS=1 keeps them): cross-stream capture buys ~0.2 ms of overlap
+            # that the replay's missing launch gaps return several times over
+            mask_was = ops.streams_mask()
+            if os.environ.get("L4D_GRAPH_STREAMS") != "1":
+                _lib.lib().l4d_streams_config(0)
+            try:
+                static = None
+                if outside:
+                    static = {k: (v.contiguous().clone() if torch.is_tensor(v) else v) for k, v in self.dataset.batch_for(frame).items()}
+                draw = (lambda: static) if outside else (lambda: self.dataset.batch_for(frame))
+                # torch's capture recipe: the warm-up step runs on the (non-default) stream the capture will use, and nothing of
+                # its autograd graph survives it -- an AccumulateGrad node that was created on the legacy default stream and is
+                # still alive makes the captured backward synchronise with that stream, which a capture cannot contain
+                side = st.setdefault("stream", torch.cuda.Stream())
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    loss = self._step_device_work(draw()).detach()  # eager: leaves every cache in its steady state
+                torch.cuda.current_stream().wait_stream(side)
+                self.opt.step_count -= 1  # (the capture below is not executed: it must not count as an iteration on the host)
+                graph = torch.cuda.CUDAGraph()
+                gen = getattr(self.dataset, "gen", None)
+                if not outside and gen is not None and hasattr(graph, "register_generator_state"):
+                    graph.register_generator_state(gen)
+                with torch.cuda.graph(graph, pool=st["pool"], stream=side):
+                    loss_g = self._step_device_work(draw()).detach()
+            finally:
+                _lib.lib().l4d_streams_config(mask_was)
             if st["pool"] is None:
                 st["pool"] = graph.pool()
-            st["graphs"][frame] = {"graph": graph, "loss": loss_g}
+            st["graphs"][frame] = {"graph": graph, "loss": loss_g, "static": static}
             self._step_host_bookkeeping()
             return loss
+        if rec["static"] is not None:
+            for k, v in self.dataset.batch_for(frame).items():
+                if torch.is_tensor(v):
+                    rec["static"][k].copy_(v)
         rec["graph"].replay()
         self.opt.step_count += 1
         self._step_host_bookkeeping()
