@@ -268,7 +268,8 @@ def parse_args():
     ap.add_argument("--urf", action="store_true", help="add the line-of-sight loss (runner.py:255-276, opt.urf_loss)")
     ap.add_argument("--graph-staged", action="store_true", help="inference workloads: replay one captured hipGraph per chunk of the staged render (measured: no gain, a 4096-ray chunk is 3.4 ms of kernels)")
     ap.add_argument("--no-ema", action="store_true", help="no parameter EMA (the reference's default keeps one, --ema_decay 0.95, updated once per epoch)")
-    ap.add_argument("--no-graph", action="store_true", help="training workloads: eager launches instead of one hipGraph replay per step (Trainer.train_step_graphed)")
+    ap.add_argument("--graph", action="store_true", help="training workloads: one hipGraph replay per step (Trainer.train_step_graphed) instead of eager launches")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # the default
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the per-kernel timing pass (0: no roofline block)")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of each secondary measurement (0: skip them)")
     ap.add_argument("--trained-steps", type=int, default=200, help="further training steps before the trained-state measurement")
@@ -364,7 +365,7 @@ def _run(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    if not inference and not args.no_graph and os.environ.get("L4D_NO_GRAPH") != "1" and trainer.graphs_supported():
+    if not inference and args.graph and not args.no_graph and trainer.graphs_supported():
         # One hipGraph per frame index, captured BEFORE the warm-up (a capture costs an eager step + the capture itself); the
         # training state those steps changed is put back afterwards, so the timed region starts where the eager loop would.
         opt, st = trainer.opt, model._store

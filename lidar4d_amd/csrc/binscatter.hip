@@ -22,11 +22,14 @@
 // share a cell, nothing to merge -- one record therefore carries BOTH: key word = [bin-local index : 13 | tz : 4 | fx : 15],
 // payload = w_yz * g (fp16); pass 2 adds payload * (1 - fx) to entry i and payload * fx to entry i ^ m.  Half the records, half
 // the bytes written and read back, half the ranking work; the weights lose nothing (fx to 2^-15, the payload is rounded to
-// fp16 once, as before).  tz code 15 = a single record (merged runs of the coarse levels; the rare pair that straddles two
-// bins is split: its second half goes to the table with a global atomic).
+// fp16 once, as before).  tz code 15 = a single record: merged runs of the coarse levels, and the two halves of the rare pair
+// that straddles two bins (tz + 1 > shift: one lane in 2^shift) -- a workgroup's slot has BS_SLACK records of room for those;
+// records beyond it (a ray that runs exactly perpendicular to x through such a cell: all its samples straddle) fall back to
+// global atomics, which costs bit-reproducibility for that one launch and nothing else.
 #define BS_CODE_SINGLE 15u
 #define BS_KEY_BITS 13
 #define BS_FX_ONE 32767.0f
+#define BS_SLACK 64  // records (a multiple of 4: slots stay 16-byte aligned for every record width)
 #include <algorithm>
 #include <cstdlib>
 
@@ -73,7 +76,8 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
   // at most NC / 2 records per lane on average: NC / 2 pair records, or NC single records per run with <= 32 runs per wave
   constexpr int RPL = NC / 2;
-  __shared__ __attribute__((aligned(16))) uint32_t stage[BS_THREADS * RPL * NW];
+  constexpr uint32_t CAP = BS_THREADS * RPL + BS_SLACK;  // records per (workgroup, level) slot
+  __shared__ __attribute__((aligned(16))) uint32_t stage[CAP * NW];
   __shared__ uint32_t total_s;
   // One workgroup walks ALL levels of its tile of samples.  (Earlier: one workgroup per (tile, level), ordered level-fast
   // and XCD-aware so that the levels of a tile at least met in one L2.  Every such workgroup started with a cold,
@@ -201,20 +205,16 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
 #pragma unroll
       for (int j = 0; j < NV; ++j) nz |= v[j] != 0.0f;
       emit[q] = any && nz;
-      if (emit[q] && !paired) {  // straddles two bins (2^-shift of the pairs): this record keeps (1 - fx), the neighbour goes direct
-        float* o = out + ((size_t)desc.offset[lvl] + k1) * NV;
+      // straddles two bins (2^-shift of the pairs): two single records, the neighbour's in the otherwise unused slot q + NC/2
+      const bool split = emit[q] && !paired;
+      emit[q + NC / 2] = split;
+      keys[q + NC / 2] = k1 | (BS_CODE_SINGLE << 24);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          if (v[j] != 0.0f) atomicAdd(o + j, v[j] * fx * out_scale);
-          v[j] *= 1.0f - fx;
-        }
-        keys[q] = k0 | (BS_CODE_SINGLE << 24);
+      for (int j = 0; j < NV; ++j) {
+        vals[q + NC / 2][j] = v[j] * fx;
+        if (split) v[j] *= 1.0f - fx;
       }
-    }
-#pragma unroll
-    for (int q = NC / 2; q < NC; ++q) {
-      emit[q] = false;
-      keys[q] = 0u;
+      if (split) keys[q] = k0 | (BS_CODE_SINGLE << 24);
     }
   } else {
 #pragma unroll
@@ -287,19 +287,24 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
       const uint32_t a = __shfl_up(inc, d, 64);
       if (lane >= d) inc += a;
     }
-    uint16_t* o = offs + wg_slot * (BS_MAX_BINS + 1);
+    // Bin offsets are stored TRANSPOSED, offs[level][bin][workgroup]: pass 2 walks one bin over all workgroups, and read from
+    // a [workgroup][bin] table every run cost it a 64-byte sector for two 2-byte numbers -- as many fabric requests as the run's
+    // records themselves.  The 2-byte stores below land in lines that the neighbouring tiles (same XCD, dispatched together:
+    // xcd_tile) complete within the same L2.
+    const uint32_t nwg32 = (uint32_t)n_wg;  // (levels x bins x workgroups < 2^32: checked by the host side)
+    uint16_t* o = offs + (uint64_t)lvl * (BS_MAX_BINS + 1) * n_wg + tile;
     uint32_t excl = inc - sum;
 #pragma unroll
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
       boff[b] = excl;
-      o[b] = (uint16_t)excl;
+      if (b <= nbins) o[(uint32_t)b * nwg32] = (uint16_t)min(excl, CAP);  // records past the slot's capacity are not staged (they go to the table directly)
       excl += c[q];
     }
     if (lane == 63) {
-      total_s = inc;
+      total_s = min(inc, CAP);
       boff[BS_MAX_BINS] = inc;
-      o[BS_MAX_BINS] = (uint16_t)inc;
+      if (nbins == BS_MAX_BINS) o[(uint32_t)BS_MAX_BINS * nwg32] = (uint16_t)min(inc, CAP);
     }
   }
   __syncthreads();
@@ -309,15 +314,28 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
       const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
       const uint32_t r = boff[b] + hist[wave_id][b] + pos[k];
       const uint32_t code = keys[k] >> 24;
-      stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));
-      uint32_t pay[NW - 1];
-      pack_payload<NV>(vals[k], pay);
+      if (r < CAP) {
+        stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));
+        uint32_t pay[NW - 1];
+        pack_payload<NV>(vals[k], pay);
 #pragma unroll
-      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = pay[q];
+        for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = pay[q];
+      } else {  // slot full (see BS_SLACK): straight into the table.  Only single records can be in excess of RPL per lane.
+        const float f1 = code == BS_CODE_SINGLE ? 0.0f : (float)fxq * (1.0f / BS_FX_ONE);
+        float* o = out + (size_t)desc.offset[lvl] * NV;
+        const uint32_t e0 = keys[k] & 0xFFFFFFu, e1 = e0 ^ ((2u << (code & 15u)) - 1u);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const float v = h2f(f2h_grad(vals[k][j]));
+          if (v == 0.0f) continue;
+          atomicAdd(o + (size_t)e0 * NV + j, v * (1.0f - f1) * out_scale);
+          if (code != BS_CODE_SINGLE) atomicAdd(o + (size_t)e1 * NV + j, v * f1 * out_scale);
+        }
+      }
     }
   __syncthreads();
   const uint32_t total = total_s;
-  uint32_t* dst = bins + wg_slot * (uint64_t)(BS_THREADS * RPL * NW);
+  uint32_t* dst = bins + wg_slot * (uint64_t)(CAP * NW);
   // already sorted by bin; 16 bytes per lane (the slot is 16-byte aligned and large enough for the rounded-up tail)
   const uint32_t n16 = (total * NW + 3) >> 2;
   for (uint32_t q = threadIdx.x; q < n16; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
@@ -372,42 +390,25 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
       }
     }
   };
-  // BS_UNROLL runs (pass-1 workgroups) per group and iteration: their offset loads, and then the first record of each, are
-  // in flight together -- the walk is a chain of dependent loads (offsets -> records) and is bound by their latency
-  for (int w0 = grp; w0 < n_wg; w0 += NGRP * BS_UNROLL) {
-    uint32_t s0[BS_UNROLL], s1[BS_UNROLL];
-    const uint32_t* rec[BS_UNROLL];
+  // The runs of this bin, one per pass-1 workgroup, consecutive groups take consecutive workgroups: their offsets
+  // offs[level][bin][w], offs[level][bin + 1][w] are two dense arrays (fetched one iteration ahead), so the only scattered
+  // accesses left are the records themselves.
+  const uint16_t* o0 = offs + ((uint64_t)lvl * (BS_MAX_BINS + 1) + b) * n_wg;
+  const uint16_t* o1 = o0 + n_wg;
+  constexpr uint64_t SLOT = (uint64_t)(BS_THREADS * (NC / 2) + BS_SLACK) * NW;
+  const uint32_t* lvl_bins = bins + (uint64_t)lvl * n_wg * SLOT;
+  uint32_t s0n = 0, s1n = 0;
+  if (grp < n_wg) { s0n = o0[grp]; s1n = o1[grp]; }
+  for (int w = grp; w < n_wg; w += NGRP) {
+    const uint32_t s0 = s0n, s1 = s1n;
+    const int wn = w + NGRP;
+    if (wn < n_wg) { s0n = o0[wn]; s1n = o1[wn]; }
+    const uint32_t* rec = lvl_bins + (uint64_t)w * SLOT;
+    for (uint32_t r = s0 + l16; r < s1; r += BS_GROUP) {
+      uint32_t wd[NW - 1];
 #pragma unroll
-    for (int u = 0; u < BS_UNROLL; ++u) {
-      const int w = w0 + u * NGRP;
-      const uint64_t slot = (uint64_t)lvl * n_wg + (w < n_wg ? w : w0);
-      const uint16_t* o = offs + slot * (BS_MAX_BINS + 1);
-      s0[u] = o[b];
-      s1[u] = w < n_wg ? (uint32_t)o[b + 1] : s0[u];  // past the end: an empty run
-      rec[u] = bins + slot * (uint64_t)(BS_THREADS * (NC / 2) * NW);
-    }
-    uint32_t key0[BS_UNROLL], wd0[BS_UNROLL][NW - 1];
-#pragma unroll
-    for (int u = 0; u < BS_UNROLL; ++u) {
-      const uint32_t r = s0[u] + l16;
-      key0[u] = BS_CODE_SINGLE << BS_KEY_BITS;
-#pragma unroll
-      for (int q = 0; q < NW - 1; ++q) wd0[u][q] = 0u;
-      if (r < s1[u]) {
-        key0[u] = rec[u][r * NW];
-#pragma unroll
-        for (int q = 0; q < NW - 1; ++q) wd0[u][q] = rec[u][r * NW + 1 + q];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < BS_UNROLL; ++u) {
-      add(key0[u], wd0[u]);  // an absent record carries zeros: no atomics issued
-      for (uint32_t r = s0[u] + l16 + BS_GROUP; r < s1[u]; r += BS_GROUP) {
-        uint32_t wd[NW - 1];
-#pragma unroll
-        for (int q = 0; q < NW - 1; ++q) wd[q] = rec[u][r * NW + 1 + q];
-        add(rec[u][r * NW], wd);
-      }
+      for (int q = 0; q < NW - 1; ++q) wd[q] = rec[r * NW + 1 + q];
+      add(rec[r * NW], wd);
     }
   }
   __syncthreads();
@@ -434,7 +435,7 @@ BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
   pl.shift = bs_shift(NV);
   pl.rec_words = 1 + (NV + 1) / 2;
   pl.n_wg = ceil_div64(P, BS_THREADS);
-  const int64_t rec_per_wg = (int64_t)BS_THREADS << (n_dims - 1);  // NC / 2 records per lane (pair records, bin_pass1_kernel)
+  const int64_t rec_per_wg = ((int64_t)BS_THREADS << (n_dims - 1)) + BS_SLACK;  // NC / 2 records per lane (pair records) + room for split pairs
   pl.off_max = 0;
   pl.off_offs = 256;
   pl.off_bins = (pl.off_offs + (int64_t)d.n_levels * pl.n_wg * (BS_MAX_BINS + 1) * 2 + 255) / 256 * 256;
@@ -454,6 +455,7 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   if (e != hipSuccess) { l4d_set_error((int)e, "bs_scatter memset"); return (int)e; }
   BsCols c;
   for (int d = 0; d < 3; ++d) c.c[d] = d < n_dims ? cols[d] : 0;
+  if ((int64_t)desc.n_levels * (BS_MAX_BINS + 1) * pl.n_wg >= ((int64_t)1 << 32)) { l4d_set_error(1, "bs_scatter: too many points for one launch"); return 1; }
   for (int l = 0; l < desc.n_levels; ++l)
     if (desc.size[l] > (1u << 24)) { l4d_set_error(1, "bs_scatter: more than 2^24 entries per level"); return 1; }
   int max_bins = 1;

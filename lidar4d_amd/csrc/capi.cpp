@@ -1,6 +1,7 @@
 // Error reporting + version of the C ABI (include/lidar4d_hip.h).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/lidar4d_hip.h"
@@ -35,7 +36,24 @@ extern "C" int l4d_profile_enable(int on) {
   return 0;
 }
 
+// L4D_TRACE=1 (debugging): every launch is announced on stderr and waited for, so that a faulting kernel is the last one named
+static int g_trace = -1;
+extern "C" void l4d_trace_sync(const char* kernel, void* stream) {
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  fprintf(stderr, "[l4d] done   %s: %s\n", kernel, e == hipSuccess ? "ok" : hipGetErrorString(e));
+  fflush(stderr);
+}
 extern "C" int l4d_prof_begin(const char* kernel, void* stream) {
+  if (g_trace < 0) {
+    const char* e = getenv("L4D_TRACE");
+    g_trace = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (g_trace) {
+    fprintf(stderr, "[l4d] launch %s\n", kernel);
+    fflush(stderr);
+    return -2;
+  }
   if (!g_prof_on) return -1;
   ProfRec r;
   r.name = kernel;

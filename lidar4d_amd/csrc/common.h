@@ -30,11 +30,13 @@ extern "C" void* l4d_side_fork(void* from, int32_t i);
 extern "C" int l4d_side_join(void* into, int32_t i);
 extern "C" int l4d_prof_begin(const char* kernel, void* stream);
 extern "C" void l4d_prof_end(int idx, void* stream);
+extern "C" void l4d_trace_sync(const char* kernel, void* stream);
 #define L4D_LAUNCH(kernel, grid, block, lds, stream, ...)                    \
   do {                                                                       \
     const int prof_idx__ = l4d_prof_begin(#kernel, (void*)(stream));         \
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);       \
     if (prof_idx__ >= 0) l4d_prof_end(prof_idx__, (void*)(stream));          \
+    else if (prof_idx__ == -2) l4d_trace_sync(#kernel, (void*)(stream));     \
   } while (0)
 
 typedef _Float16 half_t;

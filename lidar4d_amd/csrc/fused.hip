@@ -232,25 +232,25 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
 // times) take the direct global path.  Output: column-major hdT[col][P] fp16, merged into X by the encode kernel.
 #define DH_THREADS 1024
 #define DH_MAX_ENTRIES 8192  // per slice: 2 slices x 8192 x 8 B = 128 KB
-// coords9: [9][P] fp32, row 3 * axis + frame = the axis' coordinate at the frame's (warped) point (warp_coords_kernel).  Every
-// (plane, level) task streams its samples' coordinates once: read from here that is 24 bytes per sample and task, dense,
-// instead of the 48 bytes of whole xt / flow rows (the kernel moves 16 x that: it is bound by this stream).
+// Coordinates for the LDS kernel, as dense arrays: xs[3][P] fp32 (the sample point) and flowT[6][P] fp16 (the two flow vectors,
+// exactly the halfs the flow network produced: x1 = x + (float)flow stays bit-identical).  Every (plane, level) task streams its
+// samples' coordinates once -- 2 x 4 + 4 x 2 = 16 bytes per sample and task from these arrays, instead of the 48 bytes of whole
+// xt / flow rows (or 24 as three fp32 frames per axis): the kernel moves 16 x that and this stream is a third of its time.
 __global__ void __launch_bounds__(256) warp_coords_kernel(const float* __restrict__ xt, const half_t* __restrict__ flow16, int64_t P,
-                                                         float* __restrict__ coords9) {
+                                                         float* __restrict__ xs, half_t* __restrict__ flowT) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
   const uint4 u = *reinterpret_cast<const uint4*>(flow16 + p * 16);
   const half_t* fh = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    coords9[(int64_t)(3 * a + 0) * P + p] = c4[a];
-    coords9[(int64_t)(3 * a + 1) * P + p] = c4[a] + h2f(fh[a]);
-    coords9[(int64_t)(3 * a + 2) * P + p] = c4[a] + h2f(fh[3 + a]);
-  }
+  for (int a = 0; a < 3; ++a) xs[(int64_t)a * P + p] = c4[a];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) flowT[(int64_t)k * P + p] = fh[k];
 }
 
-__global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc fd, const float* __restrict__ coords9,
+__global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc fd, const float* __restrict__ xs,
+                                                                    const half_t* __restrict__ flowT,
                                                                     const float* __restrict__ tinfo, int64_t P, int64_t chunk,
                                                                     half_t* __restrict__ hdT) {
   extern __shared__ uint4 lds_tab[];  // [entry] = {slice i1: 4 halfs, slice i2: 4 halfs}: both slices of a corner in ONE ds_read_b128
@@ -326,20 +326,25 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
     return f2h(0.5f * r[0] + 0.25f * (r1 + r2));
   };
   // two samples per iteration: both samples' global loads are in flight before the first LDS lookup
-  const float* ca_rows = coords9 + (int64_t)(3 * ca) * P;
-  const float* cb_rows = coords9 + (int64_t)(3 * cb) * P;
+  const float* xa_p = xs + (int64_t)ca * P;
+  const float* xb_p = xs + (int64_t)cb * P;
+  auto load = [&](int64_t p, float xa[3], float xb[3]) {
+    const float a = xa_p[p], b = xb_p[p];
+    xa[0] = a;
+    xb[0] = b;
+#pragma unroll
+    for (int e = 1; e < 3; ++e) {  // the warped points: x + flow[:3] (frame 1), x + flow[3:] (frame 2)
+      xa[e] = a + h2f(flowT[(int64_t)((e - 1) * 3 + ca) * P + p]);
+      xb[e] = b + h2f(flowT[(int64_t)((e - 1) * 3 + cb) * P + p]);
+    }
+  };
   for (int64_t p0 = lo_p + threadIdx.x; p0 < hi_p; p0 += 2 * DH_THREADS) {
     const int64_t p1 = p0 + DH_THREADS;
     const bool ok1 = p1 < hi_p;
     const int64_t q1 = ok1 ? p1 : p0;
     float xa0[3], xb0[3], xa1[3], xb1[3];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      xa0[e] = ca_rows[(int64_t)e * P + p0];
-      xb0[e] = cb_rows[(int64_t)e * P + p0];
-      xa1[e] = ca_rows[(int64_t)e * P + q1];
-      xb1[e] = cb_rows[(int64_t)e * P + q1];
-    }
+    load(p0, xa0, xb0);
+    load(q1, xa1, xb1);
     out[p0] = eval(xa0, xb0);
     if (ok1) out[p1] = eval(xa1, xb1);
   }
@@ -420,10 +425,10 @@ extern "C" int l4d_dyn_pairs_build(const void* const* slice_tables, int32_t n_sl
   return 0;
 }
 
-// hd_scratch of l4d_density_encode_fwd: the LDS kernel's output columns [n_dyn][P] fp16, then the warped coordinates [9][P] fp32
+// hd_scratch of l4d_density_encode_fwd: the LDS kernel's output columns [n_dyn][P] fp16, then the coordinates [3][P] fp32 and flow vectors [6][P] fp16
 extern "C" int64_t l4d_density_encode_fwd_workspace(const l4d_field_desc* f, int64_t P) {
   const int64_t n_dyn = f->hash_dynamic[0].n_levels + f->hash_dynamic[1].n_levels + f->hash_dynamic[2].n_levels;
-  return (n_dyn * P * 2 + 255) / 256 * 256 + 9 * P * 4;
+  return (n_dyn * P * 2 + 255) / 256 * 256 + (3 * P * 4 + 255) / 256 * 256 + 6 * P * 2;
 }
 
 extern "C" int64_t l4d_plane_rows_workspace(const l4d_field_desc* f) {
@@ -460,10 +465,11 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     n_chunks = (int)ceil_div64(P, chunk);
     (void)hipFuncSetAttribute((const void*)dynhash_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DH_MAX_ENTRIES * 8);
     const int64_t n_dyn = d.hd[0].n_levels + d.hd[1].n_levels + d.hd[2].n_levels;
-    float* coords9 = (float*)((char*)hd_scratch + (n_dyn * P * 2 + 255) / 256 * 256);
-    L4D_LAUNCH(warp_coords_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, dh_s, xt, (const half_t*)flow16, P, coords9);
+    float* xs = (float*)((char*)hd_scratch + (n_dyn * P * 2 + 255) / 256 * 256);
+    half_t* flowT = (half_t*)((char*)xs + (3 * P * 4 + 255) / 256 * 256);
+    L4D_LAUNCH(warp_coords_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, dh_s, xt, (const half_t*)flow16, P, xs, flowT);
     L4D_LAUNCH(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
-               2 * DH_MAX_ENTRIES * 8, dh_s, d, coords9, tinfo, P, chunk, (half_t*)hd_scratch);
+               2 * DH_MAX_ENTRIES * 8, dh_s, d, xs, flowT, tinfo, P, chunk, (half_t*)hd_scratch);
   }
   const PlaneRows pr = make_plane_rows(d, plane_rows);
   if (plane_rows)  // tinfo[0..2] = t, t1, t2: frames without a neighbour get a row nobody reads

@@ -625,10 +625,10 @@ class Trainer:
         rec = st["graphs"].get(frame)
         if rec is None:
             from . import _lib
-            # side streams stay out of a capture (L4D_GRAPH_STREAMS=1 keeps them): cross-stream capture buys ~0.2 ms of overlap
-            # that the replay's missing launch gaps return several times over
+            # the library's side streams (fork / join by events) are captured like any other stream dependency;
+            # L4D_GRAPH_STREAMS=0 keeps them out of the capture (debugging)
             mask_was = ops.streams_mask()
-            if os.environ.get("L4D_GRAPH_STREAMS") != "1":
+            if os.environ.get("L4D_GRAPH_STREAMS") == "0":
                 _lib.lib().l4d_streams_config(0)
             try:
                 static = None

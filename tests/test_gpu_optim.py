@@ -285,7 +285,7 @@ def test_graphed_step_replays_the_training_step():
     from lidar4d_amd.trainer import Trainer
     cfg, data, make = _setup(num_rays=128)
     m = make()
-    tr = Trainer(m, data, num_steps=64, iters=50, chamfer=True, flow=True, init_scale=2.0 ** 10)
+    tr = Trainer(m, data, num_steps=64, iters=50, chamfer=True, flow=True, init_scale=1.0)
     assert tr.graphs_supported()
     losses = []
     for it in range(12):
