@@ -159,9 +159,13 @@ int l4d_mlp_fwd_sigma(const void* x, int64_t P, int32_t in_pad, int32_t n_hidden
  * grad_w fp32, same layout as weights, ACCUMULATED with 1/loss_scale applied.
  * act: the forward's saved activations, or null = recompute them from x inside the kernel (saves 128 B/row/layer of HBM
  * traffic twice; built for in_pad <= 32 with 1-3 hidden layers -- measured neutral at in_pad 128, and wider / deeper shapes
- * would spill registers: those return an error). */
+ * would spill registers: those return an error).
+ * dx_absmax: null, or a device fp32 that receives (atomic max; zero it first) the largest |dx| of the input columns
+ * [absmax_col_lo, absmax_col_hi) (multiples of 16) as the kernel stores them, +inf if one of them is not finite -- the
+ * consumer of those columns then needs no pass of its own to scale its fixed-point accumulators (l4d_density_encode_bwd). */
 int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64_t P, const int32_t* n_rows, int32_t in_pad,
-                int32_t n_hidden, const void* weights, void* dx, float* grad_w, float inv_loss_scale, void* stream);
+                int32_t n_hidden, const void* weights, void* dx, float* grad_w, float inv_loss_scale, float* dx_absmax,
+                int32_t absmax_col_lo, int32_t absmax_col_hi, void* stream);
 
 /* ---- LiDAR_Renderer.run : model/renderer.py:59-129 -----------------------------------------------
  * sample: lin [T] = torch.linspace(0,1,T) (renderer.py:77; passed in so that the bits are the caller's
@@ -301,6 +305,8 @@ int l4d_density_encode_bwd(const l4d_field_desc* f /*host*/, const l4d_field_gra
                            const void* flow16, const float* tinfo, int64_t P, const void* dX, int32_t in_pad,
                            float param_scale, const float* plane_abs_max, int32_t samples_per_ray, void* workspace,
                            void* dflow16, float* plane_rows /*null, or l4d_plane_rows_workspace() bytes: see the forward*/,
+                           const float* gd_absmax /*null, or device fp32: max |dX[:, n_scales*C : 2*n_scales*C]| as l4d_mlp_bwd
+                           reports it (dx_absmax): one pass over dX less -- the time-plane kernel then does the preparation pass' work*/,
                            int32_t defer_join, void* stream);
 
 /* ---- chamfer_3DDist : utils/chamfer3D/chamfer3D.cu:11-194, dist_chamfer_3D.py:31-83 (SURVEY 8f "next" row 1) ----

@@ -72,7 +72,7 @@ SIGNATURES = {
     "l4d_planes_bwd": [P, PI64, PI32, I32, I32, P, I64, I32, P, P, P, P, P],
     "l4d_freq_fwd": [P, I64, I32, I32, P, I32, P],
     "l4d_mlp_fwd": [P, I64, P, I32, I32, P, P, P, P],
-    "l4d_mlp_bwd": [P, P, P, I64, P, I32, I32, P, P, P, F32, P],
+    "l4d_mlp_bwd": [P, P, P, I64, P, I32, I32, P, P, P, F32, P, I32, I32, P],
     "l4d_sample_rays": [P, P, P, P, I64, I32, F32, F32, F32, P, P, P],
     "l4d_sample_rays_xt": [P, P, P, P, P, I64, I32, F32, F32, F32, P, P, P],
     "l4d_composite_fwd": [P, P, I64, I32, F32, F32, I32, P, P, P, P, P, P, P],
@@ -92,7 +92,7 @@ SIGNATURES = {
     "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P, P, P],
     "l4d_plane_rows_workspace": [FD],
     "l4d_density_encode_fwd_workspace": [FD, I64],
-    "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P, I32, P],
+    "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P, P, I32, P],
     "l4d_density_encode_bwd_workspace": [FD, I64],
     "l4d_field_width": [FD],
     "l4d_dyn_pairs_build": [PP, I32, I64, P, P],

@@ -70,10 +70,13 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
                                                               float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
   constexpr int NW = RecWords<NV>::n;
-  // per-wave histograms: 1024 threads x 2^D records into <= 128 bins would otherwise pile ~64 same-address returning
-  // LDS atomics onto every counter
-  constexpr int NWAVES = BS_THREADS / 64;
-  __shared__ uint32_t hist[NWAVES][BS_MAX_BINS], boff[BS_MAX_BINS + 1];
+  // ONE histogram per workgroup: a rank is the value the returning LDS atomic hands back.  (Earlier: one histogram per wavefront
+  // plus a prefix pass over the wavefronts -- needed when 8 records per lane of a 1024-thread workgroup went into <= 128 bins and
+  // piled dozens of same-address atomics onto every counter.  With <= 4 records per lane into 64-256 hashed, i.e. random, bins a
+  // wave-level atomic meets 2-4 equal addresses, and the prefix pass, its barrier and 7/8 of the zeroing were pure overhead per
+  // level.)  The order of the records inside a run now depends on atomic arrival; pass 2 sums in integers, so nothing downstream
+  // depends on it.
+  __shared__ uint32_t hist[BS_MAX_BINS], boff[BS_MAX_BINS + 1];
   // at most NC / 2 records per lane on average: NC / 2 pair records, or NC single records per run with <= 32 runs per wave
   constexpr int RPL = NC / 2;
   constexpr uint32_t CAP = BS_THREADS * RPL + BS_SLACK;  // records per (workgroup, level) slot
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
     for (int j = 0; j < NV; ++j) gnext[j] = grow[(lvl + 1) * NV + j];
   }
   __syncthreads();  // the previous level's copy-out has finished reading the staging buffer / bin offsets
-  for (int i = threadIdx.x; i < NWAVES * BS_MAX_BINS; i += BS_THREADS) (&hist[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < BS_MAX_BINS; i += BS_THREADS) hist[i] = 0;
   __syncthreads();
 
   Cell<D> c = locate<D>(xin, desc.scale[lvl]);
@@ -257,19 +260,8 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   if (lane == 0 && amax > 0.0f) atomic_max_nonneg(lvl_max + lvl, amax);
 
   // rank inside the workgroup
-  const int wave_id = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[wave_id][(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
-  __syncthreads();
-  if (threadIdx.x < BS_MAX_BINS) {  // exclusive prefix over the waves of each bin; hist[0][b] <- bin total
-    uint32_t run = 0;
-    for (int w = 0; w < NWAVES; ++w) {
-      const uint32_t c = hist[w][threadIdx.x];
-      hist[w][threadIdx.x] = run;
-      run += c;
-    }
-    boff[threadIdx.x] = run;  // temporarily the bin total
-  }
+  for (int k = 0; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   __syncthreads();
   const uint64_t wg_slot = (uint64_t)lvl * n_wg + tile;
   if (threadIdx.x < 64) {  // exclusive scan of the bin totals by one wave: BPL consecutive bins per lane
@@ -278,7 +270,7 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
 #pragma unroll
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
-      c[q] = b < nbins ? boff[b] : 0u;
+      c[q] = b < nbins ? hist[b] : 0u;
       sum += c[q];
     }
     uint32_t inc = sum;
@@ -312,7 +304,7 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   for (int k = 0; k < NC; ++k)
     if (emit[k]) {
       const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
-      const uint32_t r = boff[b] + hist[wave_id][b] + pos[k];
+      const uint32_t r = boff[b] + pos[k];
       const uint32_t code = keys[k] >> 24;
       if (r < CAP) {
         stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));

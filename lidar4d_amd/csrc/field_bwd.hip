@@ -22,6 +22,7 @@
 #include "wave_dev.h"
 #include "binscatter.h"
 #include <algorithm>
+#include <cstdlib>
 
 #define ST_GVS_MAX 0     // [0..8)  max |gvs| per plane scale
 #define ST_GD_MAX 8      // max |dX dynamic-plane columns|
@@ -185,12 +186,23 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 #ifndef PDYN_THREADS
 #define PDYN_THREADS 768  // 12 waves on the one workgroup a CU can hold (138 KB of LDS; 155 VGPRs allow 3 per SIMD): 3.00 -> 2.73 ms against 512
 #endif
-template <bool ROWS>
+// PREP: the kernel also does the prep kernel's work for its samples -- static planes' product-rule factors gvs, the transposed
+// dynamic-hash gradient gdynT, the SoA coordinates, the statistics of both -- while the sample's dX row and coordinates are in
+// registers anyway: one pass over dX instead of two, one launch less, and the plane gathers of that part (texel-bandwidth-bound)
+// overlap with the segmented scans of this one (VALU-bound).  Needs stats[ST_GD_MAX] from elsewhere: the sigma network's
+// backward reports the largest |dX| of the time-plane columns as it stores them (l4d_mlp_bwd dx_absmax).
+struct PrepOut {
+  half_t* gvs;
+  half_t* gdynT;
+  float* xsoa;
+  float* stats;
+};
+template <bool ROWS, bool PREP>
 __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
                                                             const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
                                                             int64_t P, int64_t chunk, const half_t* __restrict__ dX,
                                                             int in_pad, float pscale, const float* __restrict__ stats,
-                                                            half_t* __restrict__ dflow16, PlaneRows prows) {
+                                                            half_t* __restrict__ dflow16, PlaneRows prows, PrepOut po) {
   constexpr int C = 8;
   extern __shared__ int lds_i[];
   const int nS = fd.planes.n_scales;
@@ -219,6 +231,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
   // creates are merged in registers (row_runs / row_scan) before they reach the LDS atomics
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
   const int64_t n_iter = (chunk + blockDim.x - 1) / blockDim.x;
+  float prep_stat = 0.0f;  // PREP: lane i collects the maximum destined for stats[i] over the whole chunk (one atomic at the end)
   for (int64_t it = 0; it < n_iter; ++it) {
     const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
     const bool active = pr < hi_p;
@@ -232,6 +245,68 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
     }
     const half_t* row = dX + p * in_pad;
+    if (PREP) {
+      const int lane = __lane_id();
+      if (active) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) po.xsoa[(int64_t)a * P + pr] = c4[a];
+      }
+      const float xs0[4] = {c4[0], c4[1], c4[2], t0};
+      for (int s = 0; s < nS; ++s) {  // static planes: gradient of plane j = dX_s * (product of the other two planes' values)
+        float gs[C];
+        {
+          const uint4 u = *reinterpret_cast<const uint4*>(row + s * C);
+          const half_t* h = reinterpret_cast<const half_t*>(&u);
+#pragma unroll
+          for (int k = 0; k < C; ++k) gs[k] = active ? h2f(h[k]) : 0.0f;
+        }
+        Tap taps[3];
+        float v[3][C];
+        int cis[3];
+        group_taps<C>(fd, s, xs0, false, taps, v, cis);
+        float smax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          half_t hv[C];
+#pragma unroll
+          for (int k = 0; k < C; k += 2) {
+            const float2_t g2 = {gs[k], gs[k + 1]}, va = {v[(j + 1) % 3][k], v[(j + 1) % 3][k + 1]};
+            const float2_t vb = {v[(j + 2) % 3][k], v[(j + 2) % 3][k + 1]};
+            const float2_t gv = g2 * va * vb;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              hv[k + u] = f2h_grad(gv[u]);
+              smax = amax_nf(smax, h2f(hv[k + u]));
+            }
+          }
+          if (active) *reinterpret_cast<uint4*>(po.gvs + ((int64_t)(s * 3 + j) * P + p) * C) = *reinterpret_cast<uint4*>(hv);
+        }
+        smax = wave_max(smax);
+        if (lane == ST_GVS_MAX + s) prep_stat = fmaxf(prep_stat, smax);
+      }
+      // dynamic hash: the current frame's share c0 of the upstream gradient, transposed (neighbour frames are no_grad)
+      const int colD = 2 * nS * C + fd.hs.n_levels * 4;
+      const int L3 = fd.hd[0].n_levels + fd.hd[1].n_levels + fd.hd[2].n_levels;
+      uint32_t dw[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (q * 8 < L3) u = *reinterpret_cast<const uint4*>(row + colD + q * 8);
+        dw[4 * q + 0] = u.x; dw[4 * q + 1] = u.y; dw[4 * q + 2] = u.z; dw[4 * q + 3] = u.w;
+      }
+#pragma unroll
+      for (int cidx = 0; cidx < 32; ++cidx) {  // fully unrolled: dw[] must stay in registers
+        if (cidx < L3) {                         // uniform
+          const uint32_t wv = dw[cidx >> 1];
+          const half_t hin = __builtin_bit_cast(half_t, (unsigned short)((cidx & 1) ? wv >> 16 : wv & 0xFFFFu));
+          const half_t hv = f2h_grad(h2f(hin) * c0);
+          const float a = active ? amax_nf(0.0f, h2f(hv)) : 0.0f;
+          if (active) po.gdynT[(int64_t)cidx * P + p] = hv;
+          const float m = wave_max(a);
+          if (lane == ST_DYN_MAX + cidx) prep_stat = fmaxf(prep_stat, m);
+        }
+      }
+    }
     float gflow[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // d/d(x1), d/d(x2): x1 = x + flow[:3], x2 = x + flow[3:]
     for (int s = 0; s < nS; ++s) {
       float gd[C];
@@ -323,6 +398,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       dst[1] = reinterpret_cast<uint4*>(out)[1];
     }
   }
+  if (PREP && prep_stat > 0.0f) atomic_max_nonneg(po.stats + __lane_id(), prep_stat);
   __syncthreads();
   // an upstream gradient that left the fp16 range (inf / nan in dX) must reach the parameter gradients: the step is
   // then skipped and the loss scale lowered (common.h, f2h_grad)
@@ -570,7 +646,7 @@ extern "C" int64_t l4d_density_encode_bwd_workspace(const l4d_field_desc* f, int
 extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_grads* g, const float* xt, const void* flow16,
                                       const float* tinfo, int64_t P, const void* dX, int32_t in_pad, float param_scale,
                                       const float* plane_abs_max, int32_t samples_per_ray, void* workspace, void* dflow16,
-                                      float* plane_rows, int32_t defer_join, void* stream_) {
+                                      float* plane_rows, const float* gd_absmax, int32_t defer_join, void* stream_) {
   if (P == 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   // Independent parts of the adjoint on side streams (l4d_streams_config bit 1): the sorted scatter of the static grid
@@ -610,16 +686,21 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
                         param_scale, ws + w.bins, s_bins);
     if (rc) return rc;
   }
-  {
-    const int colsA = 2 * d.planes.n_scales * 8, colD = colsA + d.hs.n_levels * 4;
-    const int staged = (colD % 8 == 0 && L3 % 8 == 0) ? 1 : 0;  // 16-byte pieces
-    const int lds = staged ? PREP_THREADS * (colsA + L3 + 8) * 2 : 0;
+  // With the largest |dX| of the time-plane columns known beforehand (gd_absmax, from the sigma network's backward) the prep
+  // kernel's work is done by the time-plane kernel itself (planes_dyn_lds_kernel<.., PREP = true>).
+  const int colsA_ = 2 * d.planes.n_scales * 8, colD_ = colsA_ + d.hs.n_levels * 4;
+  const bool fused_prep = gd_absmax && plane_rows && colD_ % 8 == 0 && L3 % 8 == 0 && L3 <= 32 && in_pad % 8 == 0 && getenv("L4D_NO_FUSED_PREP") == nullptr;
+  if (fused_prep) {
+    e = hipMemcpyAsync(stats + ST_GD_MAX, gd_absmax, sizeof(float), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
+  } else {
+    const int staged = (colD_ % 8 == 0 && L3 % 8 == 0) ? 1 : 0;  // 16-byte pieces
+    const int lds = staged ? PREP_THREADS * (colsA_ + L3 + 8) * 2 : 0;
     L4D_LAUNCH(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, PREP_THREADS)), dim3(PREP_THREADS), lds, stream, d, xt, tinfo, P,
                (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, staged, xsoa);
   }
 
-
-  if (forked) {  // after the prep kernel
+  if (forked && !fused_prep) {  // after the prep kernel
     s_lds = (hipStream_t)l4d_side_fork(stream_, 2);
     if (!s_lds) return 1;
   }
@@ -637,16 +718,27 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       for (int j = 0; j < 3; ++j) lds += TFRAMES * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
     const PlaneRows pr = make_plane_rows(d, plane_rows);
+    const PrepOut po{gvs, gdynT, xsoa, stats};
     if (plane_rows) {
       L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, stream, d, pr, tinfo, plane_rows);
-      (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      L4D_LAUNCH((planes_dyn_lds_kernel<true>), dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
-                 P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr);
+      if (fused_prep) {
+        (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        L4D_LAUNCH((planes_dyn_lds_kernel<true, true>), dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
+                   P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr, po);
+      } else {
+        (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        L4D_LAUNCH((planes_dyn_lds_kernel<true, false>), dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
+                   P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr, po);
+      }
     } else {
-      (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      L4D_LAUNCH((planes_dyn_lds_kernel<false>), dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
-                 P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr);
+      (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      L4D_LAUNCH((planes_dyn_lds_kernel<false, false>), dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
+                 P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr, po);
     }
+  }
+  if (forked && fused_prep) {  // the static-plane / dynamic-hash adjoints need what the fused kernel wrote
+    s_lds = (hipStream_t)l4d_side_fork(stream_, 2);
+    if (!s_lds) return 1;
   }
   // static planes
   {

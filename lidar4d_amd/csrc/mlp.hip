@@ -25,6 +25,7 @@
 // MFMA utilisation is irrelevant here (~2 % of peak at target rate); the doubled MFMA work
 // buys a kernel with no LDS traffic in the loop and no barriers.
 #include "common.h"
+#include "wave_dev.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -322,6 +323,12 @@ struct AttrBwdEpi {
   int ch, accumulate;
   float loss_scale;
 };
+// DxStat: *out = max(*out, max |dx[:, 16 lo_tile : 16 hi_tile]|) over the rows of the launch, as stored (fp16-rounded; +inf for a
+// non-finite value): what the consumer of those columns needs to scale its fixed-point accumulators (field_bwd.hip).
+struct DxStat {
+  float* out;
+  int lo_tile, hi_tile;
+};
 template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST, bool RECOMP = false, bool GATHER = false, int DX_LO = COL_LO,
           bool ATTR_EPI = false>
 __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1)) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
@@ -329,9 +336,11 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
                                                      const int32_t* __restrict__ n_rows,
                                                      const half_t* __restrict__ weights, half_t* __restrict__ dx,
                                                      float* __restrict__ grad_w, float inv_scale, AttrSrc src,
-                                                     AttrBwdEpi aepi = AttrBwdEpi{nullptr, nullptr, nullptr, 0, 0, 0.0f}) {
+                                                     AttrBwdEpi aepi = AttrBwdEpi{nullptr, nullptr, nullptr, 0, 0, 0.0f},
+                                                     DxStat dstat = DxStat{nullptr, 0, 0}) {
   const int64_t P = n_rows ? min((int64_t)*n_rows, cap) : cap;
   using L = BwdFrags<IN_TILES, NH>;
+  float dx_amax = 0.0f;  // DxStat: running max |dx| of the requested column tiles (this lane's share)
   constexpr int IN_PAD = IN_TILES * 16;
   constexpr int KS_IN = L::KS_IN;
   constexpr int NF_FWD = RECOMP ? 4 * KS_IN + (NH - 1) * 8 : 0;  // forward chain fragments (layers 1 .. NH), as in mlp_fwd_kernel
@@ -739,6 +748,10 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
                 }
               } else {
                 *reinterpret_cast<h4*>(dx + rows[a] * DX_PITCH + 16 * (mt - DX_T0) + 4 * g) = ov;
+                if (!GATHER && dstat.out && mt >= dstat.lo_tile && mt < dstat.hi_tile) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) dx_amax = amax_nf(dx_amax, h2f(ov[r]));
+                }
               }
             }
           }
@@ -754,6 +767,10 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
     }
   }
 
+  if (!GATHER && dstat.out) {  // wave-uniform
+    dx_amax = wave_max(dx_amax);
+    if (lane == 0 && dx_amax > 0.0f) atomic_max_nonneg(dstat.out, dx_amax);
+  }
   // ---- flush dW (fp32 atomics; one add per element per wave) ----------------------------------
   float* gW1 = grad_w;
   float* gWo = grad_w + HID * IN_PAD + (NH - 1) * HID * HID;
@@ -868,8 +885,14 @@ extern "C" int l4d_mlp_fwd_sigma(const void* x, int64_t P, int32_t in_pad, int32
 
 extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64_t P, const int32_t* n_rows, int32_t in_pad,
                            int32_t n_hidden, const void* weights, void* dx, float* grad_w, float inv_loss_scale,
-                           void* stream) {
+                           float* dx_absmax, int32_t absmax_col_lo, int32_t absmax_col_hi, void* stream) {
   if (P == 0) return 0;
+  if (dx_absmax && (absmax_col_lo % 16 || absmax_col_hi % 16 || absmax_col_lo < 0 || absmax_col_hi > in_pad || !dx || in_pad > 128)) {
+    l4d_set_error(1, "l4d_mlp_bwd: dx_absmax needs dx, in_pad <= 128 and a column range in multiples of 16 inside [0, in_pad]");
+    return 1;
+  }
+  const DxStat dstat{dx_absmax, absmax_col_lo / 16, absmax_col_hi / 16};
+  const AttrBwdEpi no_epi{nullptr, nullptr, nullptr, 0, 0, 0.0f};
   const int in_tiles = in_pad / 16;
   int grid = grid_for((P + 31) / 32);
   if (grid > bwd_grid_cap(in_pad, n_hidden)) grid = bwd_grid_cap(in_pad, n_hidden);
@@ -879,7 +902,7 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (!done && !act && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                      \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
                (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,           \
-               (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                                      \
+               (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1}, no_epi, dstat);    \
     done = true;                                                                                                     \
   }
   X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3)  // <8, 1>: measured neutral; <6, 2> and wider / deeper spill registers
@@ -892,7 +915,7 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, IT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,         \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                              \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1}, no_epi, dstat); \
     done = true;                                                                                                     \
   }
   FOR_EACH_CFG(X)

@@ -207,10 +207,13 @@ class RenderFn(torch.autograd.Function):
                 ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad, n_enc, model.geo_feat_dim, dh)
         ops.sigma_bwd(h, d_sigma.view(-1), ls, dh)
         # sigma network
-        dX = ops.mlp_bwd(X, act_s, dh, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,
-                         store.grad_view(model.sigma_net.params), inv)
-        # field
+        # (the backward reports max |dX| of the time-plane columns as it stores them: the field adjoint's fixed-point scale)
         pe = model.planes_encoder
+        n_pl = pe.layout.n_scales * pe.layout.C
+        gd_absmax = torch.zeros(1, dtype=torch.float32, device=dev) if n_pl % 16 == 0 else None
+        dX = ops.mlp_bwd(X, act_s, dh, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,
+                         store.grad_view(model.sigma_net.params), inv, dx_absmax=gd_absmax, absmax_cols=(n_pl, 2 * n_pl))
+        # field
         gcl = torch.zeros(pe.layout.numel, dtype=torch.float32, device=dev)
         fd = _field_desc(model)
         vmax = pe._arena().abs().max().reshape(1)
@@ -219,7 +222,8 @@ class RenderFn(torch.autograd.Function):
         # the time-plane adjoint, and -- single GPU: no reducer waiting for them -- also next to the flow field's backward below,
         # which only needs d(flow).  A data-parallel trainer joins first: it starts reducing those gradients right away.
         defer = hook is None and bool(ops.streams_mask() & 2)
-        res = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv, vmax, samples_per_ray=T, defer_join=defer)
+        res = ops.density_encode_bwd(fd, _field_grads(model, gcl), xt, flow16, tinfo, dX, inv, vmax, samples_per_ray=T, defer_join=defer,
+                                     gd_absmax=gd_absmax)
         dflow16, keep = res if defer else (res, None)
 
         def planes_done():  # channel-last gradient arena -> added onto the planes' [1, C, H, W] gradient views, one launch

@@ -202,14 +202,18 @@ def mlp_recompute_supported(in_pad, n_hidden):
     return in_pad <= 32 and 1 <= n_hidden <= 3
 
 
-def mlp_bwd(x16, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale, n_rows=None, want_dx=True, dx=None):
+def mlp_bwd(x16, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale, n_rows=None, want_dx=True, dx=None, dx_absmax=None,
+            absmax_cols=(0, 0)):
+    """dx_absmax: 1-element fp32 device tensor (zeroed by the caller) that receives max |dx[:, absmax_cols[0]:absmax_cols[1]]|
+    (columns in multiples of 16; +inf if a value is not finite)."""
     _chk(x16, torch.float16, "x"), _chk(act, torch.float16, "act"), _chk(dy16, torch.float16, "dy")
     _chk(weights16, torch.float16, "weights"), _chk(grad_w, torch.float32, "grad_w"), _chk(n_rows, torch.int32, "n_rows")
+    _chk(dx_absmax, torch.float32, "dx_absmax")
     P, in_pad = x16.shape
     if want_dx and dx is None:
         dx = torch.empty(P, in_pad, dtype=torch.float16, device=x16.device)
     call("l4d_mlp_bwd", _p(x16), _p(act), _p(dy16), P, _p(n_rows), in_pad, n_hidden, _p(weights16), _p(dx), _p(grad_w),
-         float(inv_loss_scale), _stream())
+         float(inv_loss_scale), _p(dx_absmax), int(absmax_cols[0]), int(absmax_cols[1]), _stream())
     return dx
 
 
@@ -404,11 +408,13 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
 
 
 def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_scale, plane_abs_max, samples_per_ray=0,
-                       dflow16=None, defer_join=False):
+                       dflow16=None, defer_join=False, gd_absmax=None):
     """Adjoint of density_encode_fwd (several launches, lidar4d_amd/csrc/field_bwd.hip).  plane_abs_max: 1-element fp32
     device tensor, max |plane parameter| (bound for the fixed-point LDS accumulators).
     defer_join: return (dflow16, keepalive) with the library's side streams still running; the caller queues the consumers of
-    dflow16, then calls ``streams_join()`` and only then drops ``keepalive`` (the workspace the side streams write)."""
+    dflow16, then calls ``streams_join()`` and only then drops ``keepalive`` (the workspace the side streams write).
+    gd_absmax: 1-element fp32 device tensor = max |dX[:, n_scales*C : 2*n_scales*C]| (``mlp_bwd(dx_absmax=...)``): the separate
+    preparation pass over dX is then folded into the time-plane kernel."""
     _chk(dX, torch.float16, "dX"), _chk(plane_abs_max, torch.float32, "plane_abs_max")
     P, in_pad = dX.shape
     if dflow16 is None:
@@ -419,8 +425,8 @@ def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_sca
     if P >= PLANE_ROWS_MIN_POINTS:
         rows = torch.empty(_lib.lib().l4d_plane_rows_workspace(C.byref(field_desc)) // 4, dtype=torch.float32, device=dX.device)
     call("l4d_density_encode_bwd", C.byref(field_desc), C.byref(field_grads), _p(xt), _p(flow16), _p(tinfo), P, _p(dX),
-         in_pad, float(param_scale), _p(plane_abs_max), int(samples_per_ray), _p(ws), _p(dflow16), _p(rows), int(bool(defer_join)),
-         _stream())
+         in_pad, float(param_scale), _p(plane_abs_max), int(samples_per_ray), _p(ws), _p(dflow16), _p(rows), _p(gd_absmax),
+         int(bool(defer_join)), _stream())
     if defer_join:
         return dflow16, (ws, rows)
     return dflow16
