@@ -396,6 +396,18 @@ def _run(args):
             step_mode = "eager launches (graph capture failed: %s)" % repr(e)[:200]
             sys.stderr.write("graph capture failed: %r\n" % (e,))
         del keep
+    # GradScaler settling, outside every count: the reference's default init_scale (65536, on top of the internal 128) overflows
+    # at initialisation and the scale halves once per skipped step; a skipped step is a forward + backward without the
+    # Adam update, i.e. not the step this benchmark is about.  Run until two consecutive steps were applied (<= 40 steps).
+    settle_steps = 0
+    if not inference and trainer.scaler is not None:
+        applied_in_a_row, last = 0, int(trainer.opt.steps[0])
+        while applied_in_a_row < 2 and settle_steps < 40:
+            step()
+            settle_steps += 1
+            now = int(trainer.opt.steps[0])
+            applied_in_a_row = applied_in_a_row + 1 if now > last else 0
+            last = now
     steps_before = int(trainer.opt.steps[0]) if not inference else 0
     for _ in range(args.warmup):
         step()
@@ -577,7 +589,7 @@ def _run(args):
                                + ("no parameter EMA" if args.no_ema else "parameter EMA once per epoch of 51 steps (runner.py:534-535)"),
                        "state": "random init (tiny-cuda-nn default U(-1e-4, 1e-4) tables): every sample passes the weights > 1e-4 mask, the attribute networks run on all of them",
                        "loss_scale_after_timed_region": scale_after, "skipped_steps_in_timed_region": skipped,
-                       "skipped_steps_in_warmup": skipped_warmup, "step_mode": step_mode,
+                       "skipped_steps_in_warmup": skipped_warmup, "scaler_settling_steps_before_warmup": settle_steps, "step_mode": step_mode,
                        "side_streams_mask": ops.streams_mask()},
             "roofline": roofline,
             "roofline_kernels": roofline_kernels,
