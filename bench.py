@@ -74,6 +74,11 @@ WORKLOADS = {
 INFERENCE = {"c5"}
 
 
+def ops_attr_recompute(n_hidden):
+    from lidar4d_amd import ops
+    return ops.attr_mlp_recompute_supported(n_hidden)
+
+
 def kernel_models(model, P, M):
     """Per-kernel roof and byte model: {kernel name: dict(bound, bytes, [alg], note)} per LAUNCH at P sample points and M
     attribute rows (samples with weight > 1e-4).  ``bytes`` is what the roof is charged with:
@@ -100,11 +105,11 @@ def kernel_models(model, P, M):
     enc = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P, gathers=(L * 8 + L * 4) * P,
                note="planes + static hash + xy dynamic hash gathers (time planes via per-call 1-D rows, both time slices of a corner "
                     "in one 16-B load); row staged in LDS, written once")
-    m["density_encode_fwd_kernel<true, true>"] = enc
-    m["density_encode_fwd_kernel<true, false>"] = enc
-    m["density_encode_fwd_kernel<false, false>"] = dict(bound="l2", bytes=(enc_alg + lds_alg) * P, hbm=(16 + 32 + X) * P, note="all gathers direct")
-    m["density_encode_fwd_kernel<false, true>"] = m["density_encode_fwd_kernel<false, false>"]
-    m["dynhash_fwd_lds_kernel"] = dict(bound="lds", bytes=lds_alg * P, hbm=(2 * L * (16 + 16) + 2 * 2 * L) * P,
+    m["density_encode_fwd_kernel<true, true, 0>"] = enc
+    m["density_encode_fwd_kernel<true, false, 0>"] = enc
+    m["density_encode_fwd_kernel<false, false, 0>"] = dict(bound="l2", bytes=(enc_alg + lds_alg) * P, hbm=(16 + 32 + X) * P, note="all gathers direct")
+    m["density_encode_fwd_kernel<false, true, 0>"] = m["density_encode_fwd_kernel<false, false, 0>"]
+    m["dynhash_fwd_lds_kernel"] = dict(bound="lds", bytes=lds_alg * P, hbm=(2 * L * 16 + 2 * 2 * L) * P,
                                        note="xz / yz HashGridT stacks from LDS-resident slice tables; one streaming pass of xt / flow per (plane, level)")
     m["hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="l2", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, gathers=Lf * 8 * P, note="flow grid + interpT")
     fl = lambda pad, nh: 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
@@ -127,19 +132,28 @@ def kernel_models(model, P, M):
                                                                                 flops=2 * fl(a_pad, nh_a) * M, note="stored rows + activations + dy in, 32 gradient columns out")
     m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, false, true, 4>"] = dict(bound="hbm", bytes=(4 + 32 + nh_a * 128 + 32 + 64) * M,
                                                                                flops=2 * fl(a_pad, nh_a) * M, note="idx + h row (rows assembled again) + activations + dy in, 32 gradient columns out")
+    keep_act = not ops_attr_recompute(nh_a)
+    if not keep_act:  # the forward stores no activations (the backward recomputes them)
+        m[f"mlp_fwd_kernel<{it_a}, {nh_a}, true, false, 2>"] = dict(bound="hbm", bytes=(4 + 32 + 8) * M, flops=fl(a_pad, nh_a) * M,
+                                                                    note="idx + h row in (direction encoding per ray: cache resident), sigmoid epilogue (dense + compact value) out; no activations stored")
+    m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, true, true, 4, true>"] = dict(
+        bound="hbm", bytes=(4 + 32 + 8 + 8 + 48) * M, flops=3 * fl(a_pad, nh_a) * M,
+        note="idx + h row + the two sigmoid-adjoint factors in, activations recomputed; geo-feature gradient into dh (stored by the first network, read + stored by the second)")
     m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true, false, true, 4, true>"] = dict(
         bound="hbm", bytes=(4 + 32 + 8 + 8 + nh_a * 128 + 48) * M, flops=2 * fl(a_pad, nh_a) * M,
         note="idx + h row + the two sigmoid-adjoint factors + activations in; geo-feature gradient into dh (stored by the first network, read + stored by the second)")
     m[f"mlp_fwd_kernel<{it_a}, {nh_a}>"] = dict(bound="hbm", bytes=(2 * a_pad + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M, note="materialised input rows")
     m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true>"] = dict(bound="hbm", bytes=(4 * a_pad + nh_a * 128 + 32) * M, flops=2 * fl(a_pad, nh_a) * M, note="materialised input rows")
-    rec = 8 * 12  # one 12-byte record per corner (upper bound: equal-cell runs along a ray are merged first)
+    rec = 4 * 12  # one 12-byte record per x-neighbour PAIR of corners (upper bound: equal-cell runs along a ray are merged first)
     m["bin_pass1_kernel<3, 4>"] = dict(bound="hbm", bytes=(16 + 8 * L + L * rec) * P, note="static grid: xt + dX columns read, sorted records written (upper bound)")
     m["bin_pass2_kernel<3, 4>"] = dict(bound="hbm", bytes=L * rec * P, note="static grid: records read, segments reduced in LDS")
-    rec2 = 8 * 8
+    rec2 = 4 * 8
     m["bin_pass1_kernel<3, 2>"] = dict(bound="hbm", bytes=(16 + 4 * Lf + Lf * rec2) * P, note="flow grid records")
     m["bin_pass2_kernel<3, 2>"] = dict(bound="hbm", bytes=Lf * rec2 * P, note="flow grid records")
     m["field_bwd_prep_kernel"] = dict(bound="hbm", bytes=(16 + X + 3 * nS * 16 + 2 * n_dyn) * P, note="dX row read, plane factors + transposed dyn gradient written")
-    m["planes_dyn_lds_kernel<true>"] = m["planes_dyn_lds_kernel<false>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
+    m["planes_dyn_lds_kernel<true, false>"] = m["planes_dyn_lds_kernel<false, false>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
+    m["planes_dyn_lds_kernel<true, true>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32 + 3 * nS * 16 + 2 * n_dyn + 12) * P,
+                                                  note="the same + the preparation pass' outputs (static-plane factors, transposed dyn gradient, SoA coordinates) from the one read of the dX rows")
     m["planes_static_lds_kernel"] = dict(bound="hbm", bytes=(3 * nS * 16 + 3 * nS * 8) * P, note="plane-major factors read once per (scale, plane)")
     m["dynhash_lds_kernel"] = dict(bound="hbm", bytes=(2 * n_dyn + n_dyn * 8) * P, note="transposed gradient + 2 coordinates per (plane, level) pass")
     m["composite_fwd_kernel"] = dict(bound="hbm", bytes=(4 + 4 + 4 + 4) * P, note="sigma, z in; weights, index out")
@@ -448,10 +462,23 @@ def _run(args):
             M = P if inference else int(model.render(b["rays_o_lidar"], b["rays_d_lidar"], b["time"], staged=False, perturb=True, num_steps=768)["mask_count"])
         models = kernel_models(model, P, M)
         peaks = {"hbm": HBM_PEAK_GBS, "l2": L2_PEAK_GBS, "lds": LDS_PEAK_GBS}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_r02.json")
-        traffic = json.load(open(tpath)).get("kernels", {}) if os.path.exists(tpath) and args.workload == "c3" else {}
-        pmc_path = os.path.join(ROOT, "profiles", "r02_mfma_pmc.json")
-        mfma_pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) and args.workload == "c3" else {}
+        # counter files of a committed rocprofv3 --pmc pass (tools/gpu_profile_round.sh): only attached when they were measured on
+        # THIS build of the library (they carry its sha256) -- numbers of an older build would be constants, not measurements
+        import hashlib
+        lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+
+        def load_pmc(name):
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path) or args.workload != "c3":
+                return {}, None
+            d = json.load(open(path))
+            if d.get("library_sha256") != lib_sha:
+                return {}, "dropped: measured on another build of the library (%s..., loaded %s...)" % (str(d.get("library_sha256"))[:12], lib_sha[:12])
+            return d, "profiles/" + name
+
+        traffic_file, traffic_src = load_pmc("hbm_traffic_r03.json")
+        traffic = traffic_file.get("kernels", {})
+        mfma_pmc, mfma_src = load_pmc("r03_mfma_pmc.json")
         def pmc_lookup(table, name):
             """profiles/ keys carry every template argument (rocprofv3's symbol), launch-site names only the explicit ones."""
             if name in table:
@@ -476,6 +503,8 @@ def _run(args):
                 row.update(bound=mod["bound"], bytes_per_launch=mod["bytes"], modelled_launches_per_step=len(big) / args.profile_steps,
                            modelled_launch_ms=round(avg_ms, 4), achieved=round(ach, 1), peak=peaks[mod["bound"]], unit="GB/s",
                            frac=round(ach / peaks[mod["bound"]], 4), traffic=pmc_lookup(traffic, name), note=mod["note"])
+                if row["traffic"]:  # memory-side bytes of the L2 (counters) over the measured duration, against the HBM peak
+                    row["frac_hbm_counter"] = round(row["traffic"]["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 if "gathers" in mod:  # hash-entry gathers that are always issued (one lane = one table entry; coherent plane taps not counted)
                     gl = mod["gathers"] / (avg_ms * 1e-3) / 1e9
                     row["hash_gathers_G_per_s"] = round(gl, 1)
@@ -495,7 +524,8 @@ def _run(args):
         if modelled:
             d = modelled[0]  # the dominant modelled kernel
             roofline = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": d["peak"], "unit": "GB/s",
-                        "frac": d["frac"], "traffic": d["traffic"], "bytes_per_launch": d["bytes_per_launch"],
+                        "frac": d["frac"], "traffic": d["traffic"], "frac_hbm_counter": d.get("frac_hbm_counter"), "traffic_source": traffic_src,
+                        "library_sha256": lib_sha, "bytes_per_launch": d["bytes_per_launch"],
                         "avg_launch_ms": d["modelled_launch_ms"], "launches_per_step": d["modelled_launches_per_step"],
                         "bytes_are": {"hbm": "compulsory HBM bytes", "l2": "table-entry bytes gathered through L1/L2 (tables are cache resident)",
                                       "lds": "table-entry bytes served from LDS"}[d["bound"]],
@@ -506,7 +536,7 @@ def _run(args):
                                             "(64 G/s on L2 misses), measured with tools/ubench/gather.hip: that rate, not a byte rate, is what binds this kernel",
                         "samples_per_launch": P, "attribute_rows": M}
         mfma = {"kernels": mf, "peak_tflops": MFMA_F16_PEAK_TFLOPS,
-                "pmc_source": "profiles/r02_mfma_pmc.json (rocprofv3 --pmc pass of this command: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))" if mfma_pmc else None,
+                "pmc_source": (mfma_src + " (rocprofv3 --pmc pass of this command on this build: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))") if mfma_pmc else mfma_src,
                 "note": "algorithmic flops = the network's multiply-adds; the backward kernels execute about twice that on the matrix cores (operands are "
                         "produced in both orientations instead of being transposed through LDS), which is why their PMC utilisation is higher. "
                         "MLPs are 18-55 kFLOP per sample (SURVEY 8d): these kernels are bound by HBM streaming of their rows, not by the MFMA rate"}

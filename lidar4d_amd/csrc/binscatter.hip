@@ -46,6 +46,9 @@
 #ifndef BS_GROUP
 #define BS_GROUP 8
 #endif
+#ifndef BS_XCD_BINS
+#define BS_XCD_BINS 1
+#endif
 #ifndef BS_UNROLL
 #define BS_UNROLL 1
 #endif
@@ -341,7 +344,12 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   constexpr int NC = 1 << D;
   constexpr int NW = RecWords<NV>::n;
   extern __shared__ long long acc[];
-  const int lvl = blockIdx.y, b = blockIdx.x;
+  // XCD-aware bin order: workgroup x runs on XCD x % 8, so bin = (x % 8) * (n / 8) + x / 8 gives every XCD a contiguous eighth of a
+  // level's bins, and the workgroups it holds at any time own ADJACENT bins.  They walk the pass-1 workgroups in the same order at
+  // about the same pace, and a pass-1 slot is sorted by bin: what one of them misses in L2, its neighbours hit (the lines at the run
+  // boundaries, the other half of every 128-byte request).  With bin = x those neighbours sat in eight different L2s.
+  const int lvl = blockIdx.y;
+  const int b = (BS_XCD_BINS && gridDim.x % 8 == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   const uint32_t size = desc.size[lvl];
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   const int nbins = (int)((size + (1u << shift) - 1) >> shift);

@@ -232,6 +232,9 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
   const int64_t n_iter = (chunk + blockDim.x - 1) / blockDim.x;
   float prep_stat = 0.0f;  // PREP: lane i collects the maximum destined for stats[i] over the whole chunk (one atomic at the end)
+  half2_t dyn_max = {(half_t)0.0f, (half_t)0.0f};  // PREP: running max |gdynT| over ALL columns (this lane's samples)
+  uint32_t dyn_bad = 0u;   // PREP: sticky "saw inf / nan in a dynamic-hash column"
+
   for (int64_t it = 0; it < n_iter; ++it) {
     const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
     const bool active = pr < hi_p;
@@ -287,23 +290,29 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       // dynamic hash: the current frame's share c0 of the upstream gradient, transposed (neighbour frames are no_grad)
       const int colD = 2 * nS * C + fd.hs.n_levels * 4;
       const int L3 = fd.hd[0].n_levels + fd.hd[1].n_levels + fd.hd[2].n_levels;
-      uint32_t dw[16];
+      // Packed halfs throughout: the product by c0 (0.5 / 0.75 / 1: one correctly rounded fp16 multiply, the same value as the
+      // fp32 product rounded to fp16), the running maximum of |.| (v_pk_max_f16, reduced over the wave ONCE, after the chunk --
+      // 24 wave-level maxima per iteration were a quarter of this part's instructions) and a sticky flag for inf / nan (the
+      // packed maximum drops nan), which turns the maximum into +inf at the end: the step is skipped whichever level overflowed.
+      const half2_t c0h = {(half_t)c0, (half_t)c0};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint4 u = make_uint4(0, 0, 0, 0);
-        if (q * 8 < L3) u = *reinterpret_cast<const uint4*>(row + colD + q * 8);
-        dw[4 * q + 0] = u.x; dw[4 * q + 1] = u.y; dw[4 * q + 2] = u.z; dw[4 * q + 3] = u.w;
-      }
+      for (int q = 0; q < 3; ++q) {
+        if (q * 8 < L3) {  // uniform
+          const uint4 u = *reinterpret_cast<const uint4*>(row + colD + q * 8);
+          const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-      for (int cidx = 0; cidx < 32; ++cidx) {  // fully unrolled: dw[] must stay in registers
-        if (cidx < L3) {                         // uniform
-          const uint32_t wv = dw[cidx >> 1];
-          const half_t hin = __builtin_bit_cast(half_t, (unsigned short)((cidx & 1) ? wv >> 16 : wv & 0xFFFFu));
-          const half_t hv = f2h_grad(h2f(hin) * c0);
-          const float a = active ? amax_nf(0.0f, h2f(hv)) : 0.0f;
-          if (active) po.gdynT[(int64_t)cidx * P + p] = hv;
-          const float m = wave_max(a);
-          if (lane == ST_DYN_MAX + cidx) prep_stat = fmaxf(prep_stat, m);
+          for (int k = 0; k < 4; ++k) {
+            const half2_t hv = __builtin_bit_cast(half2_t, w4[k]) * c0h;
+            const uint32_t wv = active ? __builtin_bit_cast(uint32_t, hv) : 0u;
+            const int c = q * 8 + 2 * k;
+            if (active) {
+              po.gdynT[(int64_t)c * P + p] = hv[0];
+              po.gdynT[(int64_t)(c + 1) * P + p] = hv[1];
+            }
+            dyn_bad |= ((wv & 0x7C007C00u) + 0x04000400u) & 0x80008000u;
+            const half2_t av = __builtin_bit_cast(half2_t, wv & 0x7FFF7FFFu);
+            dyn_max = __builtin_elementwise_max(dyn_max, av);
+          }
         }
       }
     }
@@ -398,7 +407,16 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       dst[1] = reinterpret_cast<uint4*>(out)[1];
     }
   }
-  if (PREP && prep_stat > 0.0f) atomic_max_nonneg(po.stats + __lane_id(), prep_stat);
+  if (PREP) {
+    const int lane = __lane_id();
+    const int L3 = fd.hd[0].n_levels + fd.hd[1].n_levels + fd.hd[2].n_levels;
+    // one maximum for all dynamic-hash columns: with 30 bits per contribution (dynhash_lds_kernel) a level whose gradients are
+    // a thousand times smaller than the largest level's still resolves 2^-20 of its own values (their fp16 payload: 2^-11)
+    const bool any_bad = __any(dyn_bad != 0u);
+    const float dmax = any_bad ? __builtin_inff() : wave_max(fmaxf(h2f(dyn_max[0]), h2f(dyn_max[1])));
+    if (lane >= ST_DYN_MAX && lane < ST_DYN_MAX + L3) prep_stat = fmaxf(prep_stat, dmax);
+    if (prep_stat > 0.0f) atomic_max_nonneg(po.stats + lane, prep_stat);
+  }
   __syncthreads();
   // an upstream gradient that left the fp16 range (inf / nan in dX) must reach the parameter gradients: the step is
   // then skipped and the loss scale lowered (common.h, f2h_grad)
@@ -689,7 +707,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   // With the largest |dX| of the time-plane columns known beforehand (gd_absmax, from the sigma network's backward) the prep
   // kernel's work is done by the time-plane kernel itself (planes_dyn_lds_kernel<.., PREP = true>).
   const int colsA_ = 2 * d.planes.n_scales * 8, colD_ = colsA_ + d.hs.n_levels * 4;
-  const bool fused_prep = gd_absmax && plane_rows && colD_ % 8 == 0 && L3 % 8 == 0 && L3 <= 32 && in_pad % 8 == 0 && getenv("L4D_NO_FUSED_PREP") == nullptr;
+  const bool fused_prep = gd_absmax && plane_rows && colD_ % 8 == 0 && L3 % 8 == 0 && L3 <= 24 && in_pad % 8 == 0 && getenv("L4D_NO_FUSED_PREP") == nullptr;
   if (fused_prep) {
     e = hipMemcpyAsync(stats + ST_GD_MAX, gd_absmax, sizeof(float), hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
