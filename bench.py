@@ -290,9 +290,13 @@ def parse_args():
     return ap.parse_args()
 
 
+PLUMBING = os.environ.get("L4D_BENCH_PLUMBING") == "1"  # tests/test_distributed_cpu.py: the launch / rendezvous / reduce / print
+# path of this script on a machine without GPUs -- gloo instead of RCCL, a stand-in step, L4D_BENCH_FAKE_GPUS devices "present"
+
+
 def relaunch_distributed(args):
     """--gpus N > 1 outside a torchrun environment: run N ranks of this script on this node."""
-    n_dev = torch.cuda.device_count()
+    n_dev = int(os.environ["L4D_BENCH_FAKE_GPUS"]) if PLUMBING and "L4D_BENCH_FAKE_GPUS" in os.environ else torch.cuda.device_count()
     if n_dev < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} requested but this node exposes {n_dev} GPU(s); refusing to report a "
                          f"smaller run under that label")
@@ -327,12 +331,49 @@ def timed(step, n, barrier):
     return time.perf_counter() - t0
 
 
+def _run_plumbing(args, rank, world):
+    """The multi-rank skeleton of _run with a stand-in step (a gradient-sized all-reduce on the CPU): same process-group
+    set-up (gloo for RCCL), barrier, max-over-ranks timing and rank-0 JSON line.  What a first 8-GPU run can die on that is
+    not a kernel."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    grad = torch.ones(1 << 16)
+    n_rays = WORKLOADS[args.workload][1]
+
+    def step():
+        if world > 1:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+        time.sleep(0.001)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    dt = timed(step, args.steps, barrier)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    return {"metric": "training rays/sec (64x1024 LiDAR panorama)", "value": n_rays * world * args.steps / dt, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "none", "data": "synthetic",
+            "config": {"workload": "PLUMBING TEST (L4D_BENCH_PLUMBING=1): stand-in step on the CPU over gloo, not a measurement", "parallelism": f"dp{world}"}}
+
+
 def _run(args):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if PLUMBING:
+        return _run_plumbing(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # L4D_FORCE_DIST=1: take the multi-rank code path (RCCL init, barrier, gradient all-reduce) even with one rank --

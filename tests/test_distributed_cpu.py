@@ -99,3 +99,30 @@ def test_ray_sharded_allreduce_equals_single_batch():
     assert two_phase_equal and fallback_equal
     assert ranges[1][0] == flow_range[0] < flow_range[1] < numel  # the flow field opens lr group 1
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == numel  # two contiguous lr groups
+
+
+def test_bench_multi_rank_launch_plumbing(tmp_path):
+    """bench.py --gpus 2 outside a torchrun environment: relaunch_distributed spawns two ranks through torch.distributed.run
+    on 127.0.0.1, they rendezvous, all-reduce, agree on the max-over-ranks time, and exactly ONE JSON line with n_gpus = 2
+    reaches stdout (rank 0's) -- the path the driver's first multi-GPU run takes, here with gloo, a stand-in step and two
+    pretended devices (L4D_BENCH_PLUMBING=1: no GPU in this container)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, L4D_BENCH_PLUMBING="1", L4D_BENCH_FAKE_GPUS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    # more ranks than devices: refused loudly, nothing that looks like a result on stdout
+    env["L4D_BENCH_FAKE_GPUS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=str(tmp_path))
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")
