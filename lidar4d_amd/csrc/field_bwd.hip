@@ -708,17 +708,25 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   // kernel's work is done by the time-plane kernel itself (planes_dyn_lds_kernel<.., PREP = true>).
   const int colsA_ = 2 * d.planes.n_scales * 8, colD_ = colsA_ + d.hs.n_levels * 4;
   const bool fused_prep = gd_absmax && plane_rows && colD_ % 8 == 0 && L3 % 8 == 0 && L3 <= 24 && in_pad % 8 == 0 && getenv("L4D_NO_FUSED_PREP") == nullptr;
-  if (fused_prep) {
+  // (L4D_PREP_SIDE=1, experiment: the prep kernel stays a launch of its own, but on the side stream of its consumers, next to the
+  // time-plane kernel -- possible for the same reason, the time planes' scale no longer comes from it)
+  const bool prep_side = !fused_prep && forked && gd_absmax && getenv("L4D_PREP_SIDE") != nullptr;
+  if (fused_prep || prep_side) {
     e = hipMemcpyAsync(stats + ST_GD_MAX, gd_absmax, sizeof(float), hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
-  } else {
+  }
+  if (prep_side) {
+    s_lds = (hipStream_t)l4d_side_fork(stream_, 2);
+    if (!s_lds) return 1;
+  }
+  if (!fused_prep) {
     const int staged = (colD_ % 8 == 0 && L3 % 8 == 0) ? 1 : 0;  // 16-byte pieces
     const int lds = staged ? PREP_THREADS * (colsA_ + L3 + 8) * 2 : 0;
-    L4D_LAUNCH(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, PREP_THREADS)), dim3(PREP_THREADS), lds, stream, d, xt, tinfo, P,
+    L4D_LAUNCH(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, PREP_THREADS)), dim3(PREP_THREADS), lds, prep_side ? s_lds : stream, d, xt, tinfo, P,
                (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, staged, xsoa);
   }
 
-  if (forked && !fused_prep) {  // after the prep kernel
+  if (forked && !fused_prep && !prep_side) {  // after the prep kernel
     s_lds = (hipStream_t)l4d_side_fork(stream_, 2);
     if (!s_lds) return 1;
   }

@@ -44,8 +44,35 @@ def get_precision():
     return _PRECISION
 
 
+# Gradient precision.  "fp32" (default): adjoints and parameter-gradient accumulation in fp32 -- the exact gradient of the
+# (fp16-rounded) forward, what the HIP path is compared with elementwise.  "tcnn16": what tiny-cuda-nn's fp16 build does on the
+# way back (SURVEY A.1 "Backward wrt params", A.3): every adjoint that crosses a rounding point is an fp16 number in the
+# loss-scaled domain, and a hash table's gradient is ACCUMULATED IN fp16 -- one atomicAdd(__half2) per corner, each add rounded
+# to fp16 -- then un-scaled.  Not a parity target: it measures how far tiny-cuda-nn's own arithmetic sits from the exact gradient,
+# the yardstick for the HIP path's fp16 adjoints (tests/test_gpu_c3_parity.py::test_gradient_error_vs_tcnn_fp16_accumulation).
+_GRAD_MODE = "fp32"
+_GRAD_SCALE = 128.0  # the scale fp16 adjoints carry: tiny-cuda-nn's loss_scale (128) x the GradScaler's scale
+
+
+def set_grad_precision(mode, scale=128.0):
+    global _GRAD_MODE, _GRAD_SCALE
+    assert mode in ("fp32", "tcnn16")
+    _GRAD_MODE, _GRAD_SCALE = mode, float(scale)
+
+
+def get_grad_precision():
+    return _GRAD_MODE, _GRAD_SCALE
+
+
+def _round_adjoint(g):
+    if _GRAD_MODE == "tcnn16":
+        return (g * _GRAD_SCALE).half().float() / _GRAD_SCALE
+    return g
+
+
 class _RoundHalfSTE(torch.autograd.Function):
-    """fp32 -> fp16 -> fp32 rounding, identity in backward (straight-through)."""
+    """fp32 -> fp16 -> fp32 rounding, identity in backward (straight-through; in grad mode "tcnn16" the adjoint is an fp16
+    number in the loss-scaled domain, like the tensors tiny-cuda-nn's backward hands from layer to layer)."""
 
     @staticmethod
     def forward(ctx, x):
@@ -53,7 +80,45 @@ class _RoundHalfSTE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g
+        return _round_adjoint(g)
+
+
+def fp16_scatter_accumulate(n_entries, idx, contrib):
+    """sum of contrib [N, F] into rows idx [N] of an [n_entries, F] table where EVERY add is rounded to fp16 (sequentially, in
+    the given order per entry): tiny-cuda-nn's atomicAdd(__half2) accumulation of a hash table's gradient.  Returns fp32."""
+    c16 = contrib.half()
+    order = torch.argsort(idx, stable=True)
+    idx_s, c_s = idx[order], c16[order]
+    n = idx_s.numel()
+    first = torch.ones(n, dtype=torch.bool)
+    first[1:] = idx_s[1:] != idx_s[:-1]
+    start = torch.cummax(torch.where(first, torch.arange(n), torch.zeros(n, dtype=torch.int64)), 0).values
+    rank = torch.arange(n) - start
+    acc = torch.zeros(n_entries, contrib.shape[1], dtype=torch.float16)
+    for r in range(int(rank.max()) + 1 if n else 0):
+        sel = rank == r
+        e = idx_s[sel]
+        acc[e] = (acc[e].float() + c_s[sel].float()).half()  # the exact sum of two halfs, rounded to half: what a half add gives
+    return acc.float()
+
+
+class _LevelInterpFp16Grad(torch.autograd.Function):
+    """One hash-grid level, out = sum_c w_c * table[idx_c], whose backward is tiny-cuda-nn's: dL/dy arrives as fp16 (loss-scaled),
+    each corner contributes half((float)dy * w), contributions are accumulated into an fp16 gradient table (grid.h backward)."""
+
+    @staticmethod
+    def forward(ctx, table, idx, w):
+        ctx.save_for_backward(idx, w)
+        ctx.n = table.shape[0]
+        return (w.unsqueeze(-1) * table[idx]).sum(1)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        idx, w = ctx.saved_tensors
+        dy16 = (d_out * _GRAD_SCALE).half().float()                      # [P, F]
+        contrib = (dy16.unsqueeze(1) * w.unsqueeze(-1))                   # [P, C, F] fp32 products, rounded to half below
+        g = fp16_scatter_accumulate(ctx.n, idx.reshape(-1), contrib.reshape(-1, contrib.shape[-1]))
+        return g / _GRAD_SCALE, None, None
 
 
 def rh(x):
@@ -177,6 +242,10 @@ class HashGridRef(nn.Module):
         outs = []
         for lvl in range(self.n_levels):
             idx, w = hashgrid_corner_indices(x, self.meta, lvl, self.n_input_dims)
+            if _GRAD_MODE == "tcnn16" and torch.is_grad_enabled() and self.params.requires_grad:
+                o = self.meta["offset"][lvl]
+                outs.append(_LevelInterpFp16Grad.apply(table[o:o + self.meta["size"][lvl]], idx, w))
+                continue
             vals = table[self.meta["offset"][lvl] + idx]  # [P, 2^D, F]
             outs.append((w.unsqueeze(-1) * vals).sum(1))
         return _out(rh(torch.cat(outs, -1)))
