@@ -22,14 +22,14 @@
 // share a cell, nothing to merge -- one record therefore carries BOTH: key word = [bin-local index : 13 | tz : 4 | fx : 15],
 // payload = w_yz * g (fp16); pass 2 adds payload * (1 - fx) to entry i and payload * fx to entry i ^ m.  Half the records, half
 // the bytes written and read back, half the ranking work; the weights lose nothing (fx to 2^-15, the payload is rounded to
-// fp16 once, as before).  tz code 15 = a single record: merged runs of the coarse levels, and the two halves of the rare pair
-// that straddles two bins (tz + 1 > shift: one lane in 2^shift) -- a workgroup's slot has BS_SLACK records of room for those;
-// records beyond it (a ray that runs exactly perpendicular to x through such a cell: all its samples straddle) fall back to
-// global atomics, which costs bit-reproducibility for that one launch and nothing else.
+// fp16 once, as before).  tz code 15 = a single record: merged runs of the coarse levels, and the two halves of a pair that
+// straddles two bins (tz + 1 > shift: one cell in 2^shift -- but a ray that runs nearly perpendicular to x stays in such a
+// cell for dozens of samples, so bursts of them are an everyday event).  A workgroup's slot therefore keeps room for 2^D
+// records per lane -- no case in which records do not fit, nothing that depends on atomic arrival -- while only the records
+// that exist (2^(D-1) per lane, typically) are written and read.
 #define BS_CODE_SINGLE 15u
 #define BS_KEY_BITS 13
 #define BS_FX_ONE 32767.0f
-#define BS_SLACK 64  // records (a multiple of 4: slots stay 16-byte aligned for every record width)
 #include <algorithm>
 #include <cstdlib>
 
@@ -50,7 +50,7 @@
 #define BS_XCD_BINS 1
 #endif
 #ifndef BS_UNROLL
-#define BS_UNROLL 1
+#define BS_UNROLL 4
 #endif
 
 template <int NV>
@@ -80,9 +80,8 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   // level.)  The order of the records inside a run now depends on atomic arrival; pass 2 sums in integers, so nothing downstream
   // depends on it.
   __shared__ uint32_t hist[BS_MAX_BINS], boff[BS_MAX_BINS + 1];
-  // at most NC / 2 records per lane on average: NC / 2 pair records, or NC single records per run with <= 32 runs per wave
-  constexpr int RPL = NC / 2;
-  constexpr uint32_t CAP = BS_THREADS * RPL + BS_SLACK;  // records per (workgroup, level) slot
+  // typically NC / 2 records per lane: NC / 2 pair records, or NC single records per run with <= 32 runs per wave
+  constexpr uint32_t CAP = BS_THREADS * NC;  // records per (workgroup, level) slot: every pair of every lane may have to be split
   __shared__ __attribute__((aligned(16))) uint32_t stage[CAP * NW];
   __shared__ uint32_t total_s;
   // One workgroup walks ALL levels of its tile of samples.  (Earlier: one workgroup per (tile, level), ordered level-fast
@@ -293,13 +292,13 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
       boff[b] = excl;
-      if (b <= nbins) o[(uint32_t)b * nwg32] = (uint16_t)min(excl, CAP);  // records past the slot's capacity are not staged (they go to the table directly)
+      if (b <= nbins) o[(uint32_t)b * nwg32] = (uint16_t)excl;
       excl += c[q];
     }
     if (lane == 63) {
-      total_s = min(inc, CAP);
+      total_s = inc;
       boff[BS_MAX_BINS] = inc;
-      if (nbins == BS_MAX_BINS) o[(uint32_t)BS_MAX_BINS * nwg32] = (uint16_t)min(inc, CAP);
+      if (nbins == BS_MAX_BINS) o[(uint32_t)BS_MAX_BINS * nwg32] = (uint16_t)inc;
     }
   }
   __syncthreads();
@@ -309,24 +308,11 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
       const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
       const uint32_t r = boff[b] + pos[k];
       const uint32_t code = keys[k] >> 24;
-      if (r < CAP) {
-        stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));
-        uint32_t pay[NW - 1];
-        pack_payload<NV>(vals[k], pay);
+      stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));
+      uint32_t pay[NW - 1];
+      pack_payload<NV>(vals[k], pay);
 #pragma unroll
-        for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = pay[q];
-      } else {  // slot full (see BS_SLACK): straight into the table.  Only single records can be in excess of RPL per lane.
-        const float f1 = code == BS_CODE_SINGLE ? 0.0f : (float)fxq * (1.0f / BS_FX_ONE);
-        float* o = out + (size_t)desc.offset[lvl] * NV;
-        const uint32_t e0 = keys[k] & 0xFFFFFFu, e1 = e0 ^ ((2u << (code & 15u)) - 1u);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const float v = h2f(f2h_grad(vals[k][j]));
-          if (v == 0.0f) continue;
-          atomicAdd(o + (size_t)e0 * NV + j, v * (1.0f - f1) * out_scale);
-          if (code != BS_CODE_SINGLE) atomicAdd(o + (size_t)e1 * NV + j, v * f1 * out_scale);
-        }
-      }
+      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = pay[q];
     }
   __syncthreads();
   const uint32_t total = total_s;
@@ -395,20 +381,51 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   // accesses left are the records themselves.
   const uint16_t* o0 = offs + ((uint64_t)lvl * (BS_MAX_BINS + 1) + b) * n_wg;
   const uint16_t* o1 = o0 + n_wg;
-  constexpr uint64_t SLOT = (uint64_t)(BS_THREADS * (NC / 2) + BS_SLACK) * NW;
+  constexpr uint64_t SLOT = (uint64_t)(BS_THREADS * NC) * NW;
   const uint32_t* lvl_bins = bins + (uint64_t)lvl * n_wg * SLOT;
-  uint32_t s0n = 0, s1n = 0;
-  if (grp < n_wg) { s0n = o0[grp]; s1n = o1[grp]; }
-  for (int w = grp; w < n_wg; w += NGRP) {
-    const uint32_t s0 = s0n, s1 = s1n;
-    const int wn = w + NGRP;
-    if (wn < n_wg) { s0n = o0[wn]; s1n = o1[wn]; }
-    const uint32_t* rec = lvl_bins + (uint64_t)w * SLOT;
-    for (uint32_t r = s0 + l16; r < s1; r += BS_GROUP) {
-      uint32_t wd[NW - 1];
+  // BS_UNROLL runs per group and iteration: their first records are all in flight before any is consumed (each group otherwise has
+  // ONE load outstanding -- a dependent chain of ~1.5 us round trips that left the kernel at ~2.8 TB/s of line traffic), and the next
+  // iteration's offsets are fetched while this one is processed.
+  uint32_t s0n[BS_UNROLL], s1n[BS_UNROLL];
 #pragma unroll
-      for (int q = 0; q < NW - 1; ++q) wd[q] = rec[r * NW + 1 + q];
-      add(rec[r * NW], wd);
+  for (int u = 0; u < BS_UNROLL; ++u) {
+    const int w = grp + u * NGRP;
+    s0n[u] = s1n[u] = 0u;
+    if (w < n_wg) { s0n[u] = o0[w]; s1n[u] = o1[w]; }
+  }
+  for (int w0 = grp; w0 < n_wg; w0 += NGRP * BS_UNROLL) {
+    uint32_t s0[BS_UNROLL], s1[BS_UNROLL], key0[BS_UNROLL], wd0[BS_UNROLL][NW - 1];
+    const uint32_t* rec[BS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BS_UNROLL; ++u) {
+      s0[u] = s0n[u];
+      s1[u] = s1n[u];
+      rec[u] = lvl_bins + (uint64_t)min(w0 + u * NGRP, n_wg - 1) * SLOT;
+      const uint32_t r = s0[u] + l16;
+      key0[u] = BS_CODE_SINGLE << BS_KEY_BITS;
+#pragma unroll
+      for (int q = 0; q < NW - 1; ++q) wd0[u][q] = 0u;
+      if (r < s1[u]) {  // the run's first BS_GROUP records
+        key0[u] = rec[u][r * NW];
+#pragma unroll
+        for (int q = 0; q < NW - 1; ++q) wd0[u][q] = rec[u][r * NW + 1 + q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BS_UNROLL; ++u) {  // the next iteration's offsets
+      const int wn = w0 + (BS_UNROLL + u) * NGRP;
+      s0n[u] = s1n[u] = 0u;
+      if (wn < n_wg) { s0n[u] = o0[wn]; s1n[u] = o1[wn]; }
+    }
+#pragma unroll
+    for (int u = 0; u < BS_UNROLL; ++u) {
+      add(key0[u], wd0[u]);  // an absent record carries zeros: no atomics issued
+      for (uint32_t r = s0[u] + l16 + BS_GROUP; r < s1[u]; r += BS_GROUP) {
+        uint32_t wd[NW - 1];
+#pragma unroll
+        for (int q = 0; q < NW - 1; ++q) wd[q] = rec[u][r * NW + 1 + q];
+        add(rec[u][r * NW], wd);
+      }
     }
   }
   __syncthreads();
@@ -435,7 +452,7 @@ BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
   pl.shift = bs_shift(NV);
   pl.rec_words = 1 + (NV + 1) / 2;
   pl.n_wg = ceil_div64(P, BS_THREADS);
-  const int64_t rec_per_wg = ((int64_t)BS_THREADS << (n_dims - 1)) + BS_SLACK;  // NC / 2 records per lane (pair records) + room for split pairs
+  const int64_t rec_per_wg = (int64_t)BS_THREADS << n_dims;  // room for 2^D records per lane (only those that exist are written)
   pl.off_max = 0;
   pl.off_offs = 256;
   pl.off_bins = (pl.off_offs + (int64_t)d.n_levels * pl.n_wg * (BS_MAX_BINS + 1) * 2 + 255) / 256 * 256;

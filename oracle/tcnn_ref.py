@@ -54,19 +54,32 @@ _GRAD_MODE = "fp32"
 _GRAD_SCALE = 128.0  # the scale fp16 adjoints carry: tiny-cuda-nn's loss_scale (128) x the GradScaler's scale
 
 
+_ADJ_MAX = [0.0]     # grad mode "probe": largest |adjoint| that crossed a rounding point (un-scaled), same arithmetic as "fp32"
+
+
 def set_grad_precision(mode, scale=128.0):
     global _GRAD_MODE, _GRAD_SCALE
-    assert mode in ("fp32", "tcnn16")
+    assert mode in ("fp32", "tcnn16", "probe")
     _GRAD_MODE, _GRAD_SCALE = mode, float(scale)
+    if mode == "probe":
+        _ADJ_MAX[0] = 0.0
 
 
 def get_grad_precision():
     return _GRAD_MODE, _GRAD_SCALE
 
 
+def probed_adjoint_max():
+    """Largest |adjoint| seen at a rounding point since set_grad_precision("probe"): 65504 / this bounds the loss scale under
+    which tiny-cuda-nn's fp16 backward stays finite (what a GradScaler would back off to)."""
+    return _ADJ_MAX[0]
+
+
 def _round_adjoint(g):
     if _GRAD_MODE == "tcnn16":
         return (g * _GRAD_SCALE).half().float() / _GRAD_SCALE
+    if _GRAD_MODE == "probe" and g.numel():
+        _ADJ_MAX[0] = max(_ADJ_MAX[0], float(g.abs().max()))
     return g
 
 
