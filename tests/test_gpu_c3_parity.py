@@ -146,58 +146,65 @@ def test_c3_default_model_vs_oracle(c3_models, frame):
     assert not fails, fails
 
 
-def test_gradient_error_vs_tcnn_fp16_accumulation(c3_models):
-    """How large may the gradient error of fp16 adjoints be?  The elementwise bounds above (1.5e-2 L2, 4e-2 max) are an
-    argument; this is the measurement: the oracle in grad mode "tcnn16" restates what tiny-cuda-nn's fp16
-    build does on the way back -- fp16 adjoints at every rounding point and hash-table gradients accumulated with one fp16-rounded
-    add per corner -- under the SAME total loss scale the HIP backward ran with.  Against the exact (fp32)
-    gradient of the same forward, the HIP path's error on every hash table must not exceed tiny-cuda-nn's own: it rounds the
-    same adjoints to fp16, but sums them exactly (integer fixed point) instead of in fp16.  Frame 50 with the rays of seed 67:
-    the worst combination found."""
+def test_gradient_error_vs_fp16_yardsticks(c3_models):
+    """How large may the gradient error of an fp16 implementation be?  The elementwise bounds above (1.5e-2 L2, 4e-2 max) are an
+    argument; these are the measurements, on frame 50 with the rays of seed 67 -- the worst combination
+    found -- all against the oracle's exact gradient (fp32 adjoints, fp32 accumulation):
+
+    * ``jitter``: the exact gradient of the SAME network when 2 % of its fp16 activations sit one ulp higher or lower -- what a
+      different fp32 summation order does to the last bit.  The HIP kernels and the oracle agree bit for bit on >= 98 % of the
+      sigma logits and by one ulp on the rest, so no two correct implementations can be expected to agree better than this.
+    * ``tcnn16``: tiny-cuda-nn's own backward arithmetic on the oracle's forward -- fp16 adjoints at every rounding point, hash
+      gradients accumulated with one fp16-rounded add per corner -- at the largest loss scale its fp16
+      parameter gradients survive (the HIP path keeps those in fp32 / integers and runs 64x higher).
+
+    The HIP path's error on every hash table must stay within 1.5x the two combined."""
     ref, hip = c3_models
     frame, n_rays, steps, key = 50, 64, 768, "c3n"
     fails = render_both(ref, hip, frame, n_rays, steps, key)
     assert not fails, fails
+    named = lambda: dict(ref.named_parameters())
     tables = [n for n, p in ref.named_parameters() if (n.startswith("hash_encoder.") or n.startswith("flow_net.grid_enc"))
               and p.grad is not None and float(p.grad.abs().max()) > 0]
     hip_named = dict(hip.named_parameters())
-    g32 = {n: dict(ref.named_parameters())[n].grad.detach().double().clone() for n in tables}
+    g32 = {n: named()[n].grad.detach().double().clone() for n in tables}
     ghip = {n: hip_named[n].grad.detach().double().cpu().clone() for n in tables}
     ro, rd = make_rays(n_rays, 17 + frame)
     noise = det_uniform((n_rays, steps), f"{key}{frame}", 0.0, 1.0)
     gd_ = det_uniform((1, n_rays), key + "gd", -1, 1)
     gi_ = det_uniform((1, n_rays, 2), key + "gi", -1, 1)
-    def oracle_backward(mode, scale):
+
+    def oracle_backward(mode="fp32", scale=1.0, jitter=0.0):
         ref.zero_grad()
         tcnn_ref.set_grad_precision(mode, scale)
+        tcnn_ref.set_forward_jitter(jitter, seed=1)
         try:
             o = ref.render(ro, rd, torch.tensor([[frame / 50]]), staged=False, num_steps=steps, perturb=True, noise=noise)
             ((o["depth_lidar"] * gd_).sum() + (o["image_lidar"] * gi_).sum()).backward()
         finally:
             adj = tcnn_ref.probed_adjoint_max()
             tcnn_ref.set_grad_precision("fp32")
+            tcnn_ref.set_forward_jitter(0.0)
         return adj
 
-    # tiny-cuda-nn keeps EVERY adjoint and every parameter gradient (network weights included) in fp16: the loss scale its backward
-    # survives is set by the largest of them -- the scale a GradScaler would back off to.  (The HIP path accumulates parameter
-    # gradients in fp32 / integers and ran at LAST["scale"].)
+    oracle_backward(jitter=0.02)
+    gjit = {n: named()[n].grad.detach().double().clone() for n in tables}
     adj_max = oracle_backward("probe", 1.0)
     grad_max = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None and p.numel())
-    s16 = 2.0 ** np.floor(np.log2(65504.0 / max(adj_max, grad_max)))
-    s16 = min(s16, LAST["scale"])
+    s16 = min(2.0 ** np.floor(np.log2(65504.0 / max(adj_max, grad_max))), LAST["scale"])
     oracle_backward("tcnn16", s16)
-    assert all(bool(torch.isfinite(dict(ref.named_parameters())[n].grad).all()) for n in tables)
-    g16 = {n: dict(ref.named_parameters())[n].grad.detach().double().clone() for n in tables}
-    print(f"  HIP ran at total loss scale {LAST['scale']:g}; tiny-cuda-nn's fp16 backward stays finite up to {s16:g} (largest adjoint / fp16 parameter "
-          f"gradient {max(adj_max, grad_max):.3g}).  Gradient error against the exact (fp32-accumulated) gradient, L2 / max (of the tensor's largest gradient):")
+    assert all(bool(torch.isfinite(named()[n].grad).all()) for n in tables)
+    g16 = {n: named()[n].grad.detach().double().clone() for n in tables}
+    print(f"  HIP ran at total loss scale {LAST['scale']:g}; tiny-cuda-nn's fp16 backward stays finite up to {s16:g}.  Gradient error against the "
+          f"exact gradient, L2 (max, of the tensor's largest gradient):")
     worse = []
     for n in tables:
         b = g32[n].reshape(-1)
         e = lambda a: (float((a.reshape(-1) - b).norm() / b.norm()), float((a.reshape(-1) - b).abs().max() / b.abs().max()))
-        (h_l2, h_max), (t_l2, t_max) = e(ghip[n]), e(g16[n])
-        print(f"    {n:44s} HIP {h_l2:.2e} / {h_max:.2e}    tiny-cuda-nn fp16 arithmetic {t_l2:.2e} / {t_max:.2e}")
-        if h_l2 > 1.25 * t_l2 + 1e-4:
-            worse.append((n, h_l2, t_l2))
+        (h_l2, h_max), (t_l2, t_max), (j_l2, j_max) = e(ghip[n]), e(g16[n]), e(gjit[n])
+        print(f"    {n:44s} HIP {h_l2:.2e} ({h_max:.2e})   1-ulp jitter on 2 % {j_l2:.2e} ({j_max:.2e})   tiny-cuda-nn backward arithmetic {t_l2:.2e} ({t_max:.2e})")
+        if h_l2 > 1.5 * float(np.hypot(j_l2, t_l2)) + 1e-4:
+            worse.append((n, h_l2, j_l2, t_l2))
     assert tables and not worse, worse
 
 

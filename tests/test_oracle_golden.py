@@ -237,3 +237,41 @@ def test_render_variant_configurations(golden, tag):
         _digest_close(model, g, f"{tag}.gdig.")
     finally:
         tcnn_ref.set_precision(prev)
+
+
+def test_exact_gradient_moves_by_a_percent_under_one_ulp_forward_jitter(tcnn_oracle):
+    """The floor of every elementwise gradient comparison between two fp16 implementations: on the default
+    C3 model, frame 50, move 2 % of the fp16 activations by ONE ulp -- what a different fp32 summation order does to the last
+    bit -- and the EXACT gradient (fp32 adjoints, fp32 accumulation) of the hash tables changes by about a percent (L2): the
+    contributions along a ray nearly cancel, the net gradient is small against them.  The GPU suite measures the HIP path's
+    deviation against this (tests/test_gpu_c3_parity.py::test_gradient_error_vs_fp16_yardsticks); here the yardstick itself is
+    pinned so that it cannot silently become meaningless."""
+    from oracle import fields_ref
+    from oracle.detparams import det_uniform, fill_model
+    from oracle.make_golden import test_rays as make_rays
+    S = 0.010504329815187737
+    ref = fill_model(fields_ref.LiDAR4D(near_lidar=S, far_lidar=81 * S, density_scale=30.0), seed=3)
+    frame, n_rays, steps, key = 50, 8, 768, "c3n"
+    ro, rd = make_rays(64, 17 + frame)
+    ro, rd = ro[:, :n_rays], rd[:, :n_rays]
+    noise = det_uniform((64, steps), f"{key}{frame}", 0.0, 1.0)[:n_rays]
+    gd_ = det_uniform((1, 64), key + "gd", -1, 1)[:, :n_rays]
+    gi_ = det_uniform((1, 64, 2), key + "gi", -1, 1)[:, :n_rays]
+
+    def grads(jitter):
+        ref.zero_grad()
+        tcnn_oracle.set_forward_jitter(jitter, seed=1)
+        try:
+            o = ref.render(ro, rd, torch.tensor([[frame / 50]]), staged=False, num_steps=steps, perturb=True, noise=noise)
+            ((o["depth_lidar"] * gd_).sum() + (o["image_lidar"] * gi_).sum()).backward()
+        finally:
+            tcnn_oracle.set_forward_jitter(0.0)
+        return {n: p.grad.detach().double().clone() for n, p in ref.named_parameters()
+                if n in ("hash_encoder.hash_static.params", "flow_net.grid_enc.params")}
+
+    g0, g1 = grads(0.0), grads(0.02)
+    g0b = grads(0.0)
+    for n in g0:
+        rerun = float((g0b[n] - g0[n]).norm() / g0[n].norm())  # the oracle's own run-to-run noise (threaded fp32 accumulation order)
+        rel = float((g1[n] - g0[n]).norm() / g0[n].norm())
+        assert rerun < 1e-5 and 2e-3 < rel < 2e-1, (n, rerun, rel)
