@@ -347,8 +347,10 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
     if (threadIdx.x == 0) out[((size_t)desc.offset[lvl] + lo) * NV] = __builtin_nanf("");
     return;
   }
-  const int n_el = (int)min(1u << shift, size - lo) * NV;
-  for (int i = threadIdx.x; i < n_el; i += blockDim.x) acc[i] = 0;
+  const int seg = 1 << shift;                               // entries per bin = stride of the [value][entry] accumulator layout
+  const int n_ent = (int)min(1u << shift, size - lo);
+  const int n_el = n_ent * NV;
+  for (int i = threadIdx.x; i < seg * NV; i += blockDim.x) acc[i] = 0;
   __syncthreads();
   // Fixed point: every contribution is |v| <= gmax, scaled to 30 bits and converted with ONE v_cvt_i32_f32 (a float -> int64
   // conversion is a dozen instructions on this ISA, eight of them per record: pass 2 was bound by exactly that), then
@@ -371,8 +373,11 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
     for (int j = 0; j < NV; ++j) {
       const float v = h2f(hv[j]);
       if (v != 0.0f) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[local * NV + j]), (unsigned long long)(long long)__float2int_rn(v * s0));
-        if (!single) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[other * NV + j]), (unsigned long long)(long long)__float2int_rn(v * s1));
+        // accumulators are laid out [value j][entry]: for a given j the 64 lanes of an atomic hit random ENTRIES, i.e. all 64 banks.
+        // ([entry][j] put every lane of the instruction on the same NV-th of the banks: 8-way conflicts at NV = 4 -- that, not the
+        // records' bytes or their latency, was what pass 2 had been waiting for.)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[j * seg + local]), (unsigned long long)(long long)__float2int_rn(v * s0));
+        if (!single) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[j * seg + other]), (unsigned long long)(long long)__float2int_rn(v * s1));
       }
     }
   };
@@ -431,8 +436,8 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   __syncthreads();
   const double inv = (double)out_scale / (double)fxs;
   float* o = out + ((size_t)desc.offset[lvl] + lo) * NV;
-  for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
-    const long long v = acc[i];
+  for (int i = threadIdx.x; i < n_el; i += blockDim.x) {  // i = entry * NV + j in the table's layout
+    const long long v = acc[(i % NV) * seg + i / NV];
     if (v != 0) o[i] += (float)((double)v * inv);  // sole owner of this segment
   }
 }
