@@ -387,13 +387,14 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
             for (int k = 0; k < C; ++k) vals[k] = gv[k] * wxf;
             row_scan<C>(runs, vals);
             if (!runs.tail) continue;  // (inactive lanes carry zeros and a valid clamped key: harmless in any run)
-            // channel slot rotated by the texel index: for a given k the lanes of an atomic (run tails at different texels) would
-            // otherwise all sit on the four banks = k (mod 8); rotated, texel x puts channel k on bank
-            // 8 x + (k + x) % 8 (mod 32) -- all 32.  The flush undoes the rotation.
+            // (For a given k the lanes of an atomic -- run tails at different texels -- share the four banks = k (mod 8).  Rotating
+            // the channel slots by the texel index spreads them over all 32 and was measured SLOWER, 4.14 -> 4.40 ms: the rotated
+            // offset is two more VALU instructions per atomic in a kernel that is bound by exactly those, while a constant k rides
+            // in the instruction's offset field.)
             int* dst = acc + xq * C;
 #ifndef ABL_NO_LDS_ATOMICS
 #pragma unroll
-            for (int k = 0; k < C; ++k) atomicAdd(dst + ((k + xq) & (C - 1)), __float2int_rn(vals[k]));
+            for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k]));
 #else
             asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
 #endif
@@ -441,10 +442,9 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
         for (int i = threadIdx.x; i < W * C; i += blockDim.x) {
           const int v = acc[i];
           if (v == 0) continue;
-          const int o = (i & ~(C - 1)) | ((i - (i >> 3)) & (C - 1));  // slot (k + x) % 8 of texel x holds channel k
           const float fv = (float)v * inv;
-          atomicAdd(g + (size_t)y0 * W * C + o, fv * wy0);
-          if (wy1 != 0.0f) atomicAdd(g + (size_t)y1 * W * C + o, fv * wy1);
+          atomicAdd(g + (size_t)y0 * W * C + i, fv * wy0);
+          if (wy1 != 0.0f) atomicAdd(g + (size_t)y1 * W * C + i, fv * wy1);
         }
       }
     }
@@ -540,10 +540,9 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
       }
       row_scan<C>(runs, vals);
       if (!(runs.tail && in)) continue;
-      const int tl = (ys[q] - row0) * W + xs_[q];  // channel slots rotated by the texel index (see planes_dyn_lds_kernel)
-      int* dst = &lds_i[tl * C];
+      int* dst = &lds_i[((ys[q] - row0) * W + xs_[q]) * C];
 #pragma unroll
-      for (int k = 0; k < C; ++k) atomicAdd(dst + ((k + tl) & (C - 1)), __float2int_rn(vals[k]));
+      for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k]));
     }
     }  // while (todo)
   }
@@ -553,7 +552,7 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
   if (blockIdx.x == 0 && threadIdx.x == 0 && nonfinite(stats[ST_GVS_MAX + s])) g[0] = __builtin_nanf("");  // overflowed upstream gradient
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
     const int v = lds_i[i];
-    if (v != 0) atomicAdd(g + ((i & ~(C - 1)) | ((i - (i >> 3)) & (C - 1))), (float)v * inv);  // undo the slot rotation
+    if (v != 0) atomicAdd(g + i, (float)v * inv);
   }
 }
 
