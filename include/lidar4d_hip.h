@@ -59,8 +59,9 @@ int l4d_profile_get(int32_t i, const char** name /*host out*/, float* ms /*host 
  * library-owned side streams of the launch stream and join them back before they return (event record + wait only: no host
  * synchronisation, capturable into a hipGraph).  No reference counterpart (PyTorch runs the path on one stream).
  *   l4d_streams_config(mask)  bit 0: forward encode (the xz / yz LDS evaluation next to the plane columns), bit 1: field
- *                             adjoint (sorted scatter | time planes | static planes + dynamic hash).  Default 3
- *                             (environment L4D_STREAMS overrides); 0 = everything on the launch stream.
+ *                             adjoint (sorted scatter | time planes | static planes + dynamic hash).  Default 0 = everything
+ *                             on the launch stream (environment L4D_STREAMS overrides): measured on MI355X the overlap buys
+ *                             0 +- 0.4 ms of a 40 ms step -- these kernels share their bottlenecks.
  *   l4d_streams_mask()        current setting
  *   l4d_streams_join(stream)  `stream` waits for all outstanding side-stream work
  *   l4d_side_fork(from, i) / l4d_side_join(into, i): side stream i (0..2) continues from the end of `from` and is returned
