@@ -323,13 +323,17 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   }  // levels
 }
 
-template <int D, int NV>
-__global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shift, int n_wg, int64_t P,
+// CSHIFT > 0: the bin size is a compile-time constant, so the [value][entry] accumulator addresses are ONE register (entry * 8) plus
+// immediate offsets (j * 2^CSHIFT * 8 <= 48 KB fits the DS offset field) -- the kernel issues ~100 VALU instructions per record on 8
+// wavefronts per SIMD and is bound by exactly those (SQ_ACTIVE_INST_VALU: 11 % of every wave's cycles x 8 waves).  CSHIFT = 0: run-time.
+template <int D, int NV, int CSHIFT = 0>
+__global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shift_rt, int n_wg, int64_t P,
                                                        const uint16_t* __restrict__ offs, const uint32_t* __restrict__ bins,
                                                        const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
   constexpr int NW = RecWords<NV>::n;
   extern __shared__ long long acc[];
+  const int shift = CSHIFT > 0 ? CSHIFT : shift_rt;
   // XCD-aware bin order: workgroup x runs on XCD x % 8, so bin = (x % 8) * (n / 8) + x / 8 gives every XCD a contiguous eighth of a
   // level's bins, and the workgroups it holds at any time own ADJACENT bins.  They walk the pass-1 workgroups in the same order at
   // about the same pace, and a pass-1 slot is sorted by bin: what one of them misses in L2, its neighbours hit (the lines at the run
@@ -347,7 +351,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
     if (threadIdx.x == 0) out[((size_t)desc.offset[lvl] + lo) * NV] = __builtin_nanf("");
     return;
   }
-  const int seg = 1 << shift;                               // entries per bin = stride of the [value][entry] accumulator layout
+  const int seg = CSHIFT > 0 ? (1 << CSHIFT) : (1 << shift);  // entries per bin = stride of the [value][entry] accumulator layout
   const int n_ent = (int)min(1u << shift, size - lo);
   const int n_el = n_ent * NV;
   for (int i = threadIdx.x; i < seg * NV; i += blockDim.x) acc[i] = 0;
@@ -369,16 +373,16 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
     const float f1 = single ? 0.0f : (float)(w0 >> (BS_KEY_BITS + 4)) * (1.0f / BS_FX_ONE);
     const float s0 = (1.0f - f1) * fxs, s1 = f1 * fxs;
     const uint32_t other = local ^ ((2u << code) - 1u);
+    // accumulators are laid out [value j][entry]: for a given j the 64 lanes of an atomic hit random ENTRIES, i.e. all 64 banks.
+    // ([entry][j] put every lane of the instruction on the same NV-th of the banks: 8-way conflicts at NV = 4.)
+    unsigned long long* a0 = reinterpret_cast<unsigned long long*>(acc) + local;
+    unsigned long long* a1 = reinterpret_cast<unsigned long long*>(acc) + other;
+    if ((wd[0] | (NW > 2 ? wd[NW - 2] : 0u)) == 0u) return;  // an absent / all-zero record
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const float v = h2f(hv[j]);
-      if (v != 0.0f) {
-        // accumulators are laid out [value j][entry]: for a given j the 64 lanes of an atomic hit random ENTRIES, i.e. all 64 banks.
-        // ([entry][j] put every lane of the instruction on the same NV-th of the banks: 8-way conflicts at NV = 4 -- that, not the
-        // records' bytes or their latency, was what pass 2 had been waiting for.)
-        atomicAdd(reinterpret_cast<unsigned long long*>(&acc[j * seg + local]), (unsigned long long)(long long)__float2int_rn(v * s0));
-        if (!single) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[j * seg + other]), (unsigned long long)(long long)__float2int_rn(v * s1));
-      }
+      atomicAdd(a0 + j * seg, (unsigned long long)(long long)__float2int_rn(v * s0));
+      if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)__float2int_rn(v * s1));
     }
   };
   // The runs of this bin, one per pass-1 workgroup, consecutive groups take consecutive workgroups: their offsets
@@ -490,9 +494,16 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   {                                                                                                                          \
     L4D_LAUNCH((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
                        g_col, pre_scale, pl.shift, (int64_t)pl.n_wg, offs, bins, lvl_max, out, out_scale);                                     \
-    (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);              \
-    L4D_LAUNCH((bin_pass2_kernel<D, V>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
-                       lvl_max, out, out_scale);                                                                            \
+    constexpr int DEF = V == 4 ? 11 : V == 2 ? 12 : 13;  /* bs_shift()'s defaults: compile-time bin size */                       \
+    if (pl.shift == DEF) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V, DEF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);       \
+      L4D_LAUNCH((bin_pass2_kernel<D, V, DEF>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins,  \
+                 lvl_max, out, out_scale);                                                                                   \
+    } else {                                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);            \
+      L4D_LAUNCH((bin_pass2_kernel<D, V>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins,       \
+                 lvl_max, out, out_scale);                                                                                   \
+    }                                                                                                                        \
   }
   if (n_dims == 3 && NV == 4) BS_LAUNCH(3, 4)
   else if (n_dims == 3 && NV == 2) BS_LAUNCH(3, 2)
