@@ -125,6 +125,8 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
 #pragma unroll
     for (int j = 0; j < NV; ++j) gnext[j] = grow[j];
   }
+  for (int i = threadIdx.x; i < BS_MAX_BINS; i += BS_THREADS) hist[i] = 0;
+  __syncthreads();
   for (int lvl = 0; lvl < n_lv; ++lvl) {
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   const uint32_t size = desc.size[lvl];
@@ -156,9 +158,8 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
 #pragma unroll
     for (int j = 0; j < NV; ++j) gnext[j] = grow[(lvl + 1) * NV + j];
   }
-  __syncthreads();  // the previous level's copy-out has finished reading the staging buffer / bin offsets
-  for (int i = threadIdx.x; i < BS_MAX_BINS; i += BS_THREADS) hist[i] = 0;
-  __syncthreads();
+  // (No barrier here: the histogram was left zeroed by the scan of the previous binned level, and this level's staging writes and
+  // bin offsets come two barriers down, behind every wavefront's copy-out of the previous level -- three barriers per level, not five.)
 
   Cell<D> c = locate<D>(xin, desc.scale[lvl]);
   uint32_t keys[NC];
@@ -273,6 +274,7 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
       c[q] = b < nbins ? hist[b] : 0u;
+      if (b < nbins) hist[b] = 0u;  // ready for the next level (every rank of this level has been handed out: barrier above)
       sum += c[q];
     }
     uint32_t inc = sum;
