@@ -131,7 +131,9 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   const uint32_t size = desc.size[lvl];
   const int nbins = (int)((size + (1u << shift) - 1) >> shift);
-  const bool binned = hashed && nbins <= BS_MAX_BINS && nbins > 1;
+  // (binned levels: hashed with a power-of-two table -- what every hashed level of a tiny-cuda-nn grid is; anything else takes the
+  // atomic path below -- so that their index is the plain xor-and-mask of hashgrid_dev.h grid_index_fast)
+  const bool binned = hashed && is_pow2(size) && nbins <= BS_MAX_BINS && nbins > 1;
 
   if (g_in_regs) {  // this level's NV halfs out of the preloaded dwords
     uint32_t w[(NV + 1) / 2];
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
 #pragma unroll
       for (int d = 1; d < D; ++d) wyz *= ((2 * q) >> d) & 1 ? c.frac[d] : 1.0f - c.frac[d];
       (void)w0;
-      const uint32_t k0 = grid_index<D>(g0, desc.res[lvl], size, true), k1 = grid_index<D>(g1, desc.res[lvl], size, true);
+      const uint32_t k0 = grid_index_fast<D>(g0, size - 1u), k1 = grid_index_fast<D>(g1, size - 1u);
       const uint32_t m = k0 ^ k1;
       const bool paired = (m & (m + 1u)) == 0u && m != 0u && (m >> shift) == 0u && __popc(m) <= (int)BS_CODE_SINGLE;
       keys[q] = k0 | ((uint32_t)(__popc(m) - 1) << 24);
@@ -227,7 +229,7 @@ __global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kerne
   for (int k = 0; k < NC; ++k) {
     uint32_t gg[D];
     const float w = corner<D>(c, k, gg);
-    keys[k] = grid_index<D>(gg, desc.res[lvl], size, hashed);
+    keys[k] = binned ? grid_index_fast<D>(gg, size - 1u) : grid_index<D>(gg, desc.res[lvl], size, hashed);
 #pragma unroll
     for (int j = 0; j < NV; ++j) vals[k][j] = w * gv[j];
     if (binned) {
@@ -345,7 +347,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   const uint32_t size = desc.size[lvl];
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   const int nbins = (int)((size + (1u << shift) - 1) >> shift);
-  if (!hashed || nbins > BS_MAX_BINS || nbins <= 1 || b >= nbins) return;
+  if (!hashed || !is_pow2(size) || nbins > BS_MAX_BINS || nbins <= 1 || b >= nbins) return;
   const float gmax = lvl_max[lvl];
   if (!(gmax > 0.0f)) return;
   const uint32_t lo = (uint32_t)b << shift;

@@ -23,6 +23,7 @@
 #include "binscatter.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #define ST_GVS_MAX 0     // [0..8)  max |gvs| per plane scale
 #define ST_GD_MAX 8      // max |dX dynamic-plane columns|
@@ -591,19 +592,24 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
   const bool hashed = (g.hashed_mask >> lvl) & 1u;
   const half_t* gcol = gdynT + (int64_t)cidx * P;
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {  // hashed 2-D cells: no same-address pile-up
-    const float go = h2f(gcol[p]);
-    if (go == 0.0f) continue;
-    const float q[2] = {xt[(int64_t)ca * P + p], xt[(int64_t)cb * P + p]};
-    Cell<2> c = locate<2>(q, scale);
+  auto walk = [&](auto fast_tag) {  // FAST: hashed level with a power-of-two table (block-uniform; hashgrid_dev.h grid_index_fast)
+    constexpr bool FAST = decltype(fast_tag)::value;
+    for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {  // hashed 2-D cells: no same-address pile-up
+      const float go = h2f(gcol[p]);
+      if (go == 0.0f) continue;
+      const float q[2] = {xt[(int64_t)ca * P + p], xt[(int64_t)cb * P + p]};
+      Cell<2> c = locate<2>(q, scale);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint32_t gv[2];
-      const float w = corner<2>(c, k, gv);
-      const int idx = (int)grid_index<2>(gv, res, size, hashed) - lo;
-      if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)(long long)__float2int_rn(go * w * fxs));
+      for (int k = 0; k < 4; ++k) {
+        uint32_t gv[2];
+        const float w = corner<2>(c, k, gv);
+        const int idx = (int)(FAST ? grid_index_fast<2>(gv, size - 1u) : grid_index<2>(gv, res, size, hashed)) - lo;
+        if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)(long long)__float2int_rn(go * w * fxs));
+      }
     }
-  }
+  };
+  if (hashed && is_pow2(size)) walk(std::true_type{});
+  else walk(std::false_type{});
   __syncthreads();
   const double inv = 1.0 / (double)fxs;
   float* H = Hbuf + tasks.hoff[task] + lo;

@@ -8,6 +8,7 @@
 // This is the direct-gather formulation (every table entry is fetched through L1/L2).
 #include "field_dev.h"
 #include <algorithm>
+#include <type_traits>
 
 // tinfo: [0]=t, [1]=t1, [2]=t2, [3]=has_fwd, [4]=has_bwd, [5]=frame_idx  (model/lidar4d.py:143,157-173)
 __global__ void time_setup_kernel(const float* __restrict__ t, int num_frames, float* __restrict__ tinfo) {
@@ -293,8 +294,12 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
   __syncthreads();
   half_t* out = hdT + (int64_t)col * P;
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  // one sample: the three frames' lookups from the staged table, blended
-  auto eval = [&](const float xa[3], const float xb[3]) -> half_t {
+  // one sample: the three frames' lookups from the staged table, blended.  FAST (block-uniform: hashed level, power-of-two table --
+  // every level of the reference configuration): the index is two multiplies and a mask, without the generic form's per-lookup
+  // addressing decision (the kernel is bound by its VALU instructions: SQ_ACTIVE_INST_VALU 30 % of every wave's cycles x 4 waves).
+  const bool fast_level = hashed && is_pow2(size);
+  auto eval = [&](auto fast_tag, const float xa[3], const float xb[3]) -> half_t {
+    constexpr bool FAST = decltype(fast_tag)::value;
     float r[3];
     PairCorners pc0;  // frame 0's corner entries: reused by a warped frame whose point lies in the same cell
     Cell<2> c0;
@@ -314,7 +319,7 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
       for (int cn = 0; cn < 4; ++cn) {
         uint32_t gv[2];
         (void)corner<2>(c, cn, gv);
-        if (!same) pc.e[cn] = lds_tab[grid_index<2>(gv, res, size, hashed)];
+        if (!same) pc.e[cn] = lds_tab[FAST ? grid_index_fast<2>(gv, size - 1u) : grid_index<2>(gv, res, size, hashed)];
       }
       if (e == 0) {
         pc0 = pc;
@@ -338,16 +343,20 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
       xb[e] = b + h2f(flowT[(int64_t)((e - 1) * 3 + cb) * P + p]);
     }
   };
-  for (int64_t p0 = lo_p + threadIdx.x; p0 < hi_p; p0 += 2 * DH_THREADS) {
-    const int64_t p1 = p0 + DH_THREADS;
-    const bool ok1 = p1 < hi_p;
-    const int64_t q1 = ok1 ? p1 : p0;
-    float xa0[3], xb0[3], xa1[3], xb1[3];
-    load(p0, xa0, xb0);
-    load(q1, xa1, xb1);
-    out[p0] = eval(xa0, xb0);
-    if (ok1) out[p1] = eval(xa1, xb1);
-  }
+  auto walk = [&](auto fast_tag) {
+    for (int64_t p0 = lo_p + threadIdx.x; p0 < hi_p; p0 += 2 * DH_THREADS) {
+      const int64_t p1 = p0 + DH_THREADS;
+      const bool ok1 = p1 < hi_p;
+      const int64_t q1 = ok1 ? p1 : p0;
+      float xa0[3], xb0[3], xa1[3], xb1[3];
+      load(p0, xa0, xb0);
+      load(q1, xa1, xb1);
+      out[p0] = eval(fast_tag, xa0, xb0);
+      if (ok1) out[p1] = eval(fast_tag, xa1, xb1);
+    }
+  };
+  if (fast_level) walk(std::true_type{});
+  else walk(std::false_type{});
 }
 
 // ---- sampling that also emits the normalised (x, t) rows the field kernels read --------------------

@@ -52,6 +52,18 @@ __device__ __forceinline__ uint32_t grid_index(const uint32_t g[D], uint32_t res
   return ((size & (size - 1)) == 0) ? (idx & (size - 1)) : (idx % size);
 }
 
+// Hashed level with a power-of-two table (every hashed level tiny-cuda-nn's host code produces: n = 2^log2_hashmap_size): no
+// stride walk, no modulo, no per-call decision -- callers test (hashed && size power of two) ONCE per level / launch and take
+// this path in their inner loops (the generic form above compiles both addressings and a uniform branch into every lookup).
+template <int D>
+__device__ __forceinline__ uint32_t grid_index_fast(const uint32_t g[D], uint32_t mask) {
+  uint32_t idx = g[0];
+  if (D > 1) idx ^= g[1] * PRIME1;
+  if (D > 2) idx ^= g[2] * PRIME2;
+  return idx & mask;
+}
+__host__ __device__ __forceinline__ bool is_pow2(uint32_t v) { return v != 0u && (v & (v - 1u)) == 0u; }
+
 template <int D>
 struct Cell {
   uint32_t cell[D];

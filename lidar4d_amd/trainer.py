@@ -648,13 +648,19 @@ class Trainer:
                 gen = getattr(self.dataset, "gen", None)
                 if not outside and gen is not None and hasattr(graph, "register_generator_state"):
                     graph.register_generator_state(gen)
-                with torch.cuda.graph(graph, pool=st["pool"], stream=side):
-                    loss_g = self._step_device_work(draw()).detach()
+                keep = os.environ.get("L4D_GRAPH_KEEP_WS") == "1"
+                if keep:
+                    ops.KEEP_WORKSPACES = []
+                try:
+                    with torch.cuda.graph(graph, pool=st["pool"], stream=side):
+                        loss_g = self._step_device_work(draw()).detach()
+                finally:
+                    held, ops.KEEP_WORKSPACES = ops.KEEP_WORKSPACES, None
             finally:
                 _lib.lib().l4d_streams_config(mask_was)
             if st["pool"] is None:
                 st["pool"] = graph.pool()
-            st["graphs"][frame] = {"graph": graph, "loss": loss_g, "static": static}
+            st["graphs"][frame] = {"graph": graph, "loss": loss_g, "static": static, "held": held}
             self._step_host_bookkeeping()
             return loss
         if rec["static"] is not None:
