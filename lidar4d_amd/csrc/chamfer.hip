@@ -49,6 +49,13 @@ __global__ void __launch_bounds__(CH_THREADS) chamfer_nn_kernel(const float* __r
   }
 }
 
+// the workspace is initialised by a kernel, not hipMemsetAsync: a captured step whose graph held this memset node faulted at its
+// second replay (ROCm 7.2, linear graph; tools/graph_probe.py), the same graph without the node replays
+__global__ void chamfer_fill_kernel(unsigned long long* __restrict__ best, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) best[i] = ~0ull;
+}
+
 __global__ void chamfer_unpack_kernel(const unsigned long long* __restrict__ best, int64_t total, float* __restrict__ dist,
                                       int32_t* __restrict__ idx) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,8 +101,8 @@ extern "C" int l4d_chamfer_fwd(const float* xyz1, const float* xyz2, int32_t b, 
   hipStream_t stream = (hipStream_t)stream_;
   unsigned long long* best1 = (unsigned long long*)workspace;
   unsigned long long* best2 = best1 + (size_t)b * n;
-  hipError_t e = hipMemsetAsync(workspace, 0xff, (size_t)b * ((size_t)n + m) * 8, stream);
-  if (e != hipSuccess) { l4d_set_error((int)e, "l4d_chamfer_fwd memset"); return (int)e; }
+  const int64_t total = (int64_t)b * ((int64_t)n + m);
+  L4D_LAUNCH(chamfer_fill_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, best1, total);
   {
     const int segs = seg_for(n, m, b), seg_len = (m + segs - 1) / segs;
     L4D_LAUNCH(chamfer_nn_kernel, dim3((n + CH_THREADS - 1) / CH_THREADS, (m + seg_len - 1) / seg_len, b), dim3(CH_THREADS), 0,

@@ -136,6 +136,11 @@ __global__ void lidar_unpack_kernel(const unsigned long long* __restrict__ best,
   if (inten) inten[i] = pts[(size_t)(unsigned int)(k & 0xffffffffu) * 4 + 3];
 }
 
+__global__ void pano_fill_kernel(unsigned long long* __restrict__ best, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) best[i] = ~0ull;
+}
+
 extern "C" int64_t l4d_lidar_to_pano_workspace(int32_t H, int32_t W) { return (int64_t)H * W * 8; }
 
 extern "C" int l4d_lidar_to_pano(const float* points, int64_t n, int32_t H, int32_t W, double fov_up, double fov, float max_depth,
@@ -144,9 +149,9 @@ extern "C" int l4d_lidar_to_pano(const float* points, int64_t n, int32_t H, int3
   const int64_t npix = (int64_t)H * W;
   if (npix == 0) return 0;
   if (n >= (1ll << 32)) { l4d_set_error(1, "l4d_lidar_to_pano: more than 2^32 points"); return 1; }
-  hipError_t e = hipMemsetAsync(workspace, 0xff, (size_t)npix * 8, stream);
-  if (e != hipSuccess) { l4d_set_error((int)e, "l4d_lidar_to_pano memset"); return (int)e; }
   unsigned long long* best = (unsigned long long*)workspace;
+  // filled by a kernel: a 0xff hipMemsetAsync node made a captured graph fault at its second replay (see chamfer.hip)
+  L4D_LAUNCH(pano_fill_kernel, dim3((unsigned)ceil_div64(npix, 256)), dim3(256), 0, stream, best, npix);
   if (n > 0)
     L4D_LAUNCH(lidar_bin_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, stream, points, n, (int)H, (int)W,
                        (float)((fov - fov_up) / 180 * CV_PI), (float)(2 * CV_PI / W), (float)(fov / 180 * CV_PI / H), max_depth, best);

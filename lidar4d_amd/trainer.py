@@ -652,7 +652,8 @@ class Trainer:
                 if keep:
                     ops.KEEP_WORKSPACES = []
                 try:
-                    with torch.cuda.graph(graph, pool=st["pool"], stream=side):
+                    pool = None if os.environ.get("L4D_GRAPH_POOL") == "separate" else st["pool"]  # (debugging: one pool per graph)
+                    with torch.cuda.graph(graph, pool=pool, stream=side):
                         loss_g = self._step_device_work(draw()).detach()
                 finally:
                     held, ops.KEEP_WORKSPACES = ops.KEEP_WORKSPACES, None

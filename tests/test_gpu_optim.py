@@ -268,11 +268,25 @@ def test_flow_loss_overflow_is_skipped_not_clipped():
         scales.append(tr.scaler.get_scale())
     assert scales == [2.0 ** (39 - i) for i in range(6)], scales   # every step overflowed and halved the scale
     assert torch.equal(m._store.flat, init) and int(tr.opt.steps.max()) == 0
-    # the flow field's own gradient is what overflows here, not only the render path: loss = flow loss alone
-    tr.opt.zero_grad()
+    # the flow field's own adjoint (model.flow() outside the fused node) normalises its fp16 range on the device from the
+    # upstream gradient it receives: whatever power of two the caller scaled the loss by comes back out exactly ...
     from lidar4d_amd.trainer import flow_loss
-    fl = flow_loss(m, tr.pc_list, tr.pc_ground_list, data.batch_for(20)["time"], data.num_frames, frame_idx=20)
-    (fl * 2.0 ** 40).backward()
+    tg = torch.tensor([0.37], device=DEV)
+    grads = []
+    for s in (1.0, 2.0 ** 40):
+        tr.opt.zero_grad()
+        fl = flow_loss(m, tr.pc_list, tr.pc_ground_list, data.batch_for(20)["time"], data.num_frames, t_ground=tg, frame_idx=20)
+        (fl * s).backward()
+        grads.append([p.grad.detach().clone() for p in m.flow_net.parameters()])
+    for g1, g40 in zip(*grads):
+        assert bool(torch.isfinite(g40).all()) and float(g1.abs().max()) > 0
+        # (bit-equal up to the order of the dW atomics: compare at 1e-4 of the tensor's largest gradient)
+        err = float((g1.double() * 2.0 ** 40 - g40.double()).abs().max()) / (float(g1.abs().max()) * 2.0 ** 40)
+        assert err < 1e-4, "the flow adjoint must be invariant under power-of-two loss scales (%.2e)" % err
+    # ... and an upstream gradient that is itself non-finite surfaces as inf / nan (never as a clipped number)
+    tr.opt.zero_grad()
+    fl = flow_loss(m, tr.pc_list, tr.pc_ground_list, data.batch_for(20)["time"], data.num_frames, t_ground=tg, frame_idx=20)
+    (fl * 3.0e38).backward()
     g = m.flow_net.grid_enc.params.grad
     assert not bool(torch.isfinite(g).all()), "an overflowing flow-loss gradient must surface as inf / nan, not as a clipped number"
 
