@@ -150,6 +150,8 @@ def kernel_models(model, P, M):
     rec2 = 4 * 8
     m["bin_pass1_kernel<3, 2>"] = dict(bound="hbm", bytes=(16 + 4 * Lf + Lf * rec2) * P, note="flow grid records")
     m["bin_pass2_kernel<3, 2>"] = dict(bound="hbm", bytes=Lf * rec2 * P, note="flow grid records")
+    for k in ("bin_pass2_kernel<3, 4>", "bin_pass2_kernel<3, 2>"):  # launch-site names of the compile-time / run-time bin size variants
+        m[k[:-1] + ", DEF>"] = m[k[:-1] + ", 0>"] = m[k]
     m["field_bwd_prep_kernel"] = dict(bound="hbm", bytes=(16 + X + 3 * nS * 16 + 2 * n_dyn) * P, note="dX row read, plane factors + transposed dyn gradient written")
     m["planes_dyn_lds_kernel<true, false>"] = m["planes_dyn_lds_kernel<false, false>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
     m["planes_dyn_lds_kernel<true, true>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32 + 3 * nS * 16 + 2 * n_dyn + 12) * P,
@@ -431,6 +433,9 @@ def _run(args):
             t0 = time.perf_counter()
             for k in range(data.num_frames):
                 trainer.train_step_graphed(k)
+                if os.environ.get("L4D_BENCH_TRACE"):
+                    torch.cuda.synchronize()
+                    sys.stderr.write("captured frame %d\n" % k), sys.stderr.flush()
             torch.cuda.synchronize()
             capture_s = time.perf_counter() - t0
             from lidar4d_amd.params import bump_epoch
@@ -469,6 +474,9 @@ def _run(args):
         while applied_in_a_row < 51 and settle_steps < 250:
             step()
             settle_steps += 1
+            if os.environ.get("L4D_BENCH_TRACE"):
+                torch.cuda.synchronize()
+                sys.stderr.write("settle step %d done\n" % settle_steps), sys.stderr.flush()
             now = int(opt_.steps.max())
             applied_in_a_row = applied_in_a_row + 1 if now > last else 0
             last = now

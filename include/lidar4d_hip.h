@@ -365,6 +365,11 @@ int l4d_adam_step_ranges(float* param, const float* grad, float* exp_avg, float*
  * growth_interval consecutive clean steps, clear state[2], refresh state[3] (call after the Adam step). */
 int l4d_grad_nonfinite_check(const float* grad, int64_t n, float* scaler_state, void* stream);
 int l4d_scaler_update(float* scaler_state, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream);
+/* out[0] = max |x[i]| over n fp32 values (x 16-byte aligned), +inf if any of them is inf / nan.  Replaces the torch
+ * reductions ``x.abs().max()`` in the step (lidar4d_amd/fused.py: bound of the plane values for the fixed-point accumulators;
+ * flow_field.py: normalisation of the scene-flow adjoint): torch's multi-block reduce zeroes its semaphores with
+ * hipMemsetAsync, and a captured step must not contain memset nodes (see chamfer.hip / DESIGN.md section 5). */
+int l4d_absmax_f32(const float* x, int64_t n, float* out, void* stream);
 /* gates[i1] = gates[i2] = 1 for the pair of time slices HashGridT.forward blends at time tinfo[0] (hash_field.py:79-85):
  * the slices whose tables receive a gradient in this step (tinfo: l4d_time_setup). */
 int l4d_mark_time_slices(const float* tinfo, int32_t n_slices, float* gates, void* stream);

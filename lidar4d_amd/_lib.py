@@ -107,6 +107,7 @@ SIGNATURES = {
     "l4d_adam_step": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, F32, F32, P],
     "l4d_adam_step_ranges": [P, P, P, P, P, I32, PI64, PI64, P, PI32, P, P, P, F32, F32, F32, F32, P, F32, P],
     "l4d_grad_nonfinite_check": [P, I64, P, P],
+    "l4d_absmax_f32": [P, I64, P, P],
     "l4d_scaler_update": [P, F32, F32, I32, P],
     "l4d_mark_time_slices": [P, I32, P, P],
     "l4d_profile_enable": [I32],

@@ -482,8 +482,7 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   float* lvl_max = (float*)(ws + pl.off_max);
   uint16_t* offs = (uint16_t*)(ws + pl.off_offs);
   uint32_t* bins = (uint32_t*)(ws + pl.off_bins);
-  hipError_t e = hipMemsetAsync(ws, 0, 256, stream);
-  if (e != hipSuccess) { l4d_set_error((int)e, "bs_scatter memset"); return (int)e; }
+  l4d_fill_async(ws, 0u, 256, stream);
   BsCols c;
   for (int d = 0; d < 3; ++d) c.c[d] = d < n_dims ? cols[d] : 0;
   if ((int64_t)desc.n_levels * (BS_MAX_BINS + 1) * pl.n_wg >= ((int64_t)1 << 32)) { l4d_set_error(1, "bs_scatter: too many points for one launch"); return 1; }

@@ -64,6 +64,27 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 // touches are fetched into one L2 instead of all eight.  Launch xcd_grid(n) blocks; tiles >= n are idle.
 static inline int64_t xcd_grid(int64_t n_tiles) { return ceil_div64(n_tiles, 8) * 8; }
 #ifdef __HIPCC__
+// Device memory is initialised and small device values are moved by KERNELS, never by hipMemsetAsync / hipMemcpyAsync: a captured
+// training step whose graph held such a node (the chamfer workspace's 0xff fill) faulted at its second replay on ROCm 7.2 when the
+// graph was a single chain of nodes, and replayed once the node was a kernel (tools/graph_probe.py).
+static __global__ void l4d_fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static __global__ void l4d_copy_u32_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+// fill `bytes` (a multiple of 4) at p with the 32-bit pattern v
+static inline void l4d_fill_async(void* p, uint32_t v, int64_t bytes, hipStream_t stream) {
+  const int64_t n = bytes / 4;
+  if (n <= 0) return;
+  const int64_t blocks = (n + 255) / 256;
+  L4D_LAUNCH(l4d_fill_u32_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, (uint32_t*)p, v, n);
+}
+static inline void l4d_copy_words_async(void* dst, const void* src, int n_words, hipStream_t stream) {
+  if (n_words <= 0) return;
+  L4D_LAUNCH(l4d_copy_u32_kernel, dim3((unsigned)((n_words + 63) / 64)), dim3(64), 0, stream, (uint32_t*)dst, (const uint32_t*)src, n_words);
+}
 __device__ __forceinline__ int64_t xcd_tile(int64_t block, int64_t n_blocks /* multiple of 8 */) {
   return (block & 7) * (n_blocks >> 3) + (block >> 3);
 }

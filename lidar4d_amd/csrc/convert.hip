@@ -90,7 +90,7 @@ extern "C" int l4d_pano_to_lidar(const float* pano, const float* intensities, in
                                  float* points, int32_t* count, void* workspace, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t n = (int64_t)H * W;
-  if (n == 0) return (int)hipMemsetAsync(count, 0, 4, stream);
+  if (n == 0) { l4d_fill_async(count, 0u, 4, stream); return 0; }
   const unsigned blocks = (unsigned)ceil_div64(n, CV_THREADS);
   int32_t* counts = (int32_t*)workspace;
   L4D_LAUNCH(pano_count_kernel, dim3(blocks), dim3(CV_THREADS), 0, stream, pano, n, counts);

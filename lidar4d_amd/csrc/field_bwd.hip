@@ -699,9 +699,8 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   half_t* gvs = (half_t*)(ws + w.gvs);
   half_t* gdynT = (half_t*)(ws + w.gdynT);
   float* xsoa = (float*)(ws + w.xsoa);  // [3][P] coordinates, written by the prep kernel
-  hipError_t e = hipMemsetAsync(ws, 0, w.gvs, stream);  // stats + Hbuf
-  if (e == hipSuccess) e = hipMemcpyAsync(stats + ST_VMAX, plane_abs_max, sizeof(float), hipMemcpyDeviceToDevice, stream);
-  if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
+  l4d_fill_async(ws, 0u, (int64_t)w.gvs, stream);  // stats + Hbuf
+  l4d_copy_words_async(stats + ST_VMAX, plane_abs_max, 1, stream);
 
   // static 3-D hash grid: sorted scatter of dX[:, 2*nS*8 + lvl*4 ..] (binscatter.hip)
   {
@@ -722,8 +721,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   // time-plane kernel -- possible for the same reason, the time planes' scale no longer comes from it)
   const bool prep_side = !fused_prep && forked && gd_absmax && getenv("L4D_PREP_SIDE") != nullptr;
   if (fused_prep || prep_side) {
-    e = hipMemcpyAsync(stats + ST_GD_MAX, gd_absmax, sizeof(float), hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) { l4d_set_error((int)e, "l4d_density_encode_bwd setup"); return (int)e; }
+    l4d_copy_words_async(stats + ST_GD_MAX, gd_absmax, 1, stream);
   }
   if (prep_side) {
     s_lds = (hipStream_t)l4d_side_fork(stream_, 2);

@@ -459,8 +459,7 @@ extern "C" int l4d_hashgrid_t_bwd(const l4d_grid_desc* desc, const float* x, int
   int64_t n_entries = 0;
   for (int l = 0; l < desc->n_levels; ++l) n_entries += desc->size[l];
   const int FO = desc->n_features / 4;
-  hipError_t e = hipMemsetAsync(scratch, 0, (size_t)n_entries * FO * sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) { l4d_set_error((int)e, "l4d_hashgrid_t_bwd memset"); return (int)e; }
+  l4d_fill_async(scratch, 0u, n_entries * FO * (int64_t)sizeof(float), (hipStream_t)stream);
   dim3 block(256);
   if (workspace && dout_is_half) {
     // sorted scatter (binscatter.hip): no scattered global atomics on the hashed levels

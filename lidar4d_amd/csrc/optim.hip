@@ -3,6 +3,7 @@
 // (0.9, 0.99), eps 1e-15, no weight decay, no amsgrad) and emits the fp16 compute copy of the
 // parameters in the same pass (tiny-cuda-nn casts its fp32 master parameters to fp16 every forward).
 #include "common.h"
+#include "wave_dev.h"
 #include <algorithm>
 
 __global__ void __launch_bounds__(256) cast_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int64_t n) {
@@ -164,6 +165,24 @@ __global__ void __launch_bounds__(256) nonfinite_check_kernel(const float* __res
   if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.0f;  // benign race: everybody stores the same value
 }
 
+// max |x| over n floats into out[0] (zeroed by the caller's fill); any inf / nan makes it +inf.  One atomic per wave that can
+// still raise the value (wave_dev.h atomic_max_nonneg).
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  float m = 0.0f;
+  bool bad = false;
+  for (int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i4 < n; i4 += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (i4 + 3 < n) {
+      const float4_t v = *reinterpret_cast<const float4_t*>(x + i4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { m = fmaxf(m, fabsf(v[k])); bad |= !(fabsf(v[k]) <= 3.402823466e38f); }
+    } else {
+      for (int64_t i = i4; i < n; ++i) { m = fmaxf(m, fabsf(x[i])); bad |= !(fabsf(x[i]) <= 3.402823466e38f); }
+    }
+  }
+  m = __any(bad) ? __builtin_inff() : wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomic_max_nonneg(out, m);
+}
+
 // torch.cuda.amp.GradScaler.update(): halve after a non-finite step, double after growth_interval clean steps
 __global__ void scaler_update_kernel(float* __restrict__ state, float growth, float backoff, int interval) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -225,6 +244,16 @@ extern "C" int l4d_grad_nonfinite_check(const float* grad, int64_t n, float* sca
   const int64_t blocks = std::min<int64_t>(2048, ceil_div64(ceil_div64(n, 4), 256));
   L4D_LAUNCH(nonfinite_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, n, scaler_state);
   L4D_LAUNCH_CHECK("l4d_grad_nonfinite_check");
+  return 0;
+}
+
+extern "C" int l4d_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
+  l4d_fill_async(out, 0u, sizeof(float), (hipStream_t)stream);
+  if (n == 0) return 0;
+  if ((uintptr_t)x & 15) { l4d_set_error(1, "l4d_absmax_f32: x must be 16-byte aligned"); return 1; }
+  const int64_t blocks = std::min<int64_t>(2048, ceil_div64(ceil_div64(n, 4), 256));
+  L4D_LAUNCH(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  L4D_LAUNCH_CHECK("l4d_absmax_f32");
   return 0;
 }
 

@@ -427,8 +427,7 @@ extern "C" int l4d_composite_fwd(const float* sigma, const float* z_vals, int64_
                                  float* depth, uint8_t* mask, int32_t* mask_idx, int32_t* mask_count, void* stream) {
   if (N == 0) return 0;
   if (mask_count) {
-    hipError_t e = hipMemsetAsync(mask_count, 0, sizeof(int32_t), (hipStream_t)stream);
-    if (e != hipSuccess) { l4d_set_error((int)e, "l4d_composite_fwd memset"); return (int)e; }
+    l4d_fill_async(mask_count, 0u, sizeof(int32_t), (hipStream_t)stream);
   }
   L4D_LAUNCH(composite_fwd_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, z_vals,
                      N, T, sample_dist, density_scale, active_sensor, weights, weights_sum, depth, mask, mask_idx, mask_count);

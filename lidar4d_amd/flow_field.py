@@ -40,7 +40,7 @@ class _FlowFn(torch.autograd.Function):
         # private buffers and the power of two is taken out again in fp32.  A non-finite dy gives a non-finite scale, hence
         # non-finite gradients: the overflow still reaches the scaler, it is never clipped (csrc/common.h f2h_grad).
         dyf = dy.float()
-        amax = dyf.abs().amax() if P else dyf.new_zeros(())
+        amax = ops.absmax(dyf.contiguous()).reshape(())  # (one HIP launch, not a torch reduction: ops.absmax)
         k = torch.floor(torch.log2(4096.0 / amax.clamp_min(1e-30))).clamp(-40.0, 40.0)
         s, inv = torch.exp2(k), torch.exp2(-k)
         dy16 = torch.zeros(P, 16, dtype=torch.float16, device=dy.device)

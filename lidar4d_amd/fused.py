@@ -216,7 +216,7 @@ class RenderFn(torch.autograd.Function):
         # field
         gcl = torch.zeros(pe.layout.numel, dtype=torch.float32, device=dev)
         fd = _field_desc(model)
-        vmax = pe._arena().abs().max().reshape(1)
+        vmax = ops.absmax(pe._arena())
         hook = getattr(model, "_grads_ready_hook", None)
         # Side streams (csrc/capi.cpp): the static grid's sorted scatter and the static-plane / dynamic-hash adjoints run next to
         # the time-plane adjoint, and -- single GPU: no reducer waiting for them -- also next to the flow field's backward below,

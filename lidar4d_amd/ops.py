@@ -516,6 +516,17 @@ def grad_nonfinite_check(grad, scaler_state):
     call("l4d_grad_nonfinite_check", _p(grad), grad.numel(), _p(scaler_state), _stream())
 
 
+def absmax(x):
+    """1-element fp32 device tensor max |x| (+inf if x holds inf / nan) by one HIP launch (l4d_absmax_f32) -- not torch's
+    ``x.abs().max()``: its multi-block reduce zeroes a semaphore buffer with hipMemsetAsync, and memset nodes make a
+    captured training step misbehave from its second replay on."""
+    _chk(x, torch.float32, "x")
+    x = x.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    call("l4d_absmax_f32", _p(x), x.numel(), _p(out), _stream())
+    return out
+
+
 def scaler_update(scaler_state, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
     _chk(scaler_state, torch.float32, "scaler")
     call("l4d_scaler_update", _p(scaler_state), float(growth_factor), float(backoff_factor), int(growth_interval), _stream())

@@ -33,6 +33,7 @@ int main(void) {
       (fn_t)&l4d_field_width,
       (fn_t)&l4d_freq_fwd,
       (fn_t)&l4d_grad_nonfinite_check,
+      (fn_t)&l4d_absmax_f32,
       (fn_t)&l4d_hashgrid_bwd,
       (fn_t)&l4d_hashgrid_fwd,
       (fn_t)&l4d_hashgrid_fwd_workspace,

@@ -265,6 +265,22 @@ def test_adam_matches_torch():
     assert torch.equal(p16, p.half())
 
 
+@pytest.mark.parametrize("n", [0, 1, 7, 4096, 1000003])
+def test_absmax(n):
+    """l4d_absmax_f32: exactly torch's x.abs().max() (a maximum has no rounding); +inf as soon as one value is inf / nan."""
+    from lidar4d_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, generator=g) * 37.0).to(DEV)
+    got = ops.absmax(x)
+    assert got.shape == (1,) and got.dtype == torch.float32
+    assert float(got) == (float(x.abs().max()) if n else 0.0)
+    if n:
+        for bad in (float("inf"), float("-inf"), float("nan")):
+            y = x.clone()
+            y[n // 2] = bad
+            assert float(ops.absmax(y)) == float("inf")
+
+
 @pytest.mark.parametrize("b,n,m", [(1, 1000, 1700), (2, 513, 257), (1, 16384, 16384)])
 def test_chamfer_fwd_bwd(b, n, m):
     """l4d_chamfer_fwd/bwd (replacement of utils/chamfer3D/chamfer3D.cu) against the brute-force oracle."""
