@@ -286,6 +286,7 @@ def parse_args():
     ap.add_argument("--no-ema", action="store_true", help="no parameter EMA (the reference's default keeps one, --ema_decay 0.95, updated once per epoch)")
     ap.add_argument("--graph", action="store_true", help="training workloads: one hipGraph replay per step (Trainer.train_step_graphed) instead of eager launches")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # the default
+    ap.add_argument("--settle-max", type=int, default=250, help="upper bound of the loss-scale settling loop before the warm-up (0: none; counter passes of the profiling script)")
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the per-kernel timing pass (0: no roofline block)")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of each secondary measurement (0: skip them)")
     ap.add_argument("--trained-steps", type=int, default=200, help="further training steps before the trained-state measurement")
@@ -471,7 +472,7 @@ def _run(args):
                 "ema": None if trainer.ema is None else (trainer.ema.shadow.clone(), trainer.ema.num_updates),
                 "global_step": getattr(trainer, "global_step", None)}
         applied_in_a_row, last = 0, int(opt_.steps.max())
-        while applied_in_a_row < 51 and settle_steps < 250:
+        while applied_in_a_row < 51 and settle_steps < args.settle_max:
             step()
             settle_steps += 1
             if os.environ.get("L4D_BENCH_TRACE"):

@@ -17,7 +17,7 @@ B="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --var
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/kt -o kt -- $B > $GRAFT_REPO_ROOT/$O/kt.log 2>&1 )
 python tools/rocpd_stats.py $(find $O/kt -name "*.db" | head -1) 70 > $O/kernel_stats.txt 2>&1
 head -5 $O/kernel_stats.txt | cut -c1-160
-S="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --variant-steps 0 --profile-steps 0"
+S="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 12 --settle-max 0 --no-cpu-baseline --variant-steps 0 --profile-steps 0"
 pmc() {  # name, counters...
   name=$1; shift
   ( cd /tmp && timeout 400 rocprofv3 --pmc "$@" --kernel-trace -d $GRAFT_REPO_ROOT/$O/pmc_$name -o p -- $S > $GRAFT_REPO_ROOT/$O/pmc_$name.log 2>&1 )
