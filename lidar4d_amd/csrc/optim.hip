@@ -165,8 +165,7 @@ __global__ void __launch_bounds__(256) nonfinite_check_kernel(const float* __res
   if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.0f;  // benign race: everybody stores the same value
 }
 
-// max |x| over n floats into out[0] (zeroed by the caller's fill); any inf / nan makes it +inf.  One atomic per wave that can
-// still raise the value (wave_dev.h atomic_max_nonneg).
+// max |x| over n floats into out[0] (zeroed by the caller's fill); any inf / nan makes it +inf.
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
   float m = 0.0f;
   bool bad = false;
@@ -180,7 +179,15 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
     }
   }
   m = __any(bad) ? __builtin_inff() : wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomic_max_nonneg(out, m);
+  // one atomic per WORKGROUP: all waves of a launch finish within microseconds of each other, and a few thousand atomics on one
+  // address serialise (measured: 139 us for an 8 MB input with one atomic per wave)
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (m > 0.0f) atomic_max_nonneg(out, m);
+  }
 }
 
 // torch.cuda.amp.GradScaler.update(): halve after a non-finite step, double after growth_interval clean steps
@@ -251,7 +258,7 @@ extern "C" int l4d_absmax_f32(const float* x, int64_t n, float* out, void* strea
   l4d_fill_async(out, 0u, sizeof(float), (hipStream_t)stream);
   if (n == 0) return 0;
   if ((uintptr_t)x & 15) { l4d_set_error(1, "l4d_absmax_f32: x must be 16-byte aligned"); return 1; }
-  const int64_t blocks = std::min<int64_t>(2048, ceil_div64(ceil_div64(n, 4), 256));
+  const int64_t blocks = std::min<int64_t>(256, ceil_div64(ceil_div64(n, 4), 256));
   L4D_LAUNCH(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
   L4D_LAUNCH_CHECK("l4d_absmax_f32");
   return 0;

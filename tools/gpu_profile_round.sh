@@ -2,13 +2,17 @@
 # Round artefacts on the GPU box: full -m gpu test run, rocprofv3 kernel trace of the bench command, PMC passes (memory-side
 # request counters, L2 hit / miss, MFMA, SQ / LDS), the counter calibration, the default bench line (with the counter files of THIS
 # build attached) and the other workloads.  Summaries land in gpurun_out/<tag>/; copy the ones to keep into profiles/.
-#   usage: bash tools/gpu_profile_round.sh <tag> [skip-tests]
+#   usage: bash tools/gpu_profile_round.sh <tag> [skip-tests|subset]
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 TAG=${1:-r03}
 O=gpurun_out/$TAG
 mkdir -p $O
-if [ "$2" != "skip-tests" ]; then
+if [ "$2" == "subset" ]; then
+  python -m pytest tests/test_gpu_ops.py tests/test_gpu_c3_parity.py tests/test_gpu_optim.py -m gpu -q --tb=short > $O/pytest_subset.log 2>&1
+  echo "pytest rc=$?" >> $O/pytest_subset.log
+  grep -E "passed|failed|FAILED|Error" $O/pytest_subset.log | tail -n 8
+elif [ "$2" != "skip-tests" ]; then
   python -m pytest tests -m gpu -q -s -rfE --tb=short > $O/pytest.log 2>&1
   echo "pytest rc=$?" >> $O/pytest.log
   grep -E "passed|failed|FAILED|Error" $O/pytest.log | tail -n 8
