@@ -329,6 +329,69 @@ def test_graphed_step_replays_the_training_step():
     assert not torch.equal(m._store.flat, before) and tr.opt.sched.tolist()[0] == 21.0
 
 
+@pytest.mark.parametrize("streams", [0, 2])
+def test_graph_replay_equals_eager_step(streams, monkeypatch):
+    """A REPLAY of the captured step must produce the gradients and the parameter update the eager step produces from the same
+    state and the same batch -- also from the second replay on, which is where memset nodes in the graph (a hipMemsetAsync fill,
+    torch's multi-block reduce zeroing its semaphores) made single-chain graphs go wrong on ROCm 7.2 (DESIGN.md section 5,
+    tools/graph_diff.py): the first replay was exact, every later one differed in the time planes' gradients.  Random draws are
+    pinned (static batch, no sample jitter, fixed ground-flow time); tolerance = the order of the dW atomics."""
+    from lidar4d_amd import LiDAR4D, _lib, ops, trainer as trainer_mod
+    from lidar4d_amd.data import KITTI360_SCALE, SyntheticKitti360
+    from lidar4d_amd.params import bump_epoch
+    from lidar4d_amd.trainer import Trainer
+    monkeypatch.setenv("L4D_GRAPH_BATCH", "outside")
+    mask_was = ops.streams_mask()
+    _lib.lib().l4d_streams_config(streams)
+    try:
+        torch.manual_seed(0)
+        m = LiDAR4D(near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE).to(DEV)
+        data = SyntheticKitti360(DEV, W=1024, num_rays=1024, seed=7, frame_seed=7)
+        tr = Trainer(m, data, iters=200, chamfer=True, flow=True, ema_decay=None, init_scale=1024.0)
+        st, opt = m._store, tr.opt
+        batch = {k: (v.contiguous().clone() if torch.is_tensor(v) else v) for k, v in data.batch_for(20).items()}
+        monkeypatch.setattr(data, "batch_for", lambda frame: batch)
+        render = m.render
+        monkeypatch.setattr(m, "render", lambda *a, **kw: render(*a, **{**kw, "perturb": False}))
+        tg, fl = torch.tensor([0.37], device=DEV), trainer_mod.flow_loss
+        monkeypatch.setattr(trainer_mod, "flow_loss", lambda *a, **kw: fl(*a, **{**kw, "t_ground": tg}))
+        for _ in range(4):
+            tr.train_step(batch)
+        opt.device_schedule()
+        snap = {"flat": st.flat.detach().clone(), "m": opt.exp_avg.clone(), "v": opt.exp_avg_sq.clone(), "steps": opt.steps.clone(),
+                "scaler": tr.scaler.state.clone(), "sched": opt.sched.clone(), "count": opt.step_count}
+
+        def restore():
+            with torch.no_grad():
+                st.flat.copy_(snap["flat"]), opt.exp_avg.copy_(snap["m"]), opt.exp_avg_sq.copy_(snap["v"]), opt.steps.copy_(snap["steps"])
+                tr.scaler.state.copy_(snap["scaler"]), opt.sched.copy_(snap["sched"])
+            opt.step_count = snap["count"]
+            bump_epoch()
+            st.refresh16()
+
+        restore()
+        tr.train_step(batch)
+        g_e, p_e = st.flat_grad.detach().clone(), st.flat.detach().clone()
+        assert bool(torch.isfinite(g_e).all()) and not torch.equal(p_e, snap["flat"])
+        restore()
+        tr.train_step_graphed(20)  # eager warm-up + capture
+        for k in range(4):
+            restore()
+            tr.train_step_graphed(20)
+            for name, p, off, n, gi in st.entries:
+                if not n:
+                    continue
+                a, b = st.flat_grad[off:off + n], g_e[off:off + n]
+                assert bool(torch.isfinite(a).all()), f"replay {k}: non-finite gradient in {name}"
+                d = float((a.double() - b.double()).abs().max()) / max(float(b.abs().max()), 1e-30)
+                assert d < 1e-3, f"replay {k}: gradient of {name} differs from the eager step's by {d:.2e} of its largest value"
+            # (Adam with eps = 1e-15 turns the sign of a rounding-noise gradient into a +-lr step: a handful of parameters may differ)
+            off_frac = float(((st.flat - p_e).abs() > 1e-4).float().mean())
+            assert off_frac < 1e-4, f"replay {k}: {off_frac:.2e} of the parameters differ from the eager step's"
+    finally:
+        _lib.lib().l4d_streams_config(mask_was)
+
+
 def test_device_schedule_matches_host_schedule():
     """l4d_adam_step_ranges with the learning-rate schedule on the device (``sched``) against the same launch with the
     host-computed rate: the factor 0.1 ** min(it / iters, 1) of every iteration, and the parameters after each step (the rate

@@ -582,3 +582,26 @@ def test_flat_adam_ranges_partition_the_arena():
         assert R.lr_mults[r] == (1.0, 0.1)[gi]
         assert (R.gate_idx[r] >= 0) == (".hash_t." in name)
     assert st.grad_numel == st.numel + 32
+
+
+def test_library_issues_no_memset_or_memcpy_nodes():
+    """Graph safety: the library initialises memory and moves single words with KERNELS
+    (csrc/common.h l4d_fill_async / l4d_copy_words_async), never with hipMemsetAsync / hipMemcpyAsync -- memset nodes made captured
+    training steps fault or go wrong from their second replay on (ROCm 7.2).  Source-level guard; the behaviour itself is
+    tests/test_gpu_optim.py::test_graph_replay_equals_eager_step."""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lidar4d_amd")
+    offenders = []
+    for path in sorted(glob.glob(os.path.join(root, "csrc", "*"))):
+        if not path.endswith((".hip", ".cpp", ".h")):
+            continue
+        code = re.sub(r"//[^\n]*", "", open(path).read())          # comments may name the calls
+        code = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
+        if re.search(r"\bhipMem(set|cpy)\w*\s*\(", code):
+            offenders.append(os.path.basename(path))
+    assert not offenders, offenders
+    # and the step's value-carrying reductions go through the library (torch's multi-block reduce carries a memset node)
+    for mod in ("fused.py", "flow_field.py"):
+        src = open(os.path.join(root, mod)).read()
+        assert not re.search(r"\.abs\(\)\.(a?max)\(", src), mod
