@@ -25,16 +25,6 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# Workspace keep-alive: while KEEP_WORKSPACES is a list, the scratch buffers the wrappers allocate for a call are appended to it
-# instead of being released when the call returns (Trainer.train_step_graphed sets it for the duration of a capture: see there).
-KEEP_WORKSPACES = None
-
-
-def _hold(*tensors):
-    if KEEP_WORKSPACES is not None:
-        KEEP_WORKSPACES.extend(t for t in tensors if t is not None)
-
-
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -79,7 +69,6 @@ def hashgrid_fwd(meta, x, cols, table16, out=None, out_col=0, xcd_pinned=None):
         ws = torch.empty(_lib.lib().l4d_hashgrid_fwd_workspace(C.byref(d), P), dtype=torch.uint8, device=x.device)
         call("l4d_hashgrid_fwd_ws", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _p(table16),
              C.c_void_p(out.data_ptr() + 2 * out_col), out.stride(0), _p(ws), _stream())
-        _hold(ws)
         return out
     call("l4d_hashgrid_fwd", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _p(table16),
          C.c_void_p(out.data_ptr() + 2 * out_col), out.stride(0), _stream())
@@ -125,7 +114,6 @@ def hashgrid_t_bwd(meta, x, cols, n_slices, t_dev, dout, grad_tables, grad_scale
     call("l4d_hashgrid_t_bwd", C.byref(d), _p(x), x.shape[0], x.stride(0), _i32s(list(cols)), n_slices, _p(t_dev),
          C.c_void_p(dout.data_ptr() + dout.element_size() * dout_col), dout.stride(0), int(dout.dtype == torch.float16),
          float(grad_scale), _ptrs(grad_tables), _p(scratch), _p(ws), _stream())
-    _hold(scratch, ws)
 
 
 # ---- planes ----------------------------------------------------------------------------------------
@@ -416,7 +404,6 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
     if P >= PLANE_ROWS_MIN_POINTS:  # time planes through per-call 1-D rows (two taps instead of four)
         rows = torch.empty(_lib.lib().l4d_plane_rows_workspace(C.byref(field_desc)) // 4, dtype=torch.float32, device=xt.device)
     call("l4d_density_encode_fwd", C.byref(field_desc), _p(xt), _p(flow16), _p(tinfo), P, _p(X), in_pad, _p(scratch), _p(rows), _stream())
-    _hold(scratch, rows)
     return X
 
 
@@ -440,7 +427,6 @@ def density_encode_bwd(field_desc, field_grads, xt, flow16, tinfo, dX, param_sca
     call("l4d_density_encode_bwd", C.byref(field_desc), C.byref(field_grads), _p(xt), _p(flow16), _p(tinfo), P, _p(dX),
          in_pad, float(param_scale), _p(plane_abs_max), int(samples_per_ray), _p(ws), _p(dflow16), _p(rows), _p(gd_absmax),
          int(bool(defer_join)), _stream())
-    _hold(ws, rows)
     if defer_join:
         return dflow16, (ws, rows)
     return dflow16

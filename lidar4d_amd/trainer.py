@@ -611,7 +611,7 @@ class Trainer:
     def train_step_graphed(self, frame=None):
         """train_step as the replay of a hipGraph captured per frame index (the scene-flow loss walks that frame's point clouds, so
         the launch sequence depends on the frame and on nothing else): batch draw (device RNG), forward, losses, backward,
-        GradScaler check / skip / update, Adam with the learning-rate schedule on the device -- about 630 launches per step
+        GradScaler check / skip / update, Adam with the learning-rate schedule on the device -- about 640 launches per step
         become one.  The first call for a frame runs one eager step (refreshes every host-side cache) and captures the next."""
         if not self.graphs_supported():
             raise RuntimeError("Trainer.train_step_graphed: this configuration needs the host inside a step (see graphs_supported)")
@@ -624,44 +624,29 @@ class Trainer:
         outside = os.environ.get("L4D_GRAPH_BATCH", "inside") == "outside"
         rec = st["graphs"].get(frame)
         if rec is None:
-            from . import _lib
-            # the library's side streams (fork / join by events) are captured like any other stream dependency;
-            # L4D_GRAPH_STREAMS=0 keeps them out of the capture (debugging)
-            mask_was = ops.streams_mask()
-            if os.environ.get("L4D_GRAPH_STREAMS") == "0":
-                _lib.lib().l4d_streams_config(0)
-            try:
-                static = None
-                if outside:
-                    static = {k: (v.contiguous().clone() if torch.is_tensor(v) else v) for k, v in self.dataset.batch_for(frame).items()}
-                draw = (lambda: static) if outside else (lambda: self.dataset.batch_for(frame))
-                # torch's capture recipe: the warm-up step runs on the (non-default) stream the capture will use, and nothing of
-                # its autograd graph survives it -- an AccumulateGrad node that was created on the legacy default stream and is
-                # still alive makes the captured backward synchronise with that stream, which a capture cannot contain
-                side = st.setdefault("stream", torch.cuda.Stream())
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    loss = self._step_device_work(draw()).detach()  # eager: leaves every cache in its steady state
-                torch.cuda.current_stream().wait_stream(side)
-                self.opt.step_count -= 1  # (the capture below is not executed: it must not count as an iteration on the host)
-                graph = torch.cuda.CUDAGraph()
-                gen = getattr(self.dataset, "gen", None)
-                if not outside and gen is not None and hasattr(graph, "register_generator_state"):
-                    graph.register_generator_state(gen)
-                keep = os.environ.get("L4D_GRAPH_KEEP_WS") == "1"
-                if keep:
-                    ops.KEEP_WORKSPACES = []
-                try:
-                    pool = None if os.environ.get("L4D_GRAPH_POOL") == "separate" else st["pool"]  # (debugging: one pool per graph)
-                    with torch.cuda.graph(graph, pool=pool, stream=side):
-                        loss_g = self._step_device_work(draw()).detach()
-                finally:
-                    held, ops.KEEP_WORKSPACES = ops.KEEP_WORKSPACES, None
-            finally:
-                _lib.lib().l4d_streams_config(mask_was)
+            static = None
+            if outside:
+                static = {k: (v.contiguous().clone() if torch.is_tensor(v) else v) for k, v in self.dataset.batch_for(frame).items()}
+            draw = (lambda: static) if outside else (lambda: self.dataset.batch_for(frame))
+            # torch's capture recipe: the warm-up step runs on the (non-default) stream the capture will use, and nothing of
+            # its autograd graph survives it -- an AccumulateGrad node that was created on the legacy default stream and is
+            # still alive makes the captured backward synchronise with that stream, which a capture cannot contain.  The
+            # library's side streams, when switched on, fork and join by events and are captured like any other dependency.
+            side = st.setdefault("stream", torch.cuda.Stream())
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                loss = self._step_device_work(draw()).detach()  # eager: leaves every cache in its steady state
+            torch.cuda.current_stream().wait_stream(side)
+            self.opt.step_count -= 1  # (the capture below is not executed: it must not count as an iteration on the host)
+            graph = torch.cuda.CUDAGraph()
+            gen = getattr(self.dataset, "gen", None)
+            if not outside and gen is not None and hasattr(graph, "register_generator_state"):
+                graph.register_generator_state(gen)
+            with torch.cuda.graph(graph, pool=st["pool"], stream=side):  # (one memory pool for all frames' graphs: they never overlap)
+                loss_g = self._step_device_work(draw()).detach()
             if st["pool"] is None:
                 st["pool"] = graph.pool()
-            st["graphs"][frame] = {"graph": graph, "loss": loss_g, "static": static, "held": held}
+            st["graphs"][frame] = {"graph": graph, "loss": loss_g, "static": static}
             self._step_host_bookkeeping()
             return loss
         if rec["static"] is not None:

@@ -1,6 +1,6 @@
 """Probe (GPU box): does the whole training step capture into a hipGraph under the current environment, does a replay train
 (parameters move, gradients finite, optimiser state advances), and what does a replay cost against eager launches?
-usage: python tools/graph_probe.py [n_rays]   (env: L4D_GRAPH_BATCH, L4D_GRAPH_STREAMS, L4D_STREAMS)"""
+usage: python tools/graph_probe.py [n_rays]   (env: L4D_GRAPH_BATCH, L4D_STREAMS)"""
 import os
 import sys
 import time
