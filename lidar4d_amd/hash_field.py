@@ -13,6 +13,20 @@ from . import ops
 from . import tcnn
 
 
+def _reduction_func(reduction):
+    """hash_field.py:16-27 (``reduction_func``): how the three 2-D x time stacks of HashGrid4D are combined."""
+    import math
+    if reduction == "prod":
+        return math.prod
+    if reduction == "sum":
+        return sum
+    if reduction == "mean":
+        return lambda xs: sum(xs) / len(xs)
+    if reduction == "concat":
+        return lambda xs: torch.cat(xs, dim=-1)
+    raise ValueError("Invalid reduction")
+
+
 def _t_device(t, device):
     """1-element fp32 device tensor holding the call's time (python float, 0-dim CPU tensor or [1,1] tensor)."""
     if torch.is_tensor(t):
@@ -75,8 +89,7 @@ class HashGrid4D(nn.Module):
                  n_features_per_level=4, log2_hashmap_size=19, hash_size_dynamic=(15, 13, 13), decompose=True,
                  reduction="concat"):
         super().__init__()
-        if reduction != "concat" or not decompose:
-            raise ValueError("HashGrid4D: only the reference defaults decompose=True, reduction='concat' are implemented")
+        _reduction_func(reduction)  # raises for anything but concat / prod / sum / mean, like the reference (hash_field.py:16-27)
         per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
         self.hash_static = tcnn.Encoding(n_input_dims=3, encoding_config={
             "otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
@@ -87,14 +100,21 @@ class HashGrid4D(nn.Module):
                       n_levels=n_levels, n_features_per_level=n_features_per_level,
                       log2_hashmap_size=hash_size_dynamic[i]) for i in range(3)])
         self.decompose, self.reduction = decompose, reduction
-        self.n_output_dims = self.hash_static.n_output_dims + 3 * self.hash_dynamic[0].n_output_dims
+        n_dyn = self.hash_dynamic[0].n_output_dims
+        self.n_output_dims = self.hash_static.n_output_dims + (3 * n_dyn if reduction == "concat" else n_dyn)  # hash_field.py:134-138
 
     def forward_static(self, x):
         return self.hash_static(x)
 
     def forward_dynamic(self, x, t):
+        """hash_field.py:146-158: the xy / xz / yz stacks, concatenated (default; the layout the fused pipeline assumes) or
+        reduced elementwise by product / sum / mean (operator-level path only: plain torch arithmetic on the three outputs)."""
         xy, xz, yz = x[:, [0, 1]], x[:, [0, 2]], x[:, [1, 2]]
-        return torch.cat([self.hash_dynamic[0](xy, t), self.hash_dynamic[1](xz, t), self.hash_dynamic[2](yz, t)], dim=-1)
+        feats = [self.hash_dynamic[0](xy, t), self.hash_dynamic[1](xz, t), self.hash_dynamic[2](yz, t)]
+        return _reduction_func(self.reduction)(feats)
 
     def forward(self, x, t):
-        return [self.forward_static(x), self.forward_dynamic(x, t)]
+        static, dynamic = self.forward_static(x), self.forward_dynamic(x, t)
+        if self.decompose:
+            return [static, dynamic]
+        return torch.cat([static, dynamic], dim=-1)  # hash_field.py:167-170

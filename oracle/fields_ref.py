@@ -91,8 +91,9 @@ class HashGrid4D(nn.Module):
     """Static 3-D hash grid + xy/xz/yz HashGridT stacks.  Reference: model/hash_field.py:91-172."""
 
     def __init__(self, base_resolution=512, max_resolution=32768, time_resolution=8, n_levels=8,
-                 n_features_per_level=4, log2_hashmap_size=19, hash_size_dynamic=(15, 13, 13)):
+                 n_features_per_level=4, log2_hashmap_size=19, hash_size_dynamic=(15, 13, 13), decompose=True, reduction="concat"):
         super().__init__()
+        self.decompose, self.reduction = decompose, reduction
         per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
         self.hash_static = tcnn.Encoding(3, {
             "otype": "HashGrid",
@@ -106,17 +107,28 @@ class HashGrid4D(nn.Module):
             HashGridT(time_resolution, base_resolution, max_resolution, n_levels,
                       n_features_per_level, hash_size_dynamic[i]) for i in range(3)
         ])
-        self.n_output_dims = self.hash_static.n_output_dims + 3 * self.hash_dynamic[0].n_output_dims
+        n_dyn = self.hash_dynamic[0].n_output_dims
+        self.n_output_dims = self.hash_static.n_output_dims + (3 * n_dyn if reduction == "concat" else n_dyn)  # hash_field.py:134-138
 
     def forward_static(self, x):
         return self.hash_static(x).float()
 
     def forward_dynamic(self, x, t):
         pairs = ((0, 1), (0, 2), (1, 2))  # xy, xz, yz  (hash_field.py:147-153)
-        return torch.cat([self.hash_dynamic[i](x[:, list(p)], t) for i, p in enumerate(pairs)], -1)
+        feats = [self.hash_dynamic[i](x[:, list(p)], t) for i, p in enumerate(pairs)]
+        if self.reduction == "concat":  # hash_field.py:16-27 (reduction_func), :155-156
+            return torch.cat(feats, -1)
+        if self.reduction == "prod":
+            return feats[0] * feats[1] * feats[2]
+        if self.reduction == "sum":
+            return feats[0] + feats[1] + feats[2]
+        if self.reduction == "mean":
+            return (feats[0] + feats[1] + feats[2]) / 3
+        raise ValueError("Invalid reduction")
 
     def forward(self, x, t):
-        return [self.forward_static(x), self.forward_dynamic(x, t)]
+        static, dynamic = self.forward_static(x), self.forward_dynamic(x, t)
+        return [static, dynamic] if self.decompose else torch.cat([static, dynamic], dim=-1)  # hash_field.py:164-170
 
 
 # ----------------------------------------------------------------------------------------------

@@ -97,6 +97,40 @@ def test_hashgrid_t(t):
             rel_close(q.grad, p.grad, rtol=1e-3, atol=5e-4 * max(p.grad.abs().max().item(), 1e-9), what="hashgrid_t bwd " + n)
 
 
+@pytest.mark.parametrize("reduction,decompose", [("sum", True), ("prod", False), ("mean", True), ("concat", False)])
+def test_hashgrid4d_reduction_and_decompose(reduction, decompose):
+    """HashGrid4D's non-default options (hash_field.py:16-27,101-102,134-138,155-170): the three 2-D x time stacks combined by
+    product / sum / mean instead of concatenation, and one concatenated tensor instead of the [static, dynamic] pair --
+    operator-level path, against the oracle's restatement, forward and parameter gradients."""
+    from lidar4d_amd.hash_field import HashGrid4D
+    kw = dict(base_resolution=16, max_resolution=256, time_resolution=8, n_levels=4, n_features_per_level=4, log2_hashmap_size=12,
+              hash_size_dynamic=(10, 9, 9), decompose=decompose, reduction=reduction)
+    ref, mod = fields_ref.HashGrid4D(**kw), HashGrid4D(**kw)
+    assert mod.n_output_dims == ref.n_output_dims == 16 + (12 if reduction == "concat" else 4)
+    with torch.no_grad():
+        for (n, p), (_, q) in zip(ref.named_parameters(), mod.named_parameters()):
+            p.copy_(det_uniform(tuple(p.shape), "h4" + n, -0.5, 0.5))
+            q.copy_(p)
+    mod = mod.to(DEV)
+    x, t = det_uniform((4096, 3), "h4x", 0, 1), torch.tensor(0.3, dtype=torch.float32)
+    o_ref, o = ref(x, t), mod(x.to(DEV), t)
+    if decompose:
+        assert isinstance(o, list) and len(o) == 2
+        o_ref, o = torch.cat([v.float() for v in o_ref], -1), torch.cat([v.float() for v in o], -1)
+    assert o.shape == (4096, ref.n_output_dims)
+    rel_close(o.float(), o_ref.float(), rtol=2e-3, atol=1e-3, what=f"HashGrid4D {reduction} fwd")
+    g = det_uniform(tuple(o_ref.shape), "h4g", -1, 1)
+    o_ref.float().backward(g)
+    o.float().backward(g.to(DEV))
+    for (n, p), (_, q) in zip(ref.named_parameters(), mod.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None or float(q.grad.abs().sum()) == 0.0, n
+        else:
+            rel_close(q.grad, p.grad, rtol=3e-3, atol=3e-3 * max(p.grad.abs().max().item(), 1e-9), what=f"HashGrid4D {reduction} bwd " + n)
+    with pytest.raises(ValueError):
+        HashGrid4D(reduction="max")
+
+
 def test_planes_vs_reference_golden(golden):
     """Planes4D against fixtures produced by the reference's own F.grid_sample code (make_golden.py (3))."""
     from lidar4d_amd.planes_field import Planes4D
