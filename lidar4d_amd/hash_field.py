@@ -66,8 +66,11 @@ class HashGridT(nn.Module):
     def __init__(self, time_resolution=8, base_resolution=512, max_resolution=32768, n_levels=8,
                  n_features_per_level=4, log2_hashmap_size=14, num_basis=4):
         super().__init__()
-        if num_basis != 4 or n_features_per_level != 4:
-            raise ValueError("HashGridT: the HIP kernel implements num_basis = n_features_per_level = 4 (reference default)")
+        if num_basis < 2 or n_features_per_level % num_basis or n_features_per_level not in (2, 4, 8):
+            raise ValueError("HashGridT: n_features_per_level must be 2, 4 or 8 and a multiple of num_basis >= 2")
+        # the fused kernel (l4d_hashgrid_t_fwd / _bwd: slice blend + interpT in one launch) is specialised for the reference default;
+        # other widths run slice by slice through the generic hash-grid kernels with the blend and interpT as torch arithmetic
+        self.fused = num_basis == 4 and n_features_per_level == 4
         self.time_resolution = time_resolution
         per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
         cfg = {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
@@ -78,10 +81,32 @@ class HashGridT(nn.Module):
         self.n_levels, self.n_features_per_level, self.num_basis = n_levels, n_features_per_level, num_basis
         self.n_output_dims = n_levels * n_features_per_level // num_basis
 
+    def interpT(self, feat, t):
+        """hash_field.py:65-74: each level's features split into num_basis chunks, combined with the Lagrange basis on the nodes
+        i / (num_basis - 1) at t (same product order as the reference)."""
+        x = feat.view(-1, self.n_levels, self.n_features_per_level)
+        chunks = torch.chunk(x, self.num_basis, dim=-1)
+        T = [i / (self.num_basis - 1) for i in range(self.num_basis)]
+        acc = 0
+        for j in range(self.num_basis):
+            c = 1
+            for m in range(self.num_basis):
+                if m != j:
+                    c = c * ((t - T[m]) / (T[j] - T[m]))
+            acc = acc + c * chunks[j]
+        return acc.reshape(feat.shape[0], self.n_output_dims)
+
     def forward(self, x, t):
         t_dev = _t_device(t, x.device)
         i1, i2 = _slice_pair_host(float(t_dev), self.time_resolution)  # host sync, as the reference's `if idx1 == idx2`
-        return _HashGridTFn.apply(x, t_dev, self, i1, i2, self.hash_t[i1].params, self.hash_t[i2].params)
+        if self.fused:
+            return _HashGridTFn.apply(x, t_dev, self, i1, i2, self.hash_t[i1].params, self.hash_t[i2].params)
+        idx = t_dev * (self.time_resolution - 1)  # hash_field.py:79-86, fp32 tensor arithmetic
+        if i1 == i2:
+            feat = self.hash_t[i1](x).float()
+        else:
+            feat = (i2 - idx) * self.hash_t[i1](x).float() + (idx - i1) * self.hash_t[i2](x).float()
+        return self.interpT(feat, t_dev)
 
 
 class HashGrid4D(nn.Module):

@@ -97,6 +97,36 @@ def test_hashgrid_t(t):
             rel_close(q.grad, p.grad, rtol=1e-3, atol=5e-4 * max(p.grad.abs().max().item(), 1e-9), what="hashgrid_t bwd " + n)
 
 
+@pytest.mark.parametrize("F,num_basis,t", [(8, 4, 0.3), (4, 2, 0.62), (8, 2, 1.0), (2, 2, 0.3)])
+def test_hashgrid_t_other_widths(F, num_basis, t):
+    """HashGridT with feature widths / basis counts off the reference default (hash_field.py:39,65-74): slice by slice through the
+    generic hash-grid kernels, blend and interpT as torch arithmetic -- against the oracle, forward and table gradients."""
+    from lidar4d_amd.hash_field import HashGridT
+    kw = dict(time_resolution=8, base_resolution=16, max_resolution=512, n_levels=8, n_features_per_level=F, log2_hashmap_size=11,
+              num_basis=num_basis)
+    ref, mod = fields_ref.HashGridT(**kw), HashGridT(**kw)
+    assert not mod.fused and mod.n_output_dims == ref.n_output_dims == 8 * F // num_basis
+    with torch.no_grad():
+        for (n, p), (_, q) in zip(ref.named_parameters(), mod.named_parameters()):
+            p.copy_(det_uniform(tuple(p.shape), "hw" + n, -0.5, 0.5))
+            q.copy_(p)
+    mod = mod.to(DEV)
+    x, tt = det_uniform((4096, 2), "hwx", 0, 1), torch.tensor(t, dtype=torch.float32)
+    out_ref, out = ref(x, tt), mod(x.to(DEV), tt)
+    assert out.shape == (4096, ref.n_output_dims)
+    rel_close(out.float(), out_ref.float(), rtol=1e-3, atol=1e-3, what="hashgrid_t (composed) fwd")
+    g = det_uniform(tuple(out_ref.shape), "hwg", -1, 1)
+    out_ref.backward(g)
+    out.backward(g.to(DEV).to(out.dtype))
+    for (n, p), (_, q) in zip(ref.named_parameters(), mod.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None or float(q.grad.abs().sum()) == 0.0, n
+        else:
+            rel_close(q.grad, p.grad, rtol=3e-3, atol=3e-3 * max(p.grad.abs().max().item(), 1e-9), what="hashgrid_t (composed) bwd " + n)
+    with pytest.raises(ValueError):
+        HashGridT(n_features_per_level=4, num_basis=3)
+
+
 @pytest.mark.parametrize("reduction,decompose", [("sum", True), ("prod", False), ("mean", True), ("concat", False)])
 def test_hashgrid4d_reduction_and_decompose(reduction, decompose):
     """HashGrid4D's non-default options (hash_field.py:16-27,101-102,134-138,155-170): the three 2-D x time stacks combined by
