@@ -194,8 +194,8 @@ probe = step(8)
 n = int(max(8, min(1024, budget / max(probe / 8, 1e-6))))
 dt = step(n)
 res = dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
-      sample="oracle (torch CPU restatement of the reference path, tiny-cuda-nn rounding points) forward+backward of "
-             "render() on %d rays x 768 samples, full 4D default config, no optimizer step; %.1f s on %d threads" % (n, dt, cores))
+      sample="oracle port (torch CPU, tcnn rounding points): render() fwd+bwd, %d rays x 768 samples, default 4D config, "
+             "no optimizer; %.1f s on %d threads" % (n, dt, cores))
 # parity reference (checker role): the default model with deterministic, visible parameters, 64 rays x 768 samples, frame 25
 m.density_scale = 30.0
 fill_model(m, seed=3)
@@ -312,6 +312,77 @@ def relaunch_distributed(args):
     r = subprocess.run(cmd, env=env)
     if r.returncode != 0:
         raise SystemExit(f"bench.py: the {args.gpus}-rank launch failed with exit code {r.returncode}")
+
+DETAIL_PATH = os.environ.get("L4D_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+LINE_LIMIT = 4096  # bytes of the ONE stdout line (the round-3 line had grown to 24 KB and the driver could not parse it)
+
+
+def _r(x, n=4):
+    return None if x is None else round(float(x), n)
+
+
+def compact_line(detail, args):
+    """The ONE stdout line: the contract's fields + scalar summaries (roofline of the dominant kernel, the hash-encoder figure,
+    cpu_baseline, parity).  Everything else -- the per-kernel table, counter dictionaries, MFMA entries, prose -- is ``detail``
+    and goes to bench_detail.json (L4D_BENCH_DETAIL) next to this script; its path is the line's ``detail`` field."""
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(detail, f, indent=1)
+        detail_ref = os.path.relpath(DETAIL_PATH, ROOT) if DETAIL_PATH.startswith(ROOT) else DETAIL_PATH
+    except OSError as e:
+        detail_ref = "not written: %r" % (e,)
+    c = detail["config"]
+    line = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(line["value"], 1), _r(line["ms_per_step"], 4)
+    line["config"] = {"workload": c["workload"][:160], "rays_per_gpu_per_step": c["rays_per_gpu_per_step"], "samples_per_ray": c["samples_per_ray"],
+                      "global_rays_per_step": c["global_rays_per_step"], "parallelism": c["parallelism"].split(",")[0],
+                      "skipped_steps_in_timed_region": c["skipped_steps_in_timed_region"], "skipped_steps_in_warmup": c["skipped_steps_in_warmup"],
+                      "settling_steps": c["scaler_settling_steps_before_warmup"], "loss_scale": c["loss_scale_after_timed_region"],
+                      "step_mode": c["step_mode"][:60]}
+    rf = detail.get("roofline")
+    if rf:
+        tr = rf.get("traffic") or {}
+        req, miss = tr.get("l2_requests"), tr.get("l2_misses")
+        line["roofline"] = {"bound": rf["bound"], "kernel": rf["kernel"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
+                            "traffic": tr.get("bytes_per_launch"), "frac_hbm_counter": rf.get("frac_hbm_counter"),
+                            "l2_miss_rate": _r(miss / req) if req and miss is not None else None,
+                            "bytes_per_launch": rf["bytes_per_launch"], "avg_launch_ms": rf["avg_launch_ms"], "samples_per_launch": rf["samples_per_launch"],
+                            "hash_gathers_G_per_s": rf.get("hash_gathers_G_per_s"), "gather_peak_G_per_s": GATHER_PEAK_G if rf.get("hash_gathers_G_per_s") else None,
+                            "compulsory_hbm_frac": rf.get("compulsory_hbm_frac")}
+    else:
+        line["roofline"] = None
+    he = detail.get("hash_encoder")
+    if he:
+        line["hash_encoder"] = {"bound": "hbm", "peak": he["peak"], "unit": he["unit"], "target_frac": he["target_frac"], "ceiling_frac": he.get("ceiling_frac"),
+                                **{k: {"frac": he[k]["frac"], "achieved": he[k]["achieved"], "ms": he[k]["ms"], "variant": he[k]["variant"]} for k in ("L8", "L16") if k in he}}
+    mf = detail.get("mfma")
+    if mf and mf.get("kernels"):
+        top = max(mf["kernels"], key=lambda k: k["algorithmic_tflops"])
+        util = [k["pmc_mfma_util_percent"] for k in mf["kernels"] if k.get("pmc_mfma_util_percent") is not None]
+        line["mfma"] = {"peak_tflops": mf["peak_tflops"], "best_kernel": top["kernel"], "algorithmic_tflops": top["algorithmic_tflops"],
+                        "frac": top["frac_of_dense_f16_peak"], "pmc_busy_percent_max": max(util) if util else None}
+    v = detail.get("variants")
+    if v:
+        line["variants"] = {k: {"ms_per_step": _r(d["ms_per_step"], 3), "rays_per_s": _r(d["rays_per_s"], 0)} for k, d in v.items()}
+    if "eval" in detail:
+        line["eval"] = {"chamfer_f_score": detail["eval"]["chamfer_distance_m2, f_score@0.05"], "frames": detail["eval"]["frames"]}
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value"), 2), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": str(cb.get("sample"))[:200]}
+    pr = detail.get("parity")
+    if pr:
+        line["parity"] = {k: (pr[k] if not isinstance(pr[k], float) else float("%.3g" % pr[k])) for k in pr if k not in ("vs",)}
+        if "error" in pr:
+            line["parity"] = {"error": pr["error"][:200]}
+    line["detail"] = detail_ref
+    n = len(json.dumps(line))
+    if n > LINE_LIMIT:  # never print a line the driver cannot parse: shed the optional blocks, biggest first
+        for k in ("variants", "mfma", "eval", "parity", "hash_encoder"):
+            if len(json.dumps(line)) <= LINE_LIMIT:
+                break
+            line[k] = "see " + detail_ref
+    return line
 
 
 def main():
@@ -493,6 +564,7 @@ def _run(args):
         if snap["global_step"] is not None:
             trainer.global_step = snap["global_step"]
         bump_epoch()  # fp16 compute copies, pair tables and the channel-last planes are rebuilt from the restored arena
+        st_.refresh16()  # ... now: a graph replay does not contain the cast
         model.planes_encoder._cl_key = None
         del snap
     steps_before = int(trainer.opt.steps.max()) if not inference else 0
@@ -671,7 +743,7 @@ def _run(args):
         total_rays = n_rays * world * args.steps
         losses = "L1 depth + MSE raydrop + MSE intensity" + (" + ray chamfer" if use_chamfer else "") + \
                  (" + scene-flow consistency" if use_flow else "") + (" + line-of-sight" if args.urf else "")
-        line = {
+        detail = {
             "metric": "inference rays/sec (64x2048 novel-view frame)" if inference else "training rays/sec (64x1024 LiDAR panorama)",
             "value": total_rays / dt,
             "unit": "rays/s",
@@ -682,7 +754,8 @@ def _run(args):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 tables/MFMA operands, f32 accumulate",
+            "dtype": "f16",
+            "dtype_note": "f16 tables / MFMA operands, f32 accumulate, f32 planes and compositing",
             "data": "synthetic",
             "config": {"workload": desc, "rays_per_gpu_per_step": n_rays, "samples_per_ray": 768,
                        "global_rays_per_step": n_rays * world,
@@ -701,16 +774,17 @@ def _run(args):
             "variants": variants,
         }
         if inference:
-            line["eval"] = {"chamfer_distance_m2, f_score@0.05": [float(v) for v in meter.measure()], "frames": meter.N,
-                            "note": "random-init field vs synthetic ground truth: exercises the eval path, not a quality claim"}
+            detail["eval"] = {"chamfer_distance_m2, f_score@0.05": [float(v) for v in meter.measure()], "frames": meter.N,
+                              "note": "random-init field vs synthetic ground truth: exercises the eval path, not a quality claim"}
         if world == 1 and not args.no_cpu_baseline and not inference:
             with tempfile.TemporaryDirectory() as td:
                 ref_path = os.path.join(td, "parity_ref.npz")
-                line["cpu_baseline"] = cpu_baseline(51, KITTI360_SCALE, ref_path)
+                detail["cpu_baseline"] = cpu_baseline(51, KITTI360_SCALE, ref_path)
                 try:
-                    line["parity"] = parity_against(ref_path, dev, KITTI360_SCALE) if os.path.exists(ref_path) else None
+                    detail["parity"] = parity_against(ref_path, dev, KITTI360_SCALE) if os.path.exists(ref_path) else None
                 except Exception as e:  # the bench line must still be produced
-                    line["parity"] = {"error": repr(e)[:300]}
+                    detail["parity"] = {"error": repr(e)[:300]}
+        line = compact_line(detail, args)
     if world > 1 or force_dist:
         dist.destroy_process_group()
     return line

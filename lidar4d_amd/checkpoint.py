@@ -70,6 +70,7 @@ def load_checkpoint(path, model, opt=None, ema=None, scaler=None, model_only=Fal
         opt.load_state_dict(ckpt["optimizer"])
         if "lr_scheduler" in ckpt:  # iterations of the LambdaLR (stepped every iteration, also when the scaler skipped)
             opt.step_count = int(ckpt["lr_scheduler"]["last_epoch"])
+            opt.sync_device_schedule()
     if scaler is not None and ckpt.get("scaler"):
         scaler.load_state_dict(ckpt["scaler"])
     return info

@@ -335,6 +335,13 @@ class FlatAdam:
             steps[r] = max(steps[r], int(float(st["step"])))
         self.steps.copy_(torch.tensor(steps, dtype=torch.int32))
         self.step_count = max(steps) if steps else 0  # checkpoint.load_checkpoint overrides it with the scheduler's count
+        self.sync_device_schedule()
+
+    def sync_device_schedule(self):
+        """The device-side LR schedule ([iterations, factor], created by the first graphed step) follows ``step_count`` again --
+        after a checkpoint load the old iteration count would otherwise keep driving the learning rate."""
+        if self.sched is not None:
+            self.sched.copy_(torch.tensor([float(self.step_count), 0.1 ** min(self.step_count / self.iters, 1.0)]))
 
     def step(self, grad_scale=1.0, scaler=None):
         st = self.store
@@ -653,6 +660,9 @@ class Trainer:
             for k, v in self.dataset.batch_for(frame).items():
                 if torch.is_tensor(v):
                     rec["static"][k].copy_(v)
+        # The captured step holds no fp32 -> fp16 refresh (it was captured right after an Adam step, when the copy was current);
+        # parameters written outside the graph (EMA copy_to / restore, load_state_dict) are cast here -- a host no-op while current.
+        self.model._store.refresh16()
         rec["graph"].replay()
         self.opt.step_count += 1
         self._step_host_bookkeeping()

@@ -119,6 +119,7 @@ def test_bench_multi_rank_launch_plumbing(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
+    assert len(lines[0]) < 4096  # what the driver can parse
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     # more ranks than devices: refused loudly, nothing that looks like a result on stdout
@@ -126,3 +127,32 @@ def test_bench_multi_rank_launch_plumbing(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=120, env=env, cwd=str(tmp_path))
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")
+
+
+def test_bench_line_is_compact(tmp_path, monkeypatch):
+    """the ONE stdout line of bench.py must stay parseable by the driver.  ``compact_line`` is fed the
+    largest detail record any round produced (round 3's 24 KB line) and must return < 4 KB of JSON that round-trips and
+    still carries the contract's fields, ``roofline`` (scalars only) and ``cpu_baseline``; the detail goes to the side file."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "DETAIL_PATH", str(tmp_path / "bench_detail.json"))
+    detail = json.load(open(os.path.join(root, "profiles", "r03_bench_c3_final.json")))
+    assert len(json.dumps(detail)) > 20000
+    line = bench.compact_line(detail, None)
+    s = json.dumps(line)
+    assert len(s) < bench.LINE_LIMIT == 4096
+    back = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity", "hash_encoder"):
+        assert k in back, k
+    assert back["config"]["workload"].startswith("C3") and back["config"]["skipped_steps_in_timed_region"] == 0
+    rf = back["roofline"]
+    assert all(not isinstance(v, (dict, list)) for v in rf.values())  # scalars only
+    assert rf["frac"] == detail["roofline"]["frac"] and rf["traffic"] > 0 and 0 < rf["l2_miss_rate"] < 1
+    assert back["cpu_baseline"]["kind"] == "port" and back["cpu_baseline"]["cores"] == 32
+    assert json.load(open(tmp_path / "bench_detail.json"))["roofline_kernels"] == detail["roofline_kernels"]
