@@ -60,12 +60,26 @@ __device__ __forceinline__ void group_taps(const FieldDesc& fd, int s, const flo
 // next (12.2 GB fetched for 3.4 GB of rows, profiles/r01_pmc_FETCH_SIZE_c3_v10.txt).  Each wave now copies the two column
 // ranges the kernel uses -- plane columns [0, 16 nS) and dynamic-hash columns -- of its 64 rows with full-width coalesced
 // loads into LDS (row pitch + 8 halfs: spreads the lanes' rows over the banks) and every piece is served from there.
+// Segment bounds: coordinates of the FIRST and LAST sample of every aligned 64-sample segment (= one wavefront's samples in the
+// multi-pass kernels below), [axis][segment][2].  planes_static_lds_kernel decides from them whether a wavefront misses a row
+// band; read from the [3][P] coordinate arrays, that test touched one 64-byte sector per lane and iteration for 8 bytes
+// -- 129 band passes x 196,608 segments x 2 sectors = 3.2 GB, most of what its counters showed above the compulsory bytes
+// (9.95 GB fetched for 3.62 GB, profiles/r03_pmc_rd.txt).  4.7 MB here, read densely.
+__device__ __forceinline__ void write_seg_bounds(float* __restrict__ segb, int64_t pr, int64_t P, int lane, const float4_t& c4) {
+  // lanes of a wave hold consecutive samples starting at a multiple of 64 (all callers); lanes past P carry the last valid sample
+  if (!segb || (lane != 0 && lane != 63) || pr - lane >= P) return;
+  const int64_t n_seg = (P + 63) >> 6, seg = pr >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) segb[((int64_t)a * n_seg + seg) * 2 + (lane == 63 ? 1 : 0)] = c4[a];
+}
+
 #define PREP_THREADS 128
 __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                             const float* __restrict__ tinfo,
                                                             int64_t P, const half_t* __restrict__ dX, int in_pad, float pscale,
                                                             half_t* __restrict__ gvs, half_t* __restrict__ gdynT,
-                                                            float* __restrict__ stats, int staged, float* __restrict__ xsoa) {
+                                                            float* __restrict__ stats, int staged, float* __restrict__ xsoa,
+                                                            float* __restrict__ segb) {
   constexpr int C = 8;
   extern __shared__ __attribute__((aligned(16))) half_t prep_lds[];
   const int64_t pr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,6 +94,7 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 #pragma unroll  // densely, instead of 16-byte xt rows
     for (int a = 0; a < 3; ++a) xsoa[(int64_t)a * P + pr] = c4[a];
   }
+  write_seg_bounds(segb, pr, P, lane, c4);
   const int nS = fd.planes.n_scales;
   const half_t* row = dX + p * in_pad;
   int dyn_shift = 0;  // staged: the dynamic-hash columns sit right behind the plane columns in the LDS row
@@ -184,6 +199,16 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 // plane instead of four taps), and the coordinate adjoint of a warped lookup is sum_c gv_c (row[x1] - row[x0])_c from the
 // same two texels -- 144 instead of 480 texel loads per sample in a kernel that is bound by their latency.
 #define TFRAMES 3
+// lanes a run of equal texels is merged over before the LDS atomics (16 = a whole DPP row: 4 scan steps per value; 8: 3 steps)
+#ifndef PDYN_MERGE
+#define PDYN_MERGE 16
+#endif
+#ifndef PDYN_FMA
+#define PDYN_FMA 0
+#endif
+#ifndef PSTAT_MERGE
+#define PSTAT_MERGE 16
+#endif
 #ifndef PDYN_THREADS
 #define PDYN_THREADS 768  // 12 waves on the one workgroup a CU can hold (138 KB of LDS; 155 VGPRs allow 3 per SIMD): 3.00 -> 2.73 ms against 512
 #endif
@@ -197,6 +222,7 @@ struct PrepOut {
   half_t* gdynT;
   float* xsoa;
   float* stats;
+  float* segb;
 };
 template <bool ROWS, bool PREP>
 __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
@@ -204,6 +230,12 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
                                                             int64_t P, int64_t chunk, const half_t* __restrict__ dX,
                                                             int in_pad, float pscale, const float* __restrict__ stats,
                                                             half_t* __restrict__ dflow16, PlaneRows prows, PrepOut po) {
+#if PDYN_FMA
+  // value arithmetic of THIS function body may contract a * b + c into one fma (texel interpolation, the coordinate adjoint's dot
+  // products): gradient values move in their last bit; cell / texel indices come from axis_tap (planes_dev.h), which is
+  // compiled under the file-wide -ffp-contract=off and still rounds like the forward pass
+#pragma clang fp contract(fast)
+#endif
   constexpr int C = 8;
   extern __shared__ int lds_i[];
   const int nS = fd.planes.n_scales;
@@ -255,6 +287,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
 #pragma unroll
         for (int a = 0; a < 3; ++a) po.xsoa[(int64_t)a * P + pr] = c4[a];
       }
+      if (pr - lane < hi_p) write_seg_bounds(po.segb, pr, P, lane, c4);  // (lanes past the chunk carry its last sample)
       const float xs0[4] = {c4[0], c4[1], c4[2], t0};
       for (int s = 0; s < nS; ++s) {  // static planes: gradient of plane j = dX_s * (product of the other two planes' values)
         float gs[C];
@@ -377,7 +410,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
             }
             gflow[(e - 1) * 3 + j] += gix * t.mx;
           }
-          const RowRuns runs = row_runs((uint32_t)t.x0);  // lanes of a run share x0, hence x1 too
+          const RowRuns runs = row_runs<PDYN_MERGE>((uint32_t)t.x0);  // lanes of a run share x0, hence x1 too
           int* acc = &lds_i[lds_off(s, j) + e * W * C];
 #pragma unroll
           for (int qx = 0; qx < 2; ++qx) {
@@ -386,7 +419,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
             float vals[C];
 #pragma unroll
             for (int k = 0; k < C; ++k) vals[k] = gv[k] * wxf;
-            row_scan<C>(runs, vals);
+            row_scan<C, PDYN_MERGE>(runs, vals);
             if (!runs.tail) continue;  // (inactive lanes carry zeros and a valid clamped key: harmless in any run)
             // (For a given k the lanes of an atomic -- run tails at different texels -- share the four banks = k (mod 8).  Rotating
             // the channel slots by the texel index spreads them over all 32 and was measured SLOWER, 4.14 -> 4.40 ms: the rotated
@@ -466,7 +499,7 @@ struct BandTasks {
 __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, BandTasks tasks, float* __restrict__ garena,
                                                                const float* __restrict__ xt, int64_t P, int64_t chunk,
                                                                int wave_skip, const half_t* __restrict__ gvs, float pscale,
-                                                               const float* __restrict__ stats) {
+                                                               const float* __restrict__ stats, const float* __restrict__ segb) {
   constexpr int C = 8;
   extern __shared__ int lds_i[];
   const int task = blockIdx.y;
@@ -492,11 +525,19 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
       const int64_t pw = lo_p + (it0 + lane_) * blockDim.x + (threadIdx.x & ~63);
       bool hit = false;
       if (it0 + lane_ < n_iter && pw < hi_p) {
-        const int64_t pl = min(pw + 63, hi_p - 1);
         int r0a, r1a, r0b, r1b;
         float w0, w1, m;
-        axis_tap(xt[(int64_t)b * P + pw], H, r0a, r1a, w0, w1, m);
-        axis_tap(xt[(int64_t)b * P + pl], H, r0b, r1b, w0, w1, m);
+        float cf, cl;  // band coordinate of the segment's first / last sample
+        if (segb) {  // one dense 8-byte load (chunks start at multiples of 64: pw is a segment start)
+          const float2_t fl = *reinterpret_cast<const float2_t*>(segb + ((int64_t)b * ((P + 63) >> 6) + (pw >> 6)) * 2);
+          cf = fl[0];
+          cl = fl[1];
+        } else {
+          cf = xt[(int64_t)b * P + pw];
+          cl = xt[(int64_t)b * P + min(pw + 63, hi_p - 1)];
+        }
+        axis_tap(cf, H, r0a, r1a, w0, w1, m);
+        axis_tap(cl, H, r0b, r1b, w0, w1, m);
         hit = !(max(r1a, r1b) < row0 || min(r0a, r0b) >= row0 + nrows);
       }
       todo = __ballot(hit);
@@ -526,7 +567,7 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
     const float wts[4] = {t.wx0 * t.wy0, t.wx1 * t.wy0, t.wx0 * t.wy1, t.wx1 * t.wy1};
     const int ys[4] = {t.y0, t.y0, t.y1, t.y1}, xs_[4] = {t.x0, t.x1, t.x0, t.x1};
     // runs of samples in one cell (same y0, x0 => same four taps and the same in0 / in1); inactive lanes form their own run
-    const RowRuns runs = row_runs(active ? (uint32_t)(t.y0 * W + t.x0) : 0xFFFFFFFFu);
+    const RowRuns runs = row_runs<PSTAT_MERGE>(active ? (uint32_t)(t.y0 * W + t.x0) : 0xFFFFFFFFu);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool in = q < 2 ? in0 : in1;
@@ -539,7 +580,7 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
         vals[k] = r[0];
         vals[k + 1] = r[1];
       }
-      row_scan<C>(runs, vals);
+      row_scan<C, PSTAT_MERGE>(runs, vals);
       if (!(runs.tail && in)) continue;
       int* dst = &lds_i[((ys[q] - row0) * W + xs_[q]) * C];
 #pragma unroll
@@ -649,7 +690,7 @@ __global__ void __launch_bounds__(256) dynhash_expand_kernel(FieldDesc fd, Field
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct WorkLayout {
-  int64_t gvs, gdynT, xsoa, stats, hbuf, bins, total;
+  int64_t gvs, gdynT, xsoa, segb, stats, hbuf, bins, total;
   int64_t hbuf_floats;
 };
 static WorkLayout work_layout(const l4d_field_desc* f, int64_t P) {
@@ -664,7 +705,8 @@ static WorkLayout work_layout(const l4d_field_desc* f, int64_t P) {
   w.gvs = w.hbuf + align256(hb * 4);
   w.gdynT = w.gvs + align256(P * f->n_scales * 3 * 8 * 2);
   w.xsoa = w.gdynT + align256(L3 * P * 2);
-  w.bins = w.xsoa + align256(3 * P * 4);
+  w.segb = w.xsoa + align256(3 * P * 4);
+  w.bins = w.segb + align256(3 * ((P + 63) / 64) * 2 * 4);
   w.total = w.bins + align256(bs_plan(make_grid_desc(&f->hash_static), 3, 4, P).bytes);
   return w;
 }
@@ -699,6 +741,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   half_t* gvs = (half_t*)(ws + w.gvs);
   half_t* gdynT = (half_t*)(ws + w.gdynT);
   float* xsoa = (float*)(ws + w.xsoa);  // [3][P] coordinates, written by the prep kernel
+  float* segb = getenv("L4D_NO_SEG_BOUNDS") ? nullptr : (float*)(ws + w.segb);  // [3][P / 64][2] first / last coordinate per 64-sample segment
   l4d_fill_async(ws, 0u, (int64_t)w.gvs, stream);  // stats + Hbuf
   l4d_copy_words_async(stats + ST_VMAX, plane_abs_max, 1, stream);
 
@@ -731,7 +774,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     const int staged = (colD_ % 8 == 0 && L3 % 8 == 0) ? 1 : 0;  // 16-byte pieces
     const int lds = staged ? PREP_THREADS * (colsA_ + L3 + 8) * 2 : 0;
     L4D_LAUNCH(field_bwd_prep_kernel, dim3((unsigned)ceil_div64(P, PREP_THREADS)), dim3(PREP_THREADS), lds, prep_side ? s_lds : stream, d, xt, tinfo, P,
-               (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, staged, xsoa);
+               (const half_t*)dX, in_pad, param_scale, gvs, gdynT, stats, staged, xsoa, segb);
   }
 
   if (forked && !fused_prep && !prep_side) {  // after the prep kernel
@@ -752,7 +795,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       for (int j = 0; j < 3; ++j) lds += TFRAMES * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
     const PlaneRows pr = make_plane_rows(d, plane_rows);
-    const PrepOut po{gvs, gdynT, xsoa, stats};
+    const PrepOut po{gvs, gdynT, xsoa, stats, segb};
     if (plane_rows) {
       L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, stream, d, pr, tinfo, plane_rows);
       if (fused_prep) {
@@ -797,7 +840,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       }
     (void)hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     L4D_LAUNCH(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, s_lds, d, t, fg.planes_cl, xsoa, P, chunk,
-                       wave_skip, gvs, param_scale, stats);
+                       wave_skip, gvs, param_scale, stats, wave_skip ? segb : nullptr);
   }
   // dynamic hash
   {

@@ -46,11 +46,16 @@ struct RowRuns {
   bool tail;             // this lane is the last of its run
 };
 // n_heads (optional): number of runs in the wave (64 = nothing to merge)
+// WIDTH (16 / 8 / 4): runs are additionally cut at multiples of WIDTH lanes, so that row_scan needs log2(WIDTH) steps only
+// (fewer v_fmac_dpp per value, more run tails, i.e. more LDS atomics: a trade the VALU-bound plane adjoints can choose)
+template <int WIDTH = 16>
 __device__ __forceinline__ RowRuns row_runs(uint32_t key, int* n_heads = nullptr) {
   const int lane = __lane_id();
   // old = ~key with bound_ctrl off: the first lane of a row keeps ~key, i.e. always starts a run
   const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
-  const unsigned long long H = __ballot(key != prev);                  // run heads
+  unsigned long long H = __ballot(key != prev);                        // run heads
+  if (WIDTH == 8) H |= 0x0101010101010101ull;
+  if (WIDTH == 4) H |= 0x1111111111111111ull;
   if (n_heads) *n_heads = __popcll(H);
   const unsigned long long le = H & (~0ull >> (63 - lane));            // heads at or below this lane (never empty)
   const int off = lane - (63 - __clzll((long long)le));                // distance to this lane's run head, 0..15
@@ -62,7 +67,7 @@ __device__ __forceinline__ RowRuns row_runs(uint32_t key, int* n_heads = nullptr
   r.tail = lane == 63 || ((H >> (lane + 1)) & 1ull) != 0ull;
   return r;
 }
-template <int K>
+template <int K, int WIDTH = 16>
 __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
   // v += flag * dpp_row_shr(v) as ONE instruction.  (hipcc keeps a v_mov_b32_dpp + v_fmac pair for the builtin form.)
   // Inline asm is invisible to the hazard recogniser: an EXEC write needs 5 wait states before a DPP op and a VALU write
@@ -75,12 +80,16 @@ __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
   if (K < 3) asm volatile("s_nop 1");
 #pragma unroll
   for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f2, 2);
-  if (K < 3) asm volatile("s_nop 1");
+  if (WIDTH > 4) {
+    if (K < 3) asm volatile("s_nop 1");
 #pragma unroll
-  for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f4, 4);
-  if (K < 3) asm volatile("s_nop 1");
+    for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f4, 4);
+  }
+  if (WIDTH > 8) {
+    if (K < 3) asm volatile("s_nop 1");
 #pragma unroll
-  for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f8, 8);
+    for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f8, 8);
+  }
 #undef L4D_FMAC_DPP
 }
 
