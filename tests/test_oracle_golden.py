@@ -107,6 +107,42 @@ def test_hashgrid4d_glue(golden, fp32_oracle):
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("reduction", ["concat", "prod", "sum", "mean"])
+@pytest.mark.parametrize("decompose", [True, False])
+def test_hashgrid4d_variants(golden, fp32_oracle, reduction, decompose):
+    """The NON-default options of HashGrid4D (hash_field.py:16-27,101-102,134-138,146-172) as the reference's own module
+    computes them (oracle/make_golden_variants.py): the restatement in oracle/fields_ref.py -- what the GPU test
+    test_hashgrid4d_reduction_and_decompose compares the HIP path with -- pinned for every (reduction, decompose) pair,
+    outputs at an interior and an integer slice time, gradients of every touched table."""
+    from oracle.make_golden_variants import KW
+    g = golden("hashgrid4d_variants")
+    tag = f"{reduction}_{'dec' if decompose else 'cat'}"
+    kw = dict(KW, hash_size_dynamic=tuple(KW["hash_size_dynamic"]))
+    hg = fields_ref.HashGrid4D(decompose=decompose, reduction=reduction, **kw)
+    assert hg.n_output_dims == int(g[f"{tag}.n_output_dims"])
+    with torch.no_grad():
+        for n, p in hg.named_parameters():
+            p.copy_(det_uniform(tuple(p.shape), "hv:" + n, -0.5, 0.5))
+    x = T(g["x"])
+    for tname, t in (("t03", torch.tensor([[0.3]])), ("t1", torch.tensor([[1.0]]))):
+        out = hg(x, t)
+        assert isinstance(out, (list, tuple)) == bool(g[f"{tag}.{tname}.is_list"])
+        cat = torch.cat(list(out), -1) if isinstance(out, (list, tuple)) else out
+        close(cat, g[f"{tag}.{tname}.out"], atol=2e-6)
+        for p in hg.parameters():
+            p.grad = None
+        (cat * T(g[f"{tag}.{tname}.g"])).sum().backward()
+        pinned = 0
+        for n, p in hg.named_parameters():
+            key = f"{tag}.{tname}.grad.{n}"
+            if key in g.files:
+                close(p.grad, g[key], rtol=1e-4, atol=1e-5)
+                pinned += 1
+            elif not n.startswith("hash_static"):  # a time slice the reference did not touch
+                assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n
+        assert pinned >= 3
+
+
 @pytest.fixture(scope="module")
 def small_model():
     from oracle import tcnn_ref
