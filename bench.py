@@ -349,7 +349,8 @@ def compact_line(detail, args):
                             "l2_miss_rate": _r(miss / req) if req and miss is not None else None,
                             "bytes_per_launch": rf["bytes_per_launch"], "avg_launch_ms": rf["avg_launch_ms"], "samples_per_launch": rf["samples_per_launch"],
                             "hash_gathers_G_per_s": rf.get("hash_gathers_G_per_s"), "gather_peak_G_per_s": GATHER_PEAK_G if rf.get("hash_gathers_G_per_s") else None,
-                            "compulsory_hbm_frac": rf.get("compulsory_hbm_frac")}
+                            "compulsory_hbm_frac": rf.get("compulsory_hbm_frac"),
+                            "pmc_check_clean": (rf.get("pmc_check") or {}).get("clean")}
     else:
         line["roofline"] = None
     he = detail.get("hash_encoder")
@@ -621,13 +622,24 @@ def _run(args):
                 return {}, "dropped: measured on another build of the library (%s..., loaded %s...)" % (str(d.get("library_sha256"))[:12], lib_sha[:12])
             return d, "profiles/" + name
 
-        traffic_file, traffic_src = load_pmc("hbm_traffic_r03.json")
+        def newest(pattern):  # the latest round's counter file that exists (tools/gpu_profile_round.sh <tag>)
+            import glob
+            c = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+            return os.path.basename(c[-1]) if c else pattern
+
+        traffic_file, traffic_src = load_pmc(newest("hbm_traffic_r[0-9][0-9].json"))
         traffic = traffic_file.get("kernels", {})
-        mfma_pmc, mfma_src = load_pmc("r03_mfma_pmc.json")
+        mfma_pmc, mfma_src = load_pmc(newest("r[0-9][0-9]_mfma_pmc.json"))
         def pmc_lookup(table, name):
-            """profiles/ keys carry every template argument (rocprofv3's symbol), launch-site names only the explicit ones."""
+            """profiles/ keys carry every template argument (rocprofv3's symbol), launch-site names only the explicit ones -- and the
+            sorted scatter's launch macro leaves the compile-time bin size as the token DEF (binscatter.hip BS_LAUNCH): that is the
+            instantiation whose last argument is not 0 (0 = run-time bin size)."""
             if name in table:
                 return table[name]
+            if name.endswith(", DEF>"):
+                for k, v in table.items():
+                    if k.startswith(name[:-len("DEF>")]) and not k.endswith(", 0>"):
+                        return v
             for k, v in table.items():
                 if name.endswith(">") and k.startswith(name[:-1] + ","):
                     return v
@@ -666,6 +678,22 @@ def _run(args):
         rows.sort(key=lambda r: -r["ms_per_step"])
         roofline_kernels = rows
         modelled = [r for r in rows if "bound" in r]
+        # counter hygiene: every modelled kernel should carry counter traffic of THIS build, and the memory-side
+        # bytes cannot be smaller than what the kernel must move once (hbm-bound models: compulsory bytes; gather kernels: their
+        # compulsory streams) -- a violation means a wrong byte model or a wrong request-size conversion, and is reported, not hidden
+        pmc_check = None
+        if traffic:
+            missing = [r["kernel"] for r in modelled if not r.get("traffic")]
+            low = []
+            for r in modelled:
+                if r.get("traffic"):
+                    must = r["bytes_per_launch"] if r["bound"] == "hbm" else models[r["kernel"]].get("hbm", 0)
+                    ratio = r["traffic"]["bytes_per_launch"] / max(must, 1)
+                    r["counter_over_compulsory"] = round(ratio, 3)
+                    if ratio < 0.95:
+                        low.append({"kernel": r["kernel"], "ratio": round(ratio, 3)})
+            pmc_check = {"modelled_kernels": len(modelled), "without_traffic": missing, "counter_below_0.95x_compulsory": low,
+                         "clean": not missing and not low}
         if modelled:
             d = modelled[0]  # the dominant modelled kernel
             roofline = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": d["peak"], "unit": "GB/s",
@@ -679,7 +707,7 @@ def _run(args):
                         "frac_of_measured_random_gather_rate": d.get("frac_of_measured_random_gather_rate"),
                         "gather_rate_note": "the vector-memory path retires a 64-lane gather of 64 distinct L2-resident lines at 292 G lane-loads/s chip-wide "
                                             "(64 G/s on L2 misses), measured with tools/ubench/gather.hip: that rate, not a byte rate, is what binds this kernel",
-                        "samples_per_launch": P, "attribute_rows": M}
+                        "samples_per_launch": P, "attribute_rows": M, "pmc_check": pmc_check}
         mfma = {"kernels": mf, "peak_tflops": MFMA_F16_PEAK_TFLOPS,
                 "pmc_source": (mfma_src + " (rocprofv3 --pmc pass of this command on this build: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))") if mfma_pmc else mfma_src,
                 "note": "algorithmic flops = the network's multiply-adds; the backward kernels execute about twice that on the matrix cores (operands are "

@@ -52,6 +52,9 @@
 #ifndef BS_UNROLL
 #define BS_UNROLL 4
 #endif
+#ifndef BS_MIN_WAVES
+#define BS_MIN_WAVES 4  // pass 1: wavefronts per SIMD the register allocation must leave room for (128 registers)
+#endif
 
 template <int NV>
 struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
@@ -66,7 +69,7 @@ __device__ __forceinline__ void pack_payload(const float v[NV], uint32_t out[(NV
 }
 
 template <int D, int NV>
-__global__ void __launch_bounds__(BS_THREADS, 2048 / BS_THREADS) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
+__global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
                                                               BsCols cols, const half_t* __restrict__ g, int g_stride, int g_col,
                                                               float pre_scale, int shift, int64_t n_wg,
                                                               uint16_t* __restrict__ offs, uint32_t* __restrict__ bins,
@@ -451,6 +454,135 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   }
 }
 
+// ---- pass 2, flattened -----------------------------------------------------------------------------------------------------
+// bin_pass2_kernel gives every run (one pass-1 tile's records for this bin: 8 on average with pair records, Poisson-distributed)
+// to a group of BS_GROUP lanes, and a wavefront runs as many rounds as its LONGEST run needs: with 8 +- 3 records per run nearly
+// every wavefront runs two rounds of eight lanes per group for eight records -- half the lanes of every instruction idle in a
+// kernel that is bound by its ~100 VALU instructions per record (SQ_ACTIVE_INST_VALU x 8 wavefronts per SIMD = 80 %).
+// Here a wavefront takes 64 CONSECUTIVE tiles, reads their 64 + 64 bin offsets with two dense loads, forms the exclusive prefix of
+// the run lengths, and walks the concatenation of the 64 runs 64 records at a time: lane j of round q0 handles record q0 + j,
+// whichever run it belongs to.  The owner of a record position is found without a search: every tile's lane stamps its lane
+// number at the position where its run enters the 64-record window (LDS, one word per position, tagged with the round so that
+// nothing is ever cleared), and an inclusive maximum scan over the lanes (six DPP steps) hands every position the last stamp at
+// or before it -- runs are laid out in lane order, so that is its owner.  One ds_bpermute brings the owner's (slot start - prefix).
+template <int D, int NV, int CSHIFT = 0>
+__global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int shift_rt, int n_wg, int64_t P,
+                                                            const uint16_t* __restrict__ offs, const uint32_t* __restrict__ bins,
+                                                            const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
+  constexpr int NC = 1 << D;
+  constexpr int NW = RecWords<NV>::n;
+  extern __shared__ long long acc[];
+  __shared__ uint32_t owner_tag[16][64];  // (not volatile: that turned the accesses into flat_load / flat_store; the asm memory clobber below orders them)
+  const int shift = CSHIFT > 0 ? CSHIFT : shift_rt;
+  const int lvl = blockIdx.y;
+  const int b = (BS_XCD_BINS && gridDim.x % 8 == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const uint32_t size = desc.size[lvl];
+  const bool hashed = (desc.hashed_mask >> lvl) & 1u;
+  const int nbins = (int)((size + (1u << shift) - 1) >> shift);
+  if (!hashed || !is_pow2(size) || nbins > BS_MAX_BINS || nbins <= 1 || b >= nbins) return;
+  const float gmax = lvl_max[lvl];
+  if (!(gmax > 0.0f)) return;
+  const uint32_t lo = (uint32_t)b << shift;
+  if (nonfinite(gmax)) {
+    if (threadIdx.x == 0) out[((size_t)desc.offset[lvl] + lo) * NV] = __builtin_nanf("");
+    return;
+  }
+  const int seg = CSHIFT > 0 ? (1 << CSHIFT) : (1 << shift);
+  const int n_ent = (int)min(1u << shift, size - lo);
+  const int n_el = n_ent * NV;
+  for (int i = threadIdx.x; i < seg * NV; i += blockDim.x) acc[i] = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  owner_tag[wave][lane] = 0xFFFFFFFFu;
+  __syncthreads();
+  const float fxs = fx_scale(gmax * 16.5f, 30);
+  auto add = [&](uint32_t w0, const uint32_t* wd) {  // as in bin_pass2_kernel
+    const half_t* hv = reinterpret_cast<const half_t*>(wd);
+    const uint32_t local = w0 & ((1u << BS_KEY_BITS) - 1u), code = (w0 >> BS_KEY_BITS) & 15u;
+    const bool single = code == BS_CODE_SINGLE;
+    const float f1 = single ? 0.0f : (float)(w0 >> (BS_KEY_BITS + 4)) * (1.0f / BS_FX_ONE);
+    const float s0 = (1.0f - f1) * fxs, s1 = f1 * fxs;
+    const uint32_t other = local ^ ((2u << code) - 1u);
+    unsigned long long* a0 = reinterpret_cast<unsigned long long*>(acc) + local;
+    unsigned long long* a1 = reinterpret_cast<unsigned long long*>(acc) + other;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const float v = h2f(hv[j]);
+      if (v != 0.0f) {
+        atomicAdd(a0 + j * seg, (unsigned long long)(long long)__float2int_rn(v * s0));
+        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)__float2int_rn(v * s1));
+      }
+    }
+  };
+  const uint16_t* o0 = offs + ((uint64_t)lvl * (BS_MAX_BINS + 1) + b) * n_wg;
+  const uint16_t* o1 = o0 + n_wg;
+  constexpr uint32_t SLOT = (uint32_t)(BS_THREADS * NC) * NW;
+  const uint32_t* lvl_bins = bins + (uint64_t)lvl * n_wg * SLOT;
+  uint32_t stamp = 0u;
+  const int n_batches = (n_wg + 63) >> 6;
+  // the offsets of a wavefront's NEXT batch are fetched while the current one is walked
+  int w_n = wave * 64 + lane;
+  uint32_t s0_n = 0u, s1_n = 0u;
+  if (wave < n_batches && w_n < n_wg) { s0_n = o0[w_n]; s1_n = o1[w_n]; }
+  for (int batch = wave; batch < n_batches; batch += n_waves) {
+    const uint32_t s0 = s0_n, c = s1_n - s0_n;
+    const int tile0 = batch * 64;
+    {
+      const int wn = (batch + n_waves) * 64 + lane;
+      s0_n = s1_n = 0u;
+      if (batch + n_waves < n_batches && wn < n_wg) { s0_n = o0[wn]; s1_n = o1[wn]; }
+    }
+    // inclusive prefix sum of the run lengths over the wavefront (DPP: row scan, then the row totals carried upwards)
+    uint32_t inc = c;
+#define L4D_ADD_DPP(ctrl, rmask) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, ctrl, rmask, 0xf, true)
+    L4D_ADD_DPP(0x111, 0xf);  // row_shr:1 (bound_ctrl: lanes without a source add 0)
+    L4D_ADD_DPP(0x112, 0xf);
+    L4D_ADD_DPP(0x114, 0xf);
+    L4D_ADD_DPP(0x118, 0xf);
+    L4D_ADD_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    L4D_ADD_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef L4D_ADD_DPP
+    const uint32_t P0 = inc - c;                                                   // records of the batch in front of this tile's run
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);         // records of the batch
+    const int base = (int)s0 - (int)P0;                                            // record position q -> index in the tile's slot
+    for (uint32_t q0 = 0; q0 < T; q0 += 64) {
+      ++stamp;
+      // this tile's run enters the window [q0, q0 + 64) at position max(P0, q0) - q0, if it overlaps it at all
+      if (c != 0u && P0 < q0 + 64u && P0 + c > q0) owner_tag[wave][P0 > q0 ? P0 - q0 : 0u] = (stamp << 8) | (uint32_t)lane;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint32_t tv = owner_tag[wave][lane];
+      int own = (tv >> 8) == stamp ? (int)(tv & 255u) : -1;
+#define L4D_MAXI_DPP(ctrl, rmask) own = max(own, __builtin_amdgcn_update_dpp(-1, own, ctrl, rmask, 0xf, false))
+      L4D_MAXI_DPP(0x111, 0xf);
+      L4D_MAXI_DPP(0x112, 0xf);
+      L4D_MAXI_DPP(0x114, 0xf);
+      L4D_MAXI_DPP(0x118, 0xf);
+      L4D_MAXI_DPP(0x142, 0xa);
+      L4D_MAXI_DPP(0x143, 0xc);
+#undef L4D_MAXI_DPP
+      const uint32_t q = q0 + (uint32_t)lane;
+      const bool ok = q < T;  // (then own >= 0: position q0 lies inside a run, whose tile stamped position 0)
+      const int ob = __shfl(base, ok ? own : lane, 64);
+      uint32_t key = BS_CODE_SINGLE << BS_KEY_BITS, wd[NW - 1];
+#pragma unroll
+      for (int k = 0; k < NW - 1; ++k) wd[k] = 0u;
+      if (ok) {
+        const uint32_t* rec = lvl_bins + (uint64_t)(uint32_t)(tile0 + own) * SLOT + (uint32_t)(ob + (int)q) * NW;
+        key = rec[0];
+#pragma unroll
+        for (int k = 0; k < NW - 1; ++k) wd[k] = rec[1 + k];
+      }
+      add(key, wd);
+    }
+  }
+  __syncthreads();
+  const double inv = (double)out_scale / (double)fxs;
+  float* o = out + ((size_t)desc.offset[lvl] + lo) * NV;
+  for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
+    const long long v = acc[(i % NV) * seg + i / NV];
+    if (v != 0) o[i] += (float)((double)v * inv);
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 // Entries per bin = 2^shift: the bin's int64 accumulators take 2^shift * NV * 8 bytes of LDS in pass 2 (64 KB -> two
 // workgroups per CU, which is what hides the latency of the record walk), and more, smaller bins spread the pass-1
@@ -459,6 +591,13 @@ static int bs_shift(int NV) {
   const char* e = getenv(NV == 4 ? "L4D_BS_SHIFT4" : NV == 2 ? "L4D_BS_SHIFT2" : "L4D_BS_SHIFT1");
   if (e && atoi(e) >= 9 && atoi(e) <= BS_KEY_BITS) return atoi(e);
   return NV == 4 ? 11 : NV == 2 ? 12 : 13;
+}
+
+// L4D_BS_FLAT=0 selects the run-per-lane-group form of pass 2 (bin_pass2_kernel); default: the flattened walk
+static bool bs_flat() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("L4D_BS_FLAT"); v = (e && atoi(e) == 0) ? 0 : 1; }
+  return v != 0;
 }
 
 BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
@@ -499,7 +638,11 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
     L4D_LAUNCH((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
                        g_col, pre_scale, pl.shift, (int64_t)pl.n_wg, offs, bins, lvl_max, out, out_scale);                                     \
     constexpr int DEF = V == 4 ? 11 : V == 2 ? 12 : 13;  /* bs_shift()'s defaults: compile-time bin size */                       \
-    if (pl.shift == DEF) {                                                                                                   \
+    if (pl.shift == DEF && bs_flat()) {                                                                                      \
+      (void)hipFuncSetAttribute((const void*)bin_pass2_flat_kernel<D, V, DEF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);  \
+      L4D_LAUNCH((bin_pass2_flat_kernel<D, V, DEF>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
+                 lvl_max, out, out_scale);                                                                                   \
+    } else if (pl.shift == DEF) {                                                                                                 \
       (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V, DEF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);       \
       L4D_LAUNCH((bin_pass2_kernel<D, V, DEF>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins,  \
                  lvl_max, out, out_scale);                                                                                   \

@@ -1,7 +1,12 @@
-"""Round-3 counter summaries.  Turns the --json dumps of tools/rocpd_pmc.py (separate rocprofv3 --pmc passes of `bench.py`)
-into the files bench.py attaches to its JSON line -- tied to the library build they were measured on:
+"""Counter summaries.  Turns the --json dumps of tools/rocpd_pmc.py (separate rocprofv3 --pmc passes of `bench.py`)
+into the files bench.py attaches to its detail record -- tied to the library build they were measured on:
 
-    python tools/pmc_round3.py <rd.json> <wr.json> <l2.json> <mfma.json> <out_dir> <tag> <path to liblidar4d_hip.so>
+    python tools/pmc_summary.py <rd.json> <wr.json> <l2.json> <mfma.json> <out_dir> <tag> <path to liblidar4d_hip.so>
+
+Round 4: gfx950 counts the memory-side read requests of the L2 BY SIZE (TCC_EA0_RDREQ_32B / _64B / _128B, counter_defs.yaml),
+so read bytes = 32 x n32 + 64 x n64 + 128 x n128 exactly; the per-kernel "access class" guess of round 3 (kept as a fallback
+for dumps without the size counters) is gone from the numbers -- it had classed the MLP kernels' row streams as 64-byte
+requests and reported fewer bytes than the rows they read.
 
 <out_dir>/hbm_traffic_<tag>.json   per kernel and launch, from the L2's memory-side request counters (the guide's FETCH_SIZE /
     WRITE_SIZE are derived from the same counters with a formula that assumes 64-byte requests):
@@ -48,13 +53,22 @@ def main(rd, wr, l2, mfma, out_dir, tag, lib):
         req = req or 0.0
         r32 = per_launch(R.get(k, {}), "TCC_EA0_RDREQ_32B_sum") or 0.0
         dram = per_launch(R.get(k, {}), "TCC_EA0_RDREQ_DRAM_sum")
+        if dram is None:  # round 4: counted in the write pass (four TCC slots per pass)
+            dram = per_launch(W.get(k, {}), "TCC_EA0_RDREQ_DRAM_sum")
         wreq = per_launch(W.get(k, {}), "TCC_EA0_WRREQ_sum") or 0.0
         w64 = per_launch(W.get(k, {}), "TCC_EA0_WRREQ_64B_sum") or 0.0
-        cls = "stream" if k.startswith(STREAM) else "sector"
+        n64 = per_launch(R.get(k, {}), "TCC_EA0_RDREQ_64B_sum")
+        n128 = per_launch(R.get(k, {}), "TCC_EA0_RDREQ_128B_sum")
         rb64, rb128 = (req - r32) * 64 + r32 * 32, (req - r32) * 128 + r32 * 32
-        rb = rb128 if cls == "stream" else rb64
+        if n64 is not None and n128 is not None:  # exact: requests counted by size
+            cls = "by_size"
+            rb = r32 * 32 + n64 * 64 + n128 * 128 + max(req - r32 - n64 - n128, 0.0) * 64
+        else:
+            cls = "stream" if k.startswith(STREAM) else "sector"
+            rb = rb128 if cls == "stream" else rb64
         wb = w64 * 64 + (wreq - w64) * 32
-        e = {"read_requests": req, "read_bytes_64": rb64, "read_bytes_128": rb128, "access_class": cls, "fetch_bytes": rb,
+        e = {"read_requests": req, "read_requests_32B": r32, "read_requests_64B": n64, "read_requests_128B": n128,
+             "read_bytes_64": rb64, "read_bytes_128": rb128, "access_class": cls, "fetch_bytes": rb,
              "write_bytes": wb, "bytes_per_launch": rb + wb, "dram_fraction": None if dram is None or req == 0 else round(dram / req, 4),
              "launches": (R.get(k) or W.get(k))[next(iter(R.get(k) or W.get(k)))]["launches"]}
         hit, miss, lreq = (per_launch(L.get(k, {}), c) for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"))
@@ -62,7 +76,7 @@ def main(rd, wr, l2, mfma, out_dir, tag, lib):
             e.update(l2_hit_rate=round(hit / (hit + miss), 4), l2_requests=lreq, l2_misses=miss)
         traffic[k] = e
     json.dump({"library_sha256": sha,
-               "source": "rocprofv3 --pmc (TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum | TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum | "
+               "source": "rocprofv3 --pmc (TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum | TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_DRAM_sum | "
                          "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum), separate passes of bench.py --steps 2 --warmup 1 (side streams off), workload c3",
                "note": "memory-side requests of the L2 (Infinity-Cache hits included; dram_fraction = share that reached HBM); request size by access class, "
                        "calibrated with tools/ubench/calib.hip", "kernels": traffic}, open(f"{out_dir}/hbm_traffic_{tag}.json", "w"), indent=1)
