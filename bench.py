@@ -726,7 +726,12 @@ def _run(args):
                                    b["time"].view(-1), float(np.float32(model.near_lidar)), float(np.float32(model.far_lidar)), model.bound)
         hash_enc = {"what": "static 3-D hash grid forward alone (l4d_hashgrid_fwd / l4d_hashgrid_fwd_ws), ray-ordered samples of one batch, F = 4, 2^19-entry tables, fp16; "
                             "rows_kernel: one thread per point, all levels; xcd_pinned: level l on XCD l % 8 (table L2-resident), level-major scratch, row assembly (both kernels timed)",
-                    "samples": xt.shape[0], "peak": HBM_PEAK_GBS, "unit": "GB/s", "target_frac": 0.40}
+                    "samples": xt.shape[0], "peak": HBM_PEAK_GBS, "unit": "GB/s", "target_frac": 0.40,
+                    # every table entry is one 8-byte lane of a gather instruction, and the vector-memory path retires at most
+                    # GATHER_PEAK_G lane-loads/s when every line hits L2 (tools/ubench/gather.hip): 292 G/s x 8 B = 2.34 TB/s
+                    "ceiling_frac": round(GATHER_PEAK_G * 8.0 / HBM_PEAK_GBS, 4),
+                    "ceiling_note": "8-byte entry gathers are bound by the gather ISSUE rate (292 G lane-loads/s all-hit, 64 G/s on L2 misses; "
+                                    "profiles/r02_ubench_gather.txt, r03_ubench_l2_window.txt), not by bytes: 0.40 of the HBM byte rate would need 400 G gathers/s"}
         for Lh in (8, 16):
             meta = GridMeta(3, Lh, 4, 19, 512, np.exp2(np.log2(32768 / 512) / (Lh - 1)))
             table = ((torch.rand(meta.n_params, device=dev) - 0.5)).half()

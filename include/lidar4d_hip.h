@@ -321,6 +321,51 @@ int l4d_chamfer_bwd(const float* xyz1, const float* xyz2, int32_t b, int32_t n, 
                     const float* grad_dist2, const int32_t* idx1, const int32_t* idx2, float* grad_xyz1,
                     float* grad_xyz2, void* stream);
 
+/* ---- step glue: batch assembly and loss evaluation either side of the render path, one launch each (csrc/glue.hip) ----
+ * l4d_lidar_ray_batch: rows / cols [n] int64 = the drawn pixels (data/base_dataset.py:36-70; cols are taken modulo W);
+ * pose [4,4] row-major sensor-to-world; (fov_up, fov) in degrees; image [H,W,3] ground-truth range image or null.
+ * -> rays_o, rays_d [n,3] (base_dataset.py:72-102), gt [n,3] = image at the pixels (kitti360_dataset.py:181-187),
+ * inds [n] = row * W + col. */
+int l4d_lidar_ray_batch(const int64_t* rows, const int64_t* cols, int32_t n, const float* pose, float fov_up, float fov,
+                        int32_t H, int32_t W, const float* image, float* rays_o, float* rays_d, float* gt, int64_t* inds,
+                        void* stream);
+/* model/runner.py:179-213 with the default criteria: loss[0] = sum over rays of alpha_d |d - d_gt| m + alpha_r (r - clamp(m,
+ * smooth, 1 - smooth))^2 + alpha_i ((i - i_gt) m)^2 with m = gt[:,0]; g_depth [n], g_image [n,2] = its gradients;
+ * pts (or null) [2,n,3] = predicted / ground-truth points along the rays in metres (runner.py:215-218: rays_d * depth * m / scale). */
+int l4d_lidar_losses(const float* depth, const float* image, const float* gt, const float* rays_d, int32_t n, float alpha_d,
+                     float alpha_r, float alpha_i, float smooth, float scale, float* loss, float* g_depth, float* g_image,
+                     float* pts, void* stream);
+/* ray-chamfer term (runner.py:215-220) behind l4d_chamfer_fwd on pts: loss[0] += coef * sum(dist1 + dist2) and g_depth +=
+ * its gradient wrt the rendered depth (coef = 0.5 / n / world for the reference's mean * 0.5). */
+int l4d_ray_chamfer_grad(const float* pts, const float* rays_d, const float* gt, const float* dist1, const float* dist2,
+                         const int32_t* idx1, const int32_t* idx2, int32_t n, float coef, float scale, float* loss,
+                         float* g_depth, void* stream);
+/* out_a[i] = a[i] * s[0] (na values), out_b[i] = b[i] * s[0] (nb values); s on the device */
+int l4d_scale_buffers(const float* a, float* out_a, int64_t na, const float* b, float* out_b, int64_t nb, const float* s,
+                      void* stream);
+
+/* scene-flow consistency loss (runner.py:222-253) around the flow field's own kernels (l4d_hashgrid_t_fwd / l4d_mlp_fwd and their
+ * adjoints):
+ *   l4d_flow_xt            xt [n,4] = [(pc + bound) / (2 bound), t[0]]                                   (lidar4d.py:133-137)
+ *   l4d_flow_warp          out [v,n,3] = pc + float(y16[:, col0[v] .. +2]) * step[v], v < n_variants <= 4 (runner.py:233-247)
+ *   l4d_flow_chamfer_grad  one chamfer term behind l4d_chamfer_fwd(p, q): partial[block] = share of sum(dist1) + sum(dist2);
+ *                          dy [n,6] (zero-filled by the caller) += step * d(0.5 (sum dist1 + sum dist2)) / dp in columns col0 .. +2
+ *   l4d_flow_loss_finish   loss[0] = 0.5 sum(partial) + w_ground sum |y_ground[:, :6]|; dy_g [ng,6] = w_ground sign(y_ground);
+ *                          amax[0] = max |dy|, amax[1] = max |dy_g|
+ *   l4d_flow_dy16          dy16 [n,16] fp16 = dy * g[0] * 2^k, k chosen on the device so that the largest entry lands in
+ *                          [2^11, 2^12); inv_out[0] = 2^-k                                               (flow_field.py _FlowFn.backward)
+ *   l4d_axpy_dev           y += a[0] * x, a on the device */
+int l4d_flow_xt(const float* pc, int32_t n, const float* t, float bound, float* xt, void* stream);
+int l4d_flow_warp(const float* pc, const void* y16, int32_t n, int32_t n_variants, const int32_t* col0, const float* step,
+                  float* out, void* stream);
+int l4d_flow_chamfer_grad(const float* p, int32_t n, const float* q, int32_t m, const float* dist1, const float* dist2,
+                          const int32_t* idx1, const int32_t* idx2, float step, int32_t col0, float* dy, float* partial,
+                          void* stream);
+int l4d_flow_loss_finish(const float* partial, int32_t n_partial, const void* y_ground16, int32_t ng, float w_ground, float* dy_g,
+                         const float* dy, int64_t n_dy, float* loss, float* amax, void* stream);
+int l4d_flow_dy16(const float* dy, int32_t n, const float* g, const float* amax, void* dy16, float* inv_out, void* stream);
+int l4d_axpy_dev(float* y, const float* x, int64_t n, const float* a, void* stream);
+
 /* ---- range image <-> point cloud : utils/convert.py:4-156 (SURVEY 8f "next" row 4) ----
  * pano_to_lidar_with_intensities (convert.py:99-137): pano [H,W] fp32 range image (0 = no return), intensities [H,W]
  * or null (-> 0); lidar_K = (fov_up, fov) in degrees.  points: room for H*W rows [x,y,z,intensity]; the non-empty

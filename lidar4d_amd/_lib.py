@@ -99,6 +99,16 @@ SIGNATURES = {
     "l4d_chamfer_workspace": [I32, I32, I32],
     "l4d_chamfer_fwd": [P, P, I32, I32, I32, P, P, P, P, P, P],
     "l4d_chamfer_bwd": [P, P, I32, I32, I32, P, P, P, P, P, P, P],
+    "l4d_lidar_ray_batch": [P, P, I32, P, F32, F32, I32, I32, P, P, P, P, P, P],
+    "l4d_lidar_losses": [P, P, P, P, I32, F32, F32, F32, F32, F32, P, P, P, P, P],
+    "l4d_ray_chamfer_grad": [P, P, P, P, P, P, P, I32, F32, F32, P, P, P],
+    "l4d_scale_buffers": [P, P, I64, P, P, I64, P, P],
+    "l4d_flow_xt": [P, I32, P, F32, P, P],
+    "l4d_flow_warp": [P, P, I32, I32, PI32, P, P, P],  # (col0 / step: small HOST arrays)
+    "l4d_flow_chamfer_grad": [P, I32, P, I32, P, P, P, P, F32, I32, P, P, P],
+    "l4d_flow_loss_finish": [P, I32, P, I32, F32, P, P, I64, P, P, P],
+    "l4d_flow_dy16": [P, I32, P, P, P, P, P],
+    "l4d_axpy_dev": [P, P, I64, P, P],
     "l4d_pano_to_lidar_workspace": [I32, I32],
     "l4d_pano_to_lidar": [P, P, I32, I32, F64, F64, P, P, P, P],
     "l4d_lidar_to_pano_workspace": [I32, I32],

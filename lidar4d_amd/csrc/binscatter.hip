@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   uint32_t fxq = 0u;  // keys[] carry the record's tz code in bits 24..27 from here on (entries per level <= 2^24: checked by the host side)
   if (pairs) {
     // one record per x-neighbour pair (corners 2q, 2q + 1): slots 0 .. NC/2 - 1 are used, the rest stay silent
-    fxq = (uint32_t)__float2int_rn(c.frac[0] * BS_FX_ONE);
+    fxq = (uint32_t)fx_round(c.frac[0] * BS_FX_ONE);
     const float fx = (float)fxq * (1.0f / BS_FX_ONE);
 #pragma unroll
     for (int q = 0; q < NC / 2; ++q) {
@@ -388,8 +388,8 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
     for (int j = 0; j < NV; ++j) {
       const float v = h2f(hv[j]);
       if (v != 0.0f) {  // (many payloads ARE zero: w * g below the smallest fp16 -- dropping this test cost 8 % / 35 % at NV = 4 / 2)
-        atomicAdd(a0 + j * seg, (unsigned long long)(long long)__float2int_rn(v * s0));
-        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)__float2int_rn(v * s1));
+        atomicAdd(a0 + j * seg, (unsigned long long)(long long)fx_round(v * s0));
+        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)fx_round(v * s1));
       }
     }
   };
@@ -508,8 +508,8 @@ __global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int
     for (int j = 0; j < NV; ++j) {
       const float v = h2f(hv[j]);
       if (v != 0.0f) {
-        atomicAdd(a0 + j * seg, (unsigned long long)(long long)__float2int_rn(v * s0));
-        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)__float2int_rn(v * s1));
+        atomicAdd(a0 + j * seg, (unsigned long long)(long long)fx_round(v * s0));
+        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)fx_round(v * s1));
       }
     }
   };

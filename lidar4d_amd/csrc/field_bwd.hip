@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
             int* dst = acc + xq * C;
 #ifndef ABL_NO_LDS_ATOMICS
 #pragma unroll
-            for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k]));
+            for (int k = 0; k < C; ++k) atomicAdd(dst + k, fx_round(vals[k]));
 #else
             asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
 #endif
@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
       if (!(runs.tail && in)) continue;
       int* dst = &lds_i[((ys[q] - row0) * W + xs_[q]) * C];
 #pragma unroll
-      for (int k = 0; k < C; ++k) atomicAdd(dst + k, __float2int_rn(vals[k]));
+      for (int k = 0; k < C; ++k) atomicAdd(dst + k, fx_round(vals[k]));
     }
     }  // while (todo)
   }
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
         uint32_t gv[2];
         const float w = corner<2>(c, k, gv);
         const int idx = (int)(FAST ? grid_index_fast<2>(gv, size - 1u) : grid_index<2>(gv, res, size, hashed)) - lo;
-        if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)(long long)__float2int_rn(go * w * fxs));
+        if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)(long long)fx_round(go * w * fxs));
       }
     }
   };

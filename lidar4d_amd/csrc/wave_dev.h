@@ -97,6 +97,20 @@ __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
 // fixed-point statistics double as the "gradient overflowed" signal of the adjoint chain (common.h, f2h_grad)
 __device__ __forceinline__ float amax_nf(float m, float v) { return nonfinite(v) ? __builtin_inff() : fmaxf(m, fabsf(v)); }
 
+// float -> fixed point for the integer LDS accumulators: floor(x + 0.5) as ONE instruction (v_cvt_rpi_i32_f32), where
+// __float2int_rn is v_rndne_f32 + v_cvt_i32_f32.  The adjoint kernels convert every contribution they accumulate (576 per
+// sample in the time-plane kernel alone) and are bound by VALU issue; exact ties round up instead of to even, which changes
+// nothing that is measurable (the quantum is 2^-26 ... 2^-30 of the largest gradient) and keeps sums exact and order-independent.
+__device__ __forceinline__ int fx_round(float x) {
+#ifdef L4D_FX_ROUND_RN
+  return __float2int_rn(x);
+#else
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+#endif
+}
+
 // fixed-point scale: largest power of two s with bound * s < 2^bits (bound > 0)
 __device__ __forceinline__ float fx_scale(float bound, int bits) {
   if (!(bound > 0.0f)) return 1.0f;

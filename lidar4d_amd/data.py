@@ -99,6 +99,7 @@ class SyntheticKitti360:
                  sort_pixels=False, frame_seed=None):
         self.device, self.H, self.W, self.num_frames, self.num_rays = device, H, W, num_frames, num_rays
         self.patch_size_lidar = 1  # settable like the reference's dataset attribute (runner.py:700-705): int or [px, py]
+        self.fused_batch = True  # batch_for: one HIP launch behind the two random draws (False: the torch restatement)
         self.sort_pixels = sort_pixels  # pixel_block_order; measured SLOWER on MI355X (66.3 vs 63.5 ms/step: neighbouring rays
         # pile onto the same LDS histogram bins / cache lines), kept as an option for experiments
         self.scale, self.fov = scale, fov
@@ -155,11 +156,22 @@ class SyntheticKitti360:
 
     def batch_for(self, frame):
         pose = self.poses[frame:frame + 1]
+        t = self.times[frame]
+        if self.fused_batch and self.device.type == "cuda" and self.patch_size_lidar == 1 and not self.sort_pixels:
+            # the two draws of get_lidar_rays (same generator consumption), then ONE launch for pixel index, direction,
+            # rotation, origin and the ground-truth gather (csrc/glue.hip: 33 torch launches otherwise)
+            from . import ops
+            n = min(self.num_rays, self.H * self.W)
+            top = torch.randint(0, self.H - 1, size=[n], device=self.device, generator=self.gen)
+            left = torch.randint(0, self.W, size=[n], device=self.device, generator=self.gen)
+            rays_o, rays_d, images, _ = ops.lidar_ray_batch(top, left, self.poses[frame], self.fov, self.H, self.W, self.images[frame])
+            return {"rays_o_lidar": rays_o, "rays_d_lidar": rays_d, "time": t, "images_lidar": images,
+                    "poses_lidar": pose, "H_lidar": self.H, "W_lidar": self.W, "index": [frame],
+                    "time_host": frame / (self.num_frames - 1)}
         rays = get_lidar_rays(pose, self.fov, self.H, self.W, self.num_rays, self.patch_size_lidar, generator=self.gen,
                               sort_pixels=self.sort_pixels and self.patch_size_lidar == 1)
         inds = rays["inds"]
         images = torch.gather(self.images[frame].view(1, -1, 3), 1, inds[..., None].expand(-1, -1, 3))
-        t = self.times[frame]
         return {"rays_o_lidar": rays["rays_o"], "rays_d_lidar": rays["rays_d"], "time": t, "images_lidar": images,
                 "poses_lidar": pose, "H_lidar": self.H, "W_lidar": self.W, "index": [frame],
                 "time_host": frame / (self.num_frames - 1)}  # the same number on the host: no read-back for host-side decisions

@@ -530,3 +530,78 @@ def dyn_pairs_build(slice_tables16, pairs):
     _chk(pairs, torch.float16, "pairs")
     n_entries = slice_tables16[0].numel() // 4
     call("l4d_dyn_pairs_build", _ptrs(slice_tables16), len(slice_tables16), n_entries, _p(pairs), _stream())
+
+
+# ---- step glue (csrc/glue.hip): batch assembly and loss evaluation, one launch each ------------------------------------------
+def lidar_ray_batch(rows, cols, pose, fov, H, W, image=None):
+    """Drawn pixels (rows / cols [n] int64 on the device) of one frame -> rays_o, rays_d [1,n,3], gt [1,n,3] (None without
+    ``image`` [H,W,3]), inds [1,n]: data/base_dataset.py:72-102 and the gather of kitti360_dataset.py:181-187 in one launch."""
+    _chk(rows, torch.int64, "rows"), _chk(cols, torch.int64, "cols"), _chk(pose, torch.float32, "pose")
+    n, dev = rows.numel(), rows.device
+    pose = pose.reshape(4, 4).contiguous()
+    rays_o = torch.empty(1, n, 3, dtype=torch.float32, device=dev)
+    rays_d = torch.empty(1, n, 3, dtype=torch.float32, device=dev)
+    inds = torch.empty(1, n, dtype=torch.int64, device=dev)
+    gt = None
+    if image is not None:
+        _chk(image, torch.float32, "image")
+        image = image.contiguous()
+        gt = torch.empty(1, n, 3, dtype=torch.float32, device=dev)
+    call("l4d_lidar_ray_batch", _p(rows.contiguous()), _p(cols.contiguous()), n, _p(pose), float(fov[0]), float(fov[1]), int(H), int(W),
+         _p(image), _p(rays_o), _p(rays_d), _p(gt), _p(inds), _stream())
+    return rays_o, rays_d, gt, inds
+
+
+def lidar_losses(depth, image, gt, rays_d, alpha_d, alpha_r, alpha_i, smooth, scale, want_points):
+    """runner.py:179-213 (default criteria) -> loss [1], g_depth [n], g_image [n,2], pts [2,n,3] or None."""
+    for t, nm in ((depth, "depth"), (image, "image"), (gt, "gt"), (rays_d, "rays_d")):
+        _chk(t, torch.float32, nm)
+    n, dev = depth.numel(), depth.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    g_depth = torch.empty(n, dtype=torch.float32, device=dev)
+    g_image = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    pts = torch.empty(2, n, 3, dtype=torch.float32, device=dev) if want_points else None
+    call("l4d_lidar_losses", _p(depth), _p(image), _p(gt), _p(rays_d), n, float(alpha_d), float(alpha_r), float(alpha_i), float(smooth),
+         float(scale), _p(loss), _p(g_depth), _p(g_image), _p(pts), _stream())
+    return loss, g_depth, g_image, pts
+
+
+def ray_chamfer_accumulate(pts, rays_d, gt, coef, scale, loss, g_depth):
+    """Chamfer distance between pts[0] and pts[1] (l4d_chamfer_fwd), then loss += coef * sum(dist1 + dist2) and g_depth += its
+    gradient wrt the rendered depth (l4d_ray_chamfer_grad): runner.py:215-220 with its autograd, three + five launches."""
+    n, dev = pts.shape[1], pts.device
+    if n == 0:
+        return
+    dist = torch.empty(2, n, dtype=torch.float32, device=dev)
+    idx = torch.empty(2, n, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.lib().l4d_chamfer_workspace(1, n, n), dtype=torch.uint8, device=dev)
+    call("l4d_chamfer_fwd", _p(pts[0]), _p(pts[1]), 1, n, n, _p(dist[0]), _p(dist[1]), _p(idx[0]), _p(idx[1]), _p(ws), _stream())
+    call("l4d_ray_chamfer_grad", _p(pts), _p(rays_d), _p(gt), _p(dist[0]), _p(dist[1]), _p(idx[0]), _p(idx[1]), n, float(coef), float(scale),
+         _p(loss), _p(g_depth), _stream())
+
+
+def scale_buffers(a, b, s):
+    """(a * s[0], b * s[0]) in one launch; s a one-element fp32 tensor on the device."""
+    out_a, out_b = torch.empty_like(a), torch.empty_like(b)
+    call("l4d_scale_buffers", _p(a), _p(out_a), a.numel(), _p(b), _p(out_b), b.numel(), _p(s), _stream())
+    return out_a, out_b
+
+
+def flow_xt(pc, t_dev, bound):
+    """[(pc + bound) / (2 bound), t] as [n,4] fp32 (lidar4d.py:133-137)."""
+    _chk(pc, torch.float32, "pc"), _chk(t_dev, torch.float32, "t")
+    n = pc.shape[0]
+    xt = torch.empty(n, 4, dtype=torch.float32, device=pc.device)
+    call("l4d_flow_xt", _p(pc), n, _p(t_dev), float(bound), _p(xt), _stream())
+    return xt
+
+
+def flow_warp(pc, y16, variants):
+    """variants: [(col0, step)] (<= 4) -> [v, n, 3] fp32: pc + float(y16[:, col0:col0+3]) * step."""
+    _chk(pc, torch.float32, "pc"), _chk(y16, torch.float16, "y16")
+    n, nv = pc.shape[0], len(variants)
+    out = torch.empty(nv, n, 3, dtype=torch.float32, device=pc.device)
+    col0 = (C.c_int32 * 4)(*[int(c) for c, _ in variants])
+    step = (C.c_float * 4)(*[float(s) for _, s in variants])
+    call("l4d_flow_warp", _p(pc), _p(y16), n, nv, col0, C.cast(step, C.c_void_p), _p(out), _stream())
+    return out

@@ -52,6 +52,39 @@ def lidar_loss(outputs, images_lidar, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, sm
     return loss.sum()
 
 
+class _PrimaryLossFn(torch.autograd.Function):
+    """``lidar_loss`` (+ ``ray_chamfer_loss / world``) with the reference's default criteria as one autograd node on
+    csrc/glue.hip: forward = l4d_lidar_losses (+ l4d_chamfer_fwd, l4d_ray_chamfer_grad), which also leaves the gradients wrt
+    the rendered depth / image; backward = one launch that scales them by the upstream gradient (the loss scale, a device
+    scalar).  Replaces ~70 element-wise torch launches per step (runner.py:179-220 as torch evaluates it)."""
+
+    @staticmethod
+    def forward(ctx, depth, image, gt, rays_d, alpha_d, alpha_r, alpha_i, smooth, scale, chamfer, world):
+        c = lambda t, *shape: t.detach().to(torch.float32).reshape(*shape).contiguous()
+        n = depth.numel()
+        gt_c, rd_c = c(gt, n, 3), c(rays_d, n, 3)
+        loss, g_depth, g_image, pts = ops.lidar_losses(c(depth, n), c(image, n, 2), gt_c, rd_c, alpha_d, alpha_r, alpha_i, smooth, scale,
+                                                       want_points=bool(chamfer))
+        if chamfer:
+            ops.ray_chamfer_accumulate(pts, rd_c, gt_c, 0.5 / max(n, 1) / world, scale, loss, g_depth)
+        ctx.save_for_backward(g_depth, g_image)
+        ctx.shapes = (depth.shape, image.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g_depth, g_image = ctx.saved_tensors
+        d, i = ops.scale_buffers(g_depth, g_image, g.detach().to(torch.float32).reshape(1).contiguous())
+        return (d.view(ctx.shapes[0]), i.view(ctx.shapes[1])) + (None,) * 9
+
+
+def primary_losses(outputs, data, scale, chamfer=True, world=1, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, smooth=0.2):
+    """= lidar_loss(outputs, images) [+ ray_chamfer_loss(outputs, data, scale) / world] for the default criteria (L1 / MSE /
+    MSE), evaluated by the fused HIP path (``_PrimaryLossFn``)."""
+    return _PrimaryLossFn.apply(outputs["depth_lidar"], outputs["image_lidar"], data["images_lidar"], data["rays_d_lidar"],
+                                alpha_d, alpha_r, alpha_i, smooth, scale, chamfer, world)
+
+
 def frame_index(time_lidar, num_frames):
     """``int(time_lidar * (num_frames - 1))`` as the reference evaluates it (runner.py:228, lidar4d.py:143): the product is
     an fp32 TENSOR product, truncated.  (In float64 the same expression lands just below k for 26 of the 51 default frame
@@ -172,7 +205,7 @@ def process_pointcloud(dataset, ground_split=None):
     return pc_list, pc_ground_list
 
 
-def flow_loss(model, pc_list, pc_ground_list, time_lidar, num_frames, t_ground=None, frame_idx=None):
+def flow_loss(model, pc_list, pc_ground_list, time_lidar, num_frames, t_ground=None, frame_idx=None, fused=False):
     """runner.py:222-253: two-step forward / backward chamfer consistency of the scene flow between neighbouring frames'
     point clouds (sum, not mean, of the squared distances) + 0.001 * L1 of the flow on ground points at a random time.
     ``t_ground`` replaces the reference's ``torch.rand(1)`` when given (tests).  ``frame_idx``: the value of
@@ -183,6 +216,19 @@ def flow_loss(model, pc_list, pc_ground_list, time_lidar, num_frames, t_ground=N
     if frame_idx is None:
         frame_idx = frame_index(time_lidar, num_frames)
     pc = pc_list[f"{frame_idx}"]
+    if fused and pc.is_cuda and pc.shape[0] > 0 and hasattr(model, "_store"):  # one autograd node on csrc/glue.hip
+        others = []
+        for step in (1, 2):
+            for sign, col0 in ((+1, 0), (-1, 3)):
+                other = pc_list.get(f"{frame_idx + sign * step}")
+                if other is not None and other.shape[0] > 0:
+                    others.append((other.contiguous(), float(step), col0))
+        ground = pc_ground_list[f"{frame_idx}"]
+        if ground.shape[0] and t_ground is None:
+            t_ground = torch.rand(1, device=ground.device)
+        tg = None if t_ground is None else t_ground.reshape(1).to(device=pc.device, dtype=torch.float32).contiguous()
+        return _SceneFlowLossFn.apply(model, pc.contiguous(), others, ground.contiguous() if ground.shape[0] else None,
+                                      time_lidar.reshape(1).to(torch.float32).contiguous(), tg, *fn_params(model))
     pred = model.flow(pc, time_lidar)
     loss = pc.new_zeros(())
     for step in (1, 2):
@@ -200,6 +246,91 @@ def flow_loss(model, pc_list, pc_ground_list, time_lidar, num_frames, t_ground=N
         zero_flow = model.flow(ground, t_ground.reshape(1, 1).to(ground))
         loss = loss + 0.001 * (zero_flow["forward"].float().abs().sum() + zero_flow["backward"].float().abs().sum())
     return loss
+
+
+class _SceneFlowLossFn(torch.autograd.Function):
+    """``flow_loss`` (runner.py:222-253) as ONE autograd node for a ``LiDAR4D`` with its flat parameter store: the flow field is
+    evaluated with the render path's own kernels (l4d_flow_xt -> l4d_hashgrid_t_fwd -> l4d_mlp_fwd), the warped clouds, the
+    chamfer terms' sums and their gradients wrt the flow outputs come from csrc/glue.hip, and the backward runs the flow field's
+    adjoint straight into the gradient arena (fp16 adjoints normalised on the device, as flow_field._FlowFn does).  About 50
+    launches instead of about 165 per step.
+    inputs: pc [n,3]; others [(cloud [m,3], step, col0)]; ground [ng,3] or None; t, t_ground one-element device tensors."""
+
+    @staticmethod
+    def forward(ctx, model, pc, others, ground, t_dev, t_ground, *params):
+        from .fused import _flow_w16
+        store, fn, dev = model._store, model.flow_net, pc.device
+        w16, grid16 = _flow_w16(model), store.half(fn.grid_enc.params)
+        keep_act = not ops.mlp_recompute_supported(fn.input_dim, fn.n_hidden)
+
+        def evaluate(points, t):
+            xt = ops.flow_xt(points, t, model.bound)
+            xf = ops.hashgrid_t_fwd(fn.grid_enc.meta, xt, (0, 1, 2), [grid16], xt[0, 3:4], half_out=True)
+            y, act = ops.mlp_fwd(xf, w16, fn.n_hidden, save_act=keep_act)
+            return xt, xf, act, y
+
+        n = pc.shape[0]
+        xt, xf, act, y = evaluate(pc, t_dev)
+        dy = torch.zeros(n, 6, dtype=torch.float32, device=dev)
+        blocks = [(max(n, o.shape[0]) + 255) // 256 for o, _, _ in others]
+        partial = torch.zeros(max(sum(blocks), 1), dtype=torch.float32, device=dev)
+        if others:
+            warped = ops.flow_warp(pc, y, [(col0, step) for _, step, col0 in others])
+            off = 0
+            for v, (other, step, col0) in enumerate(others):
+                m = other.shape[0]
+                dist = torch.empty(n + m, dtype=torch.float32, device=dev)
+                idx = torch.empty(n + m, dtype=torch.int32, device=dev)
+                ws = torch.empty(ops._lib.lib().l4d_chamfer_workspace(1, n, m), dtype=torch.uint8, device=dev)
+                ops.call("l4d_chamfer_fwd", ops._p(warped[v]), ops._p(other), 1, n, m, ops._p(dist[:n]), ops._p(dist[n:]), ops._p(idx[:n]),
+                         ops._p(idx[n:]), ops._p(ws), ops._stream())
+                ops.call("l4d_flow_chamfer_grad", ops._p(warped[v]), n, ops._p(other), m, ops._p(dist[:n]), ops._p(dist[n:]), ops._p(idx[:n]),
+                         ops._p(idx[n:]), float(step), int(col0), ops._p(dy), ops._p(partial[off:]), ops._stream())
+                off += blocks[v]
+        ng = 0 if ground is None else ground.shape[0]
+        ev_g, dy_g, y_g = None, None, None
+        if ng:
+            xt_g, xf_g, act_g, y_g = evaluate(ground, t_ground)
+            dy_g = torch.empty(ng, 6, dtype=torch.float32, device=dev)
+            ev_g = (xt_g, xf_g, act_g)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        amax = torch.empty(2, dtype=torch.float32, device=dev)
+        ops.call("l4d_flow_loss_finish", ops._p(partial), sum(blocks), ops._p(y_g), ng, 0.001, ops._p(dy_g), ops._p(dy), dy.numel(),
+                 ops._p(loss), ops._p(amax), ops._stream())
+        ctx.model = model
+        ctx.evals = [(xt, xf, act, dy, 0)] + ([ev_g + (dy_g, 1)] if ng else [])
+        ctx.amax = amax
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from .fused import _flow_w16, _flow_wgrad
+        model = ctx.model
+        store, fn = model._store, model.flow_net
+        store.prepare_grads()
+        dev = g.device
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        w16 = _flow_w16(model)
+        g_w, g_grid = _flow_wgrad(model), store.grad_view(fn.grid_enc.params)
+        for xt, xf, act, dy, which in ctx.evals:
+            k = dy.shape[0]
+            dy16 = torch.empty(k, 16, dtype=torch.float16, device=dev)
+            inv = torch.empty(1, dtype=torch.float32, device=dev)
+            ops.call("l4d_flow_dy16", ops._p(dy), k, ops._p(gs), ops._p(ctx.amax[which:]), ops._p(dy16), ops._p(inv), ops._stream())
+            # the adjoint kernels take their output scale from the host; the power of two is only known on the device: private
+            # buffers (sparse: most entries stay zero), then y += inv * x into the arena
+            gw = torch.zeros(w16.numel(), dtype=torch.float32, device=dev)
+            ggrid = torch.zeros(g_grid.numel(), dtype=torch.float32, device=dev)
+            dxf = ops.mlp_bwd(xf, act, dy16, w16, fn.n_hidden, gw, 1.0)
+            ops.hashgrid_t_bwd(fn.grid_enc.meta, xt, (0, 1, 2), 1, xt[0, 3:4], dxf, [ggrid], 1.0)
+            ops.call("l4d_axpy_dev", ops._p(g_w), ops._p(gw), gw.numel(), ops._p(inv), ops._stream())
+            ops.call("l4d_axpy_dev", ops._p(g_grid), ops._p(ggrid), ggrid.numel(), ops._p(inv), ops._stream())
+        return (None,) * (6 + len(fn_params(model)))
+
+
+def fn_params(model):
+    """The flow field's parameters in a fixed order (autograd inputs of _SceneFlowLossFn: grid table, then the linear layers)."""
+    return [model.flow_net.grid_enc.params] + [m.weight for m in model.flow_net.linears()]
 
 
 class DynamicLossScaler:
@@ -560,6 +691,10 @@ class Trainer:
         self.model, self.dataset, self.num_steps, self.chamfer = model, dataset, num_steps, chamfer
         self.flow, self.urf, self.iters = flow, urf, iters
         self.loss_kinds = dict(depth_loss=depth_loss, raydrop_loss=raydrop_loss, intensity_loss=intensity_loss)
+        # the default criteria run as one fused node (primary_losses); any other choice, or L4D_TORCH_LOSSES=1, takes the torch
+        # restatement of runner.py:179-220 (lidar_loss / ray_chamfer_loss)
+        self.fused_losses = (depth_loss, raydrop_loss, intensity_loss) == ("l1", "mse", "mse") and os.environ.get("L4D_TORCH_LOSSES") != "1"
+        self.fused_flow_loss = os.environ.get("L4D_TORCH_LOSSES") != "1"  # the scene-flow term as one autograd node (_SceneFlowLossFn)
         self.ema = FlatEMA(model, ema_decay) if ema_decay is not None else None  # runner.py:97-98
         self.epoch_steps = epoch_steps if epoch_steps is not None else getattr(dataset, "num_frames", 1)
         self.local_step = 0
@@ -579,13 +714,16 @@ class Trainer:
 
     def compute_loss(self, data, out):
         """The reference's training loss (runner.py:179-276,277-367) for one batch and its render outputs."""
-        loss = lidar_loss(out, data["images_lidar"], scale=self.dataset.scale, **self.loss_kinds)
-        if self.chamfer:
-            loss = loss + ray_chamfer_loss(out, data, self.dataset.scale) / self.world
+        if self.fused_losses and out["depth_lidar"].is_cuda:
+            loss = primary_losses(out, data, self.dataset.scale, chamfer=self.chamfer, world=self.world)
+        else:
+            loss = lidar_loss(out, data["images_lidar"], scale=self.dataset.scale, **self.loss_kinds)
+            if self.chamfer:
+                loss = loss + ray_chamfer_loss(out, data, self.dataset.scale) / self.world
         if self.flow:
             known = frame_index(data["time_host"], self.dataset.num_frames) if "time_host" in data else None
             loss = loss + flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames,
-                                    frame_idx=known)
+                                    frame_idx=known, fused=self.fused_flow_loss)
         patch = getattr(self.dataset, "patch_size_lidar", 1)
         if patch != 1:  # rays were drawn as pixel patches (runner.py:277-367); a sum over this rank's patches
             gt = data["images_lidar"]

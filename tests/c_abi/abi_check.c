@@ -20,6 +20,16 @@ int main(void) {
       (fn_t)&l4d_attr_scatter_bwd,
       (fn_t)&l4d_cast_f32_to_f16,
       (fn_t)&l4d_chamfer_bwd,
+      (fn_t)&l4d_lidar_ray_batch,
+      (fn_t)&l4d_lidar_losses,
+      (fn_t)&l4d_ray_chamfer_grad,
+      (fn_t)&l4d_scale_buffers,
+      (fn_t)&l4d_flow_xt,
+      (fn_t)&l4d_flow_warp,
+      (fn_t)&l4d_flow_chamfer_grad,
+      (fn_t)&l4d_flow_loss_finish,
+      (fn_t)&l4d_flow_dy16,
+      (fn_t)&l4d_axpy_dev,
       (fn_t)&l4d_chamfer_fwd,
       (fn_t)&l4d_chamfer_workspace,
       (fn_t)&l4d_composite_bwd,
