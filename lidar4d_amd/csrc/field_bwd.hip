@@ -787,6 +787,19 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   n_chunks = (int)ceil_div64(P, chunk);
   // consecutive-lane = consecutive-sample-of-one-ray property, needed for the wave-level band skip
   const int wave_skip = samples_per_ray > 0 && samples_per_ray % 64 == 0 && chunk % 64 == 0;
+  // the multi-pass LDS kernels may cut the samples into fewer, larger chunks than the time-plane kernel (whose grid IS the chunks):
+  // every workgroup flushes its whole LDS window once, so fewer chunks = less flush traffic (L4D_PSTAT_CHUNKS / L4D_DYNHASH_CHUNKS: tuning)
+  auto chunks_for = [&](const char* env, int dflt, int* n_out) -> int64_t {
+    const char* e = getenv(env);
+    int n = (e && atoi(e) >= 1 && atoi(e) <= 4096) ? atoi(e) : dflt;
+    n = (int)std::min<int64_t>(n, std::max<int64_t>(1, ceil_div64(P, 8192)));
+    int64_t c = ceil_div64(ceil_div64(P, n), 64) * 64;  // whole 64-sample segments
+    *n_out = (int)ceil_div64(P, c);
+    return c;
+  };
+  int n_chunks_ps = n_chunks, n_chunks_dh = n_chunks;
+  const int64_t chunk_ps = wave_skip ? chunks_for("L4D_PSTAT_CHUNKS", n_chunks, &n_chunks_ps) : chunk;
+  const int64_t chunk_dh = wave_skip ? chunks_for("L4D_DYNHASH_CHUNKS", n_chunks, &n_chunks_dh) : chunk;
 
   // time planes
   {
@@ -839,7 +852,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
         }
       }
     (void)hipFuncSetAttribute((const void*)planes_static_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    L4D_LAUNCH(planes_static_lds_kernel, dim3(n_chunks, t.n), dim3(1024), max_lds, s_lds, d, t, fg.planes_cl, xsoa, P, chunk,
+    L4D_LAUNCH(planes_static_lds_kernel, dim3(n_chunks_ps, t.n), dim3(1024), max_lds, s_lds, d, t, fg.planes_cl, xsoa, P, chunk_ps,
                        wave_skip, gvs, param_scale, stats, wave_skip ? segb : nullptr);
   }
   // dynamic hash
@@ -865,7 +878,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
     (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DYNHASH_LDS_KB * 1024);
-    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks, t.n), dim3(1024), DYNHASH_LDS_KB * 1024, s_lds, d, t, xsoa, P, chunk, gdynT, stats, Hbuf);
+    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks_dh, t.n), dim3(1024), DYNHASH_LDS_KB * 1024, s_lds, d, t, xsoa, P, chunk_dh, gdynT, stats, Hbuf);
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);
