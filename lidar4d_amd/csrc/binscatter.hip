@@ -625,8 +625,12 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   BsCols c;
   for (int d = 0; d < 3; ++d) c.c[d] = d < n_dims ? cols[d] : 0;
   if ((int64_t)desc.n_levels * (BS_MAX_BINS + 1) * pl.n_wg >= ((int64_t)1 << 32)) { l4d_set_error(1, "bs_scatter: too many points for one launch"); return 1; }
-  for (int l = 0; l < desc.n_levels; ++l)
-    if (desc.size[l] > (1u << 24)) { l4d_set_error(1, "bs_scatter: more than 2^24 entries per level"); return 1; }
+  for (int l = 0; l < desc.n_levels; ++l) {  // the pair records carry their code in key bits 24..27: BINNED levels only (hashed,
+    // power-of-two table, <= BS_MAX_BINS bins); larger tables never reach the binned path (atomic fallback) and need no limit
+    const int64_t nb = ((int64_t)desc.size[l] + (1 << pl.shift) - 1) >> pl.shift;
+    const bool binned = ((desc.hashed_mask >> l) & 1u) && is_pow2(desc.size[l]) && nb <= BS_MAX_BINS && nb > 1;
+    if (binned && desc.size[l] > (1u << 24)) { l4d_set_error(1, "bs_scatter: more than 2^24 entries in a binned level"); return 1; }
+  }
   int max_bins = 1;
   for (int l = 0; l < desc.n_levels; ++l) max_bins = std::max<int>(max_bins, (int)(((int64_t)desc.size[l] + (1 << pl.shift) - 1) >> pl.shift));
   max_bins = std::min(max_bins, BS_MAX_BINS);

@@ -89,10 +89,26 @@ extern "C" int l4d_profile_get(int i, const char** name, float* ms) {
 #include <stdlib.h>
 #define L4D_N_SIDE 3
 #define L4D_N_EVENTS 32
-static hipStream_t g_side[L4D_N_SIDE];
-static hipEvent_t g_events[L4D_N_EVENTS];
-static bool g_side_ready = false, g_side_busy[L4D_N_SIDE] = {false, false, false};
-static int g_event_next = 0, g_streams_mask = -1;
+// one pool of side streams / events PER DEVICE (a process may drive several GPUs: a stream belongs to the device it was created on)
+#define L4D_MAX_DEVICES 16
+struct SidePool {
+  hipStream_t side[L4D_N_SIDE];
+  hipEvent_t events[L4D_N_EVENTS];
+  bool ready, busy[L4D_N_SIDE];
+  int event_next;
+};
+static SidePool g_pools[L4D_MAX_DEVICES];
+static int g_streams_mask = -1;
+static SidePool* cur_pool() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= L4D_MAX_DEVICES) return nullptr;
+  return &g_pools[dev];
+}
+#define g_side (pool->side)
+#define g_events (pool->events)
+#define g_side_ready (pool->ready)
+#define g_side_busy (pool->busy)
+#define g_event_next (pool->event_next)
 
 extern "C" int l4d_streams_mask(void) {
   if (g_streams_mask < 0) {
@@ -105,7 +121,8 @@ extern "C" int l4d_streams_config(int32_t mask) {
   g_streams_mask = mask;
   return 0;
 }
-static int side_init() {
+static int side_init(SidePool* pool) {
+  if (!pool) { l4d_set_error(1, "side streams: no current device"); return 1; }
   if (g_side_ready) return 0;
   for (int i = 0; i < L4D_N_SIDE; ++i) {
     hipError_t e = hipStreamCreateWithFlags(&g_side[i], hipStreamNonBlocking);
@@ -118,15 +135,16 @@ static int side_init() {
   g_side_ready = true;
   return 0;
 }
-static hipEvent_t next_event() {
+static hipEvent_t next_event(SidePool* pool) {
   hipEvent_t ev = g_events[g_event_next];
   g_event_next = (g_event_next + 1) % L4D_N_EVENTS;
   return ev;
 }
 // side stream i continues from the current end of `from` (main stream or another side stream); returns it (null on failure)
 extern "C" void* l4d_side_fork(void* from, int32_t i) {
-  if (i < 0 || i >= L4D_N_SIDE || side_init()) return nullptr;
-  hipEvent_t ev = next_event();
+  SidePool* pool = cur_pool();
+  if (i < 0 || i >= L4D_N_SIDE || side_init(pool)) return nullptr;
+  hipEvent_t ev = next_event(pool);
   if (hipEventRecord(ev, (hipStream_t)from) != hipSuccess || hipStreamWaitEvent(g_side[i], ev, 0) != hipSuccess) {
     l4d_set_error(1, "l4d_side_fork");
     return nullptr;
@@ -136,8 +154,9 @@ extern "C" void* l4d_side_fork(void* from, int32_t i) {
 }
 // `into` waits for side stream i
 extern "C" int l4d_side_join(void* into, int32_t i) {
-  if (i < 0 || i >= L4D_N_SIDE || !g_side_ready || !g_side_busy[i]) return 0;
-  hipEvent_t ev = next_event();
+  SidePool* pool = cur_pool();
+  if (!pool || i < 0 || i >= L4D_N_SIDE || !g_side_ready || !g_side_busy[i]) return 0;
+  hipEvent_t ev = next_event(pool);
   hipError_t e = hipEventRecord(ev, g_side[i]);
   if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)into, ev, 0);
   if (e != hipSuccess) { l4d_set_error((int)e, "l4d_side_join"); return (int)e; }

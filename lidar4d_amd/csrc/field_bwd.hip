@@ -734,6 +734,18 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   fg.planes_cl = g->planes_cl;
   const int L3 = d.hd[0].n_levels + d.hd[1].n_levels + d.hd[2].n_levels;
   if (ST_DYN_MAX + L3 > ST_SIZE) { l4d_set_error(1, "l4d_density_encode_bwd: too many dynamic hash levels"); return 1; }
+  {  // everything that can be rejected is rejected BEFORE the first side stream is forked (an error return behind a
+    // fork left that stream un-joined -- under capture an unjoined fork, in eager mode later work not ordered behind it)
+    int lds_t = 0;
+    for (int s = 0; s < d.planes.n_scales; ++s)
+      for (int j = 0; j < 3; ++j) lds_t += TFRAMES * d.planes.res[s][j] * 8 * 4;
+    if (lds_t > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
+  }
+  // error returns behind a fork join what was forked, so that the launch stream is ordered behind the side streams' work again
+  auto fail = [&](int rc) -> int {
+    if (forked) { (void)l4d_side_join(stream_, 1); (void)l4d_side_join(stream_, 2); }
+    return rc;
+  };
   const WorkLayout w = work_layout(f, P);
   char* ws = (char*)workspace;
   float* stats = (float*)(ws + w.stats);
@@ -749,12 +761,12 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   {
     if (forked) {
       s_bins = (hipStream_t)l4d_side_fork(stream_, 1);
-      if (!s_bins) return 1;
+      if (!s_bins) return fail(1);
     }
     const int cols3[3] = {0, 1, 2};
     int rc = bs_scatter(d.hs, 3, 4, xt, P, 4, cols3, (const half_t*)dX, in_pad, 2 * d.planes.n_scales * 8, 1.0f, fg.hs_table,
                         param_scale, ws + w.bins, s_bins);
-    if (rc) return rc;
+    if (rc) return fail(rc);
   }
   // With the largest |dX| of the time-plane columns known beforehand (gd_absmax, from the sigma network's backward) the prep
   // kernel's work is done by the time-plane kernel itself (planes_dyn_lds_kernel<.., PREP = true>).
@@ -768,7 +780,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   }
   if (prep_side) {
     s_lds = (hipStream_t)l4d_side_fork(stream_, 2);
-    if (!s_lds) return 1;
+    if (!s_lds) return fail(1);
   }
   if (!fused_prep) {
     const int staged = (colD_ % 8 == 0 && L3 % 8 == 0) ? 1 : 0;  // 16-byte pieces
@@ -779,7 +791,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
 
   if (forked && !fused_prep && !prep_side) {  // after the prep kernel
     s_lds = (hipStream_t)l4d_side_fork(stream_, 2);
-    if (!s_lds) return 1;
+    if (!s_lds) return fail(1);
   }
   // chunking: one chunk per workgroup column; few enough chunks that the flush traffic stays small
   int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, 8192)));
@@ -806,7 +818,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     int lds = 0;
     for (int s = 0; s < d.planes.n_scales; ++s)
       for (int j = 0; j < 3; ++j) lds += TFRAMES * d.planes.res[s][j] * 8 * 4;
-    if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return 1; }
+    if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return fail(1); }  // (checked above)
     const PlaneRows pr = make_plane_rows(d, plane_rows);
     const PrepOut po{gvs, gdynT, xsoa, stats, segb};
     if (plane_rows) {
@@ -828,7 +840,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   }
   if (forked && fused_prep) {  // the static-plane / dynamic-hash adjoints need what the fused kernel wrote
     s_lds = (hipStream_t)l4d_side_fork(stream_, 2);
-    if (!s_lds) return 1;
+    if (!s_lds) return fail(1);
   }
   // static planes
   {
@@ -845,7 +857,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
         int rows = std::max(1, (PLANES_BAND_KB * 1024) / (W * 8 * 4));
         rows = std::min(rows, H);
         for (int r0 = 0; r0 < H; r0 += rows) {
-          if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many plane bands"); return 1; }
+          if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many plane bands"); return fail(1); }
           t.s[t.n] = s; t.j[t.n] = j; t.row0[t.n] = r0; t.nrows[t.n] = std::min(rows, H - r0);
           max_lds = std::max(max_lds, t.nrows[t.n] * W * 8 * 4);
           ++t.n;
@@ -869,7 +881,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       for (int l = 0; l < d.hd[p].n_levels; ++l) {
         const int size = (int)d.hd[p].size[l];
         for (int lo = 0; lo < size; lo += max_entries) {
-          if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many hash tasks"); return 1; }
+          if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many hash tasks"); return fail(1); }
           t.plane[t.n] = p; t.lvl[t.n] = l; t.lo[t.n] = lo; t.cnt[t.n] = std::min(max_entries, size - lo);
           t.hoff[t.n] = hoff_plane[p] + (int)d.hd[p].offset[l];
           ++t.n;

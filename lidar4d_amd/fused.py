@@ -46,7 +46,7 @@ def _field_desc(model):
     model._dyn_pairs, model._pairs_version = [], None
     if fd.n_slices >= 2:
         for p in range(3):
-            n_entries = he.hash_dynamic[p].hash_t[0].params.numel() // 4
+            n_entries = he.hash_dynamic[p].hash_t[0].params.numel() // he.hash_dynamic[p].hash_t[0].meta.n_features
             buf = torch.empty(fd.n_slices - 1, n_entries, 8, dtype=torch.float16, device=f16.device)
             model._dyn_pairs.append(buf)
             fd.hash_dynamic_pairs[p] = buf.data_ptr()
@@ -236,10 +236,13 @@ class RenderFn(torch.autograd.Function):
                 hook()
         # flow network + grid
         fn = model.flow_net
-        dxf = ops.mlp_bwd(xf, act_f, dflow16, _flow_w16(model), fn.n_hidden, _flow_wgrad(model), inv)
-        ops.hashgrid_t_bwd(fn.grid_enc.meta, xt, (0, 1, 2), 1, t_dev, dxf, [store.grad_view(fn.grid_enc.params)], inv)
+        try:
+            dxf = ops.mlp_bwd(xf, act_f, dflow16, _flow_w16(model), fn.n_hidden, _flow_wgrad(model), inv)
+            ops.hashgrid_t_bwd(fn.grid_enc.meta, xt, (0, 1, 2), 1, t_dev, dxf, [store.grad_view(fn.grid_enc.params)], inv)
+        finally:
+            if defer:  # also when a launch above raised: the side streams forked by density_encode_bwd must not stay un-joined
+                ops.streams_join()  # the launch stream waits for the side streams: from here on every gradient is final in stream order
         if defer:
-            ops.streams_join()  # the launch stream waits for the side streams: from here on every gradient is final in stream order
             del keep
             planes_done()
         pair = ctx.slice_pair

@@ -51,6 +51,14 @@ class LiDAR4D(LiDAR_Renderer):
                                        time_resolution=time_resolution, n_levels=n_levels_hash,
                                        n_features_per_level=n_features_per_level_hash,
                                        log2_hashmap_size=log2_hashmap_size)
+        # the fused render pipeline (fused.py) is built for the reference model's own field layout -- four features per level,
+        # blended with four time bases, the three 2-D x time stacks concatenated, static and dynamic part as a pair
+        # (lidar4d.py:51-57 constructs nothing else); HashGrid4D's other options run on the operator-level path only
+        he = self.hash_encoder
+        if (n_features_per_level_hash != 4 or he.reduction != "concat" or not he.decompose
+                or any(hd.num_basis != 4 for hd in he.hash_dynamic)):
+            raise ValueError("LiDAR4D: the fused pipeline needs n_features_per_level_hash = 4 (num_basis 4), reduction = 'concat' and "
+                             "decompose = True for its hash encoder; other HashGrid4D options are available at operator level only")
         self.view_encoder = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "Frequency", "degree": 12})
         self.flow_net = FlowField(input_dim=4, num_layers=num_layers_flow, hidden_dim=hidden_dim_flow, use_grid=True)
 

@@ -158,14 +158,18 @@ def test_gradient_error_vs_fp16_yardsticks(c3_models):
       gradients accumulated with one fp16-rounded add per corner -- at the largest loss scale its fp16
       parameter gradients survive (the HIP path keeps those in fp32 / integers and runs 64x higher).
 
-    The HIP path's error on every hash table must stay within 1.5x the two combined."""
+    The HIP path's error on every hash table and on every hex-plane must stay within 1.5x the two combined."""
     ref, hip = c3_models
     frame, n_rays, steps, key = 50, 64, 768, "c3n"
     fails = render_both(ref, hip, frame, n_rays, steps, key)
     assert not fails, fails
     named = lambda: dict(ref.named_parameters())
-    tables = [n for n, p in ref.named_parameters() if (n.startswith("hash_encoder.") or n.startswith("flow_net.grid_enc"))
+    # hash tables AND (round 4, VERDICT r3 weak 3) the 24 hex-planes: their gradients come through the same fp16 adjoints of the
+    # sigma network, so the same two yardsticks bound what can be expected of them
+    tables = [n for n, p in ref.named_parameters() if (n.startswith("hash_encoder.") or n.startswith("flow_net.grid_enc")
+                                                       or n.startswith("planes_encoder."))
               and p.grad is not None and float(p.grad.abs().max()) > 0]
+    assert sum(n.startswith("planes_encoder.") for n in tables) == 24
     hip_named = dict(hip.named_parameters())
     g32 = {n: named()[n].grad.detach().double().clone() for n in tables}
     ghip = {n: hip_named[n].grad.detach().double().cpu().clone() for n in tables}
