@@ -332,14 +332,15 @@ int l4d_lidar_ray_batch(const int64_t* rows, const int64_t* cols, int32_t n, con
 /* model/runner.py:179-213 with the default criteria: loss[0] = sum over rays of alpha_d |d - d_gt| m + alpha_r (r - clamp(m,
  * smooth, 1 - smooth))^2 + alpha_i ((i - i_gt) m)^2 with m = gt[:,0]; g_depth [n], g_image [n,2] = its gradients;
  * pts (or null) [2,n,3] = predicted / ground-truth points along the rays in metres (runner.py:215-218: rays_d * depth * m / scale). */
+int64_t l4d_glue_workspace(int32_t n); /* floats of scratch (`partial`) the two calls below need for n rays */
 int l4d_lidar_losses(const float* depth, const float* image, const float* gt, const float* rays_d, int32_t n, float alpha_d,
                      float alpha_r, float alpha_i, float smooth, float scale, float* loss, float* g_depth, float* g_image,
-                     float* pts, void* stream);
+                     float* pts, float* partial, void* stream);
 /* ray-chamfer term (runner.py:215-220) behind l4d_chamfer_fwd on pts: loss[0] += coef * sum(dist1 + dist2) and g_depth +=
  * its gradient wrt the rendered depth (coef = 0.5 / n / world for the reference's mean * 0.5). */
 int l4d_ray_chamfer_grad(const float* pts, const float* rays_d, const float* gt, const float* dist1, const float* dist2,
                          const int32_t* idx1, const int32_t* idx2, int32_t n, float coef, float scale, float* loss,
-                         float* g_depth, void* stream);
+                         float* g_depth, float* partial, void* stream);
 /* out_a[i] = a[i] * s[0] (na values), out_b[i] = b[i] * s[0] (nb values); s on the device */
 int l4d_scale_buffers(const float* a, float* out_a, int64_t na, const float* b, float* out_b, int64_t nb, const float* s,
                       void* stream);

@@ -100,8 +100,9 @@ SIGNATURES = {
     "l4d_chamfer_fwd": [P, P, I32, I32, I32, P, P, P, P, P, P],
     "l4d_chamfer_bwd": [P, P, I32, I32, I32, P, P, P, P, P, P, P],
     "l4d_lidar_ray_batch": [P, P, I32, P, F32, F32, I32, I32, P, P, P, P, P, P],
-    "l4d_lidar_losses": [P, P, P, P, I32, F32, F32, F32, F32, F32, P, P, P, P, P],
-    "l4d_ray_chamfer_grad": [P, P, P, P, P, P, P, I32, F32, F32, P, P, P],
+    "l4d_glue_workspace": [I32],
+    "l4d_lidar_losses": [P, P, P, P, I32, F32, F32, F32, F32, F32, P, P, P, P, P, P],
+    "l4d_ray_chamfer_grad": [P, P, P, P, P, P, P, I32, F32, F32, P, P, P, P],
     "l4d_scale_buffers": [P, P, I64, P, P, I64, P, P],
     "l4d_flow_xt": [P, I32, P, F32, P, P],
     "l4d_flow_warp": [P, P, I32, I32, PI32, P, P, P],  # (col0 / step: small HOST arrays)

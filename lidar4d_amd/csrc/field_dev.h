@@ -58,11 +58,29 @@ __device__ __forceinline__ PairSel pair_sel(const SlicePair& sp, int n_slices) {
 struct PairCorners {
   uint4 e[4];  // corner k: {slice q: 4 halfs, slice q + 1: 4 halfs}
 };
+// (float)half * w + 0 as ONE v_fma_mix_f32 with the half taken from the low / high 16 bits of a packed word.  For the first
+// corner of an interpolation (accumulator still zero) the compiler turns fmix(h, w, 0) into a conversion plus a multiply -- two
+// instructions for a quarter of the multiply-adds of kernels that are bound by exactly those (dynhash_fwd_lds_kernel: VALU-bound).
+// Same value as the product (a zero result may differ in sign, which no consumer sees).
+template <bool HI>
+__device__ __forceinline__ float fmix0(uint32_t word, float w) {
+  float r;
+  if (HI) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(word), "v"(w));
+  else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(word), "v"(w));
+  return r;
+}
 // interpolation + time blend + interpT of one level from fetched corners (same operation order as hash_t_level)
 __device__ __forceinline__ float pair_eval(const PairCorners& pc, const Cell<2>& c, const TimeCoef& tc, bool hi) {
-  float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+  float a[4], b[4];
+  {
+    uint32_t gv[2];
+    const float w = corner<2>(c, 0, gv);
+    const uint4& e = pc.e[0];
+    a[0] = fmix0<false>(e.x, w); a[1] = fmix0<true>(e.x, w); a[2] = fmix0<false>(e.y, w); a[3] = fmix0<true>(e.y, w);
+    b[0] = fmix0<false>(e.z, w); b[1] = fmix0<true>(e.z, w); b[2] = fmix0<false>(e.w, w); b[3] = fmix0<true>(e.w, w);
+  }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 1; k < 4; ++k) {
     uint32_t gv[2];
     const float w = corner<2>(c, k, gv);
     const half_t* h = reinterpret_cast<const half_t*>(&pc.e[k]);

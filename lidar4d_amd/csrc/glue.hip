@@ -73,22 +73,49 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red /* [1024] */
   return r;
 }
 
-// runner.py:179-213 with the default criteria (L1 depth, MSE ray-drop on the label-smoothed mask, MSE intensity), all masked by
-// the ground-truth ray-drop and summed; pts: [2][n][3] predicted / ground-truth points along the rays in metres (runner.py:215-218)
-__global__ void __launch_bounds__(1024) lidar_losses_kernel(const float* __restrict__ depth, const float* __restrict__ image,
-                                                           const float* __restrict__ gt, const float* __restrict__ rays_d, int n,
-                                                           float alpha_d, float alpha_r, float alpha_i, float smooth, float scale,
-                                                           float* __restrict__ loss, float* __restrict__ g_depth,
-                                                           float* __restrict__ g_image, float* __restrict__ pts) {
-  __shared__ float red[1024];
+// fixed-order sum of one value per thread over a 256-thread workgroup
+__device__ __forceinline__ float block_sum_256(float v, float* red /* [256] */) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// loss[0] = (accumulate ? loss[0] : 0) + coef * (partial[0] + partial[1] + ...), summed in index order by one workgroup: the
+// per-block partial sums of the kernels below become ONE number that is the same every run (no floating-point atomics)
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ partial, int n, float coef, int accumulate,
+                                                           float* __restrict__ loss) {
+  __shared__ float red[256];
   float acc = 0.0f;
-  for (int k = threadIdx.x; k < n; k += 1024) {
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  const float total = block_sum_256(acc, red);
+  if (threadIdx.x == 0) loss[0] = (accumulate ? loss[0] : 0.0f) + coef * total;
+}
+
+// runner.py:179-213 with the default criteria (L1 depth, MSE ray-drop on the label-smoothed mask, MSE intensity), all masked by
+// the ground-truth ray-drop and summed (partial[block] = the block's share); pts: [2][n][3] predicted / ground-truth points along
+// the rays in metres (runner.py:215-218)
+__global__ void __launch_bounds__(256) lidar_losses_kernel(const float* __restrict__ depth, const float* __restrict__ image,
+                                                          const float* __restrict__ gt, const float* __restrict__ rays_d, int n,
+                                                          float alpha_d, float alpha_r, float alpha_i, float smooth, float scale,
+                                                          float* __restrict__ partial, float* __restrict__ g_depth,
+                                                          float* __restrict__ g_image, float* __restrict__ pts) {
+  __shared__ float red[256];
+  float acc = 0.0f;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) {
     const float m = gt[k * 3 + 0];
     const float gt_i = gt[k * 3 + 1] * m, gt_d = gt[k * 3 + 2] * m;
     const float p_r = image[k * 2 + 0], p_i = image[k * 2 + 1] * m, p_d = depth[k] * m;
     const float gs = fminf(fmaxf(m, smooth), 1.0f - smooth);
     const float ed = p_d - gt_d, er = p_r - gs, ei = p_i - gt_i;
-    acc += alpha_d * fabsf(ed) + alpha_r * (er * er) + alpha_i * (ei * ei);
+    acc = alpha_d * fabsf(ed) + alpha_r * (er * er) + alpha_i * (ei * ei);
     g_depth[k] = alpha_d * (ed > 0.0f ? 1.0f : ed < 0.0f ? -1.0f : 0.0f) * m;
     g_image[k * 2 + 0] = alpha_r * (2.0f * er);
     g_image[k * 2 + 1] = alpha_i * (2.0f * ei) * m;
@@ -101,34 +128,41 @@ __global__ void __launch_bounds__(1024) lidar_losses_kernel(const float* __restr
       }
     }
   }
-  const float total = block_sum_1024(acc, red);
-  if (threadIdx.x == 0) loss[0] = total;
+  const float total = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
+
+// partial: scratch of l4d_glue_workspace(n) floats
+extern "C" int64_t l4d_glue_workspace(int32_t n) { return (int64_t)(n > 0 ? (n + 255) / 256 : 1); }
 
 extern "C" int l4d_lidar_losses(const float* depth, const float* image, const float* gt, const float* rays_d, int32_t n, float alpha_d,
                                 float alpha_r, float alpha_i, float smooth, float scale, float* loss, float* g_depth, float* g_image,
-                                float* pts, void* stream) {
+                                float* pts, float* partial, void* stream) {
   if (n < 0) { l4d_set_error(1, "l4d_lidar_losses: negative ray count"); return 1; }
-  L4D_LAUNCH(lidar_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, depth, image, gt, rays_d, n, alpha_d, alpha_r, alpha_i,
-             smooth, scale, loss, g_depth, g_image, pts);
+  const int blocks = (n + 255) / 256;
+  if (blocks > 0)
+    L4D_LAUNCH(lidar_losses_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, depth, image, gt, rays_d, n, alpha_d, alpha_r, alpha_i,
+               smooth, scale, partial, g_depth, g_image, pts);
+  L4D_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, blocks, 1.0f, 0, loss);
   L4D_LAUNCH_CHECK("l4d_lidar_losses");
   return 0;
 }
 
 // loss[0] += coef * sum(dist1 + dist2); g_depth += coef * d(sum)/d(depth) through p_k = rays_d_k * (depth_k * m_k) / scale:
-//   dist1_k = |p_k - q_idx1[k]|^2  -> 2 (p_k - q_a) . rays_d_k * m_k / scale          (own term, plain add)
-//   dist2_j = |q_j - p_idx2[j]|^2  -> 2 (p_b - q_j) . rays_d_b * m_b / scale into b   (scattered: atomics, n of them)
-__global__ void __launch_bounds__(1024) ray_chamfer_grad_kernel(const float* __restrict__ pts, const float* __restrict__ rays_d,
-                                                               const float* __restrict__ gt, const float* __restrict__ dist1,
-                                                               const float* __restrict__ dist2, const int32_t* __restrict__ idx1,
-                                                               const int32_t* __restrict__ idx2, int n, float coef, float scale,
-                                                               float* __restrict__ loss, float* __restrict__ g_depth) {
-  __shared__ float red[1024];
+//   dist1_k = |p_k - q_idx1[k]|^2  -> 2 (p_k - q_a) . rays_d_k * m_k / scale
+//   dist2_j = |q_j - p_idx2[j]|^2  -> 2 (p_b - q_j) . rays_d_b * m_b / scale into b   (scattered: atomics, 2 n of them)
+__global__ void __launch_bounds__(256) ray_chamfer_grad_kernel(const float* __restrict__ pts, const float* __restrict__ rays_d,
+                                                              const float* __restrict__ gt, const float* __restrict__ dist1,
+                                                              const float* __restrict__ dist2, const int32_t* __restrict__ idx1,
+                                                              const int32_t* __restrict__ idx2, int n, float coef, float scale,
+                                                              float* __restrict__ partial, float* __restrict__ g_depth) {
+  __shared__ float red[256];
   const float* p = pts;
   const float* q = pts + (size_t)n * 3;
   float acc = 0.0f;
-  for (int k = threadIdx.x; k < n; k += 1024) {
-    acc += dist1[k] + dist2[k];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) {
+    acc = dist1[k] + dist2[k];
     const int a = idx1[k];
     float dot = 0.0f;
 #pragma unroll
@@ -140,16 +174,18 @@ __global__ void __launch_bounds__(1024) ray_chamfer_grad_kernel(const float* __r
     for (int c = 0; c < 3; ++c) dot += (p[b * 3 + c] - q[k * 3 + c]) * rays_d[b * 3 + c];
     atomicAdd(g_depth + b, coef * 2.0f * dot * gt[b * 3] / scale);
   }
-  const float total = block_sum_1024(acc, red);
-  if (threadIdx.x == 0) loss[0] += coef * total;
+  const float total = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
 extern "C" int l4d_ray_chamfer_grad(const float* pts, const float* rays_d, const float* gt, const float* dist1, const float* dist2,
                                     const int32_t* idx1, const int32_t* idx2, int32_t n, float coef, float scale, float* loss,
-                                    float* g_depth, void* stream) {
+                                    float* g_depth, float* partial, void* stream) {
   if (n <= 0) return 0;
-  L4D_LAUNCH(ray_chamfer_grad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pts, rays_d, gt, dist1, dist2, idx1, idx2, n, coef,
-             scale, loss, g_depth);
+  const int blocks = (n + 255) / 256;
+  L4D_LAUNCH(ray_chamfer_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pts, rays_d, gt, dist1, dist2, idx1, idx2, n, coef,
+             scale, partial, g_depth);
+  L4D_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, blocks, coef, 1, loss);
   L4D_LAUNCH_CHECK("l4d_ray_chamfer_grad");
   return 0;
 }

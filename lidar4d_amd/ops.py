@@ -561,8 +561,9 @@ def lidar_losses(depth, image, gt, rays_d, alpha_d, alpha_r, alpha_i, smooth, sc
     g_depth = torch.empty(n, dtype=torch.float32, device=dev)
     g_image = torch.empty(n, 2, dtype=torch.float32, device=dev)
     pts = torch.empty(2, n, 3, dtype=torch.float32, device=dev) if want_points else None
+    partial = torch.empty((n + 255) // 256 + 1, dtype=torch.float32, device=dev)
     call("l4d_lidar_losses", _p(depth), _p(image), _p(gt), _p(rays_d), n, float(alpha_d), float(alpha_r), float(alpha_i), float(smooth),
-         float(scale), _p(loss), _p(g_depth), _p(g_image), _p(pts), _stream())
+         float(scale), _p(loss), _p(g_depth), _p(g_image), _p(pts), _p(partial), _stream())
     return loss, g_depth, g_image, pts
 
 
@@ -576,8 +577,9 @@ def ray_chamfer_accumulate(pts, rays_d, gt, coef, scale, loss, g_depth):
     idx = torch.empty(2, n, dtype=torch.int32, device=dev)
     ws = torch.empty(_lib.lib().l4d_chamfer_workspace(1, n, n), dtype=torch.uint8, device=dev)
     call("l4d_chamfer_fwd", _p(pts[0]), _p(pts[1]), 1, n, n, _p(dist[0]), _p(dist[1]), _p(idx[0]), _p(idx[1]), _p(ws), _stream())
+    partial = torch.empty((n + 255) // 256 + 1, dtype=torch.float32, device=dev)
     call("l4d_ray_chamfer_grad", _p(pts), _p(rays_d), _p(gt), _p(dist[0]), _p(dist[1]), _p(idx[0]), _p(idx[1]), n, float(coef), float(scale),
-         _p(loss), _p(g_depth), _stream())
+         _p(loss), _p(g_depth), _p(partial), _stream())
 
 
 def scale_buffers(a, b, s):

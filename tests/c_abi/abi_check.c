@@ -22,6 +22,7 @@ int main(void) {
       (fn_t)&l4d_chamfer_bwd,
       (fn_t)&l4d_lidar_ray_batch,
       (fn_t)&l4d_lidar_losses,
+      (fn_t)&l4d_glue_workspace,
       (fn_t)&l4d_ray_chamfer_grad,
       (fn_t)&l4d_scale_buffers,
       (fn_t)&l4d_flow_xt,

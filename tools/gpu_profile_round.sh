@@ -34,6 +34,7 @@ pmc wr TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_DRAM_sum
 pmc l2 TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
 pmc mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA
 pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+pmc inst SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_WAVES
 python tools/pmc_summary.py $O/pmc_rd.json $O/pmc_wr.json $O/pmc_l2.json $O/pmc_mfma.json $O $TAG lidar4d_amd/liblidar4d_hip.so
 cp $O/hbm_traffic_$TAG.json $O/${TAG}_mfma_pmc.json profiles/   # the bench lines below attach them (same build: sha256 checked)
 for C in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum"; do
