@@ -508,8 +508,9 @@ __global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int
     for (int j = 0; j < NV; ++j) {
       const float v = h2f(hv[j]);
       if (v != 0.0f) {
-        atomicAdd(a0 + j * seg, (unsigned long long)(long long)fx_round(v * s0));
-        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)fx_round(v * s1));
+        const float2_t p = float2_t{s0, s1} * v;  // one v_pk_mul_f32
+        atomicAdd(a0 + j * seg, (unsigned long long)(long long)fx_round(p[0]));
+        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)fx_round(p[1]));
       }
     }
   };

@@ -206,6 +206,9 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 #ifndef PDYN_FMA
 #define PDYN_FMA 1  // measured: 4.12 -> 3.97 ms (gpurun_out/r4a)
 #endif
+#ifndef PDYN_PK
+#define PDYN_PK 1
+#endif
 #ifndef PSTAT_MERGE
 #define PSTAT_MERGE 16
 #endif
@@ -368,7 +371,16 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
         Tap taps[3];
         float v[3][C];
         float dv[3][C];  // ROWS: row[x1] - row[x0] per channel (d value / d ix)
+        (void)dv;
         int cis[3];
+#if PDYN_PK
+        // Packed fp32 (v_pk_mul / v_pk_fma / v_pk_add: two channels per instruction at the issue cost of one).  A wave64 VALU
+        // instruction occupies its SIMD for ~4 cycles whatever it computes (SQ_INSTS_VALU x 4.35 cycles = this kernel's
+        // SQ_ACTIVE_INST_VALU), and two thirds of this kernel's instructions are per-channel multiplies and adds.
+        float2_t v2[3][C / 2], dv2[3][C / 2], cg2[C / 2];
+#pragma unroll
+        for (int k2 = 0; k2 < C / 2; ++k2) cg2[k2] = float2_t{gd[2 * k2], gd[2 * k2 + 1]} * coef;
+#endif
         if (ROWS) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
@@ -380,28 +392,60 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
 #pragma unroll
             for (int q = 0; q < C / 4; ++q) {
               const float4_t a = p0[q], c = p1[q];
+#if PDYN_PK
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const float2_t a2 = {a[2 * h], a[2 * h + 1]}, c2 = {c[2 * h], c[2 * h + 1]};
+                v2[j][q * 2 + h] = a2 * taps[j].wx0 + c2 * taps[j].wx1;
+                dv2[j][q * 2 + h] = c2 - a2;
+              }
+#else
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
                 v[j][q * 4 + k] = a[k] * taps[j].wx0 + c[k] * taps[j].wx1;
                 dv[j][q * 4 + k] = c[k] - a[k];
               }
+#endif
             }
           }
         } else {
           group_taps<C>(fd, s, xe, true, taps, v, cis);
+#if PDYN_PK
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k2 = 0; k2 < C / 2; ++k2) v2[j][k2] = float2_t{v[j][2 * k2], v[j][2 * k2 + 1]};
+#endif
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const Tap& t = taps[j];
           const int W = fd.planes.res[s][j];
           float gv[C];
+#if PDYN_PK
+          float2_t gv2[C / 2];
+#pragma unroll
+          for (int k2 = 0; k2 < C / 2; ++k2) {
+            gv2[k2] = cg2[k2] * v2[(j + 1) % 3][k2] * v2[(j + 2) % 3][k2];
+            gv[2 * k2] = gv2[k2][0];
+            gv[2 * k2 + 1] = gv2[k2][1];
+          }
+#else
 #pragma unroll
           for (int k = 0; k < C; ++k) gv[k] = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
+#endif
           if (e > 0) {  // coordinate adjoint of the warped lookups (time plane j pairs spatial axis j with t)
             float gix = 0.0f, giy = 0.0f;
             if (ROWS) {
+#if PDYN_PK
+              float2_t g2 = dv2[j][0] * gv2[0];
+#pragma unroll
+              for (int k2 = 1; k2 < C / 2; ++k2) g2 = dv2[j][k2] * gv2[k2] + g2;
+              gix = g2[0] + g2[1];
+#else
 #pragma unroll
               for (int k = 0; k < C; ++k) gix += dv[j][k] * gv[k];
+#endif
             } else {
               TapVals<C> tv;
               float dummy[C];
@@ -417,8 +461,17 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
             const int xq = qx == 0 ? t.x0 : t.x1;
             const float wxf = (qx == 0 ? t.wx0 : t.wx1) * fxs;
             float vals[C];
+#if PDYN_PK
+#pragma unroll
+            for (int k2 = 0; k2 < C / 2; ++k2) {
+              const float2_t vv = gv2[k2] * wxf;
+              vals[2 * k2] = vv[0];
+              vals[2 * k2 + 1] = vv[1];
+            }
+#else
 #pragma unroll
             for (int k = 0; k < C; ++k) vals[k] = gv[k] * wxf;
+#endif
             row_scan<C, PDYN_MERGE>(runs, vals);
             if (!runs.tail) continue;  // (inactive lanes carry zeros and a valid clamped key: harmless in any run)
             // (For a given k the lanes of an atomic -- run tails at different texels -- share the four banks = k (mod 8).  Rotating
@@ -870,28 +923,42 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   }
   // dynamic hash
   {
-    HashTasks t;
-    t.n = 0;
     int hoff = 0, hoff_plane[3];
 #ifndef DYNHASH_LDS_KB
 #define DYNHASH_LDS_KB 64  // two workgroups per CU: measured 2.10 -> 1.85 ms against 128 KB parts
 #endif
-    const int max_entries = (DYNHASH_LDS_KB * 1024) / 8;
     for (int p = 0; p < 3; ++p) {
       hoff_plane[p] = hoff;
-      for (int l = 0; l < d.hd[p].n_levels; ++l) {
-        const int size = (int)d.hd[p].size[l];
-        for (int lo = 0; lo < size; lo += max_entries) {
-          if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many hash tasks"); return fail(1); }
-          t.plane[t.n] = p; t.lvl[t.n] = l; t.lo[t.n] = lo; t.cnt[t.n] = std::min(max_entries, size - lo);
-          t.hoff[t.n] = hoff_plane[p] + (int)d.hd[p].offset[l];
-          ++t.n;
-        }
-      }
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
-    (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DYNHASH_LDS_KB * 1024);
-    L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks_dh, t.n), dim3(1024), DYNHASH_LDS_KB * 1024, s_lds, d, t, xsoa, P, chunk_dh, gdynT, stats, Hbuf);
+    // Levels larger than one 64 KB window (the xy stack: 2^15 entries = 256 KB of int64 accumulators) are walked in table parts,
+    // and every part streams all samples again.  L4D_DYNHASH_BIG_KB = 128 gives those levels a launch of their own with 128 KB
+    // parts (one workgroup per CU, half the passes); the levels that fit 64 KB keep two workgroups per CU.
+    static int big_kb = -1;
+    if (big_kb < 0) {
+      const char* e = getenv("L4D_DYNHASH_BIG_KB");
+      big_kb = (e && (atoi(e) == 128 || atoi(e) == 64)) ? atoi(e) : DYNHASH_LDS_KB;
+    }
+    for (int group = 0; group < 2; ++group) {  // 0: levels that fit DYNHASH_LDS_KB; 1: larger ones
+      const int lds_kb = group == 0 ? DYNHASH_LDS_KB : big_kb;
+      const int max_entries = (lds_kb * 1024) / 8, fit = (DYNHASH_LDS_KB * 1024) / 8;
+      HashTasks t;
+      t.n = 0;
+      for (int p = 0; p < 3; ++p)
+        for (int l = 0; l < d.hd[p].n_levels; ++l) {
+          const int size = (int)d.hd[p].size[l];
+          if ((size <= fit) != (group == 0)) continue;
+          for (int lo = 0; lo < size; lo += max_entries) {
+            if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many hash tasks"); return fail(1); }
+            t.plane[t.n] = p; t.lvl[t.n] = l; t.lo[t.n] = lo; t.cnt[t.n] = std::min(max_entries, size - lo);
+            t.hoff[t.n] = hoff_plane[p] + (int)d.hd[p].offset[l];
+            ++t.n;
+          }
+        }
+      if (t.n == 0) continue;
+      (void)hipFuncSetAttribute((const void*)dynhash_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      L4D_LAUNCH(dynhash_lds_kernel, dim3(n_chunks_dh, t.n), dim3(1024), lds_kb * 1024, s_lds, d, t, xsoa, P, chunk_dh, gdynT, stats, Hbuf);
+    }
     for (int p = 0; p < 3; ++p) {
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);
