@@ -207,8 +207,8 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 #define PDYN_FMA 1  // measured: 4.12 -> 3.97 ms (gpurun_out/r4a)
 #endif
 #ifndef PDYN_PK
-#define PDYN_PK 1
-#endif
+#define PDYN_PK 0  // per-channel arithmetic as packed fp32 pairs: 19 % fewer instructions in the scale loop, measured 3.91 -> 4.04 ms
+#endif             // (gpurun_out/r4e, r4f): v_pk_* fp32 issues at half rate here and brings hazard s_nops; kept as a knob
 #ifndef PSTAT_MERGE
 #define PSTAT_MERGE 16
 #endif
@@ -932,12 +932,12 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);
     }
     // Levels larger than one 64 KB window (the xy stack: 2^15 entries = 256 KB of int64 accumulators) are walked in table parts,
-    // and every part streams all samples again.  L4D_DYNHASH_BIG_KB = 128 gives those levels a launch of their own with 128 KB
-    // parts (one workgroup per CU, half the passes); the levels that fit 64 KB keep two workgroups per CU.
+    // and every part streams all samples again.  Those levels get a launch of their own with 128 KB parts (one workgroup per CU,
+    // half the passes; L4D_DYNHASH_BIG_KB = 64: the old form); the levels that fit 64 KB keep two workgroups per CU.
     static int big_kb = -1;
     if (big_kb < 0) {
       const char* e = getenv("L4D_DYNHASH_BIG_KB");
-      big_kb = (e && (atoi(e) == 128 || atoi(e) == 64)) ? atoi(e) : DYNHASH_LDS_KB;
+      big_kb = (e && (atoi(e) == 128 || atoi(e) == 64)) ? atoi(e) : 128;  // measured 1.51 -> 1.46 ms (gpurun_out/r4f)
     }
     for (int group = 0; group < 2; ++group) {  // 0: levels that fit DYNHASH_LDS_KB; 1: larger ones
       const int lds_kb = group == 0 ? DYNHASH_LDS_KB : big_kb;
