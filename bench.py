@@ -152,12 +152,15 @@ def kernel_models(model, P, M):
     m["bin_pass2_kernel<3, 2>"] = dict(bound="hbm", bytes=Lf * rec2 * P, note="flow grid records")
     for k in ("bin_pass2_kernel<3, 4>", "bin_pass2_kernel<3, 2>"):  # launch-site names of the compile-time / run-time bin size variants
         m[k[:-1] + ", DEF>"] = m[k[:-1] + ", 0>"] = m[k]
+        m[k.replace("pass2_kernel", "pass2_flat_kernel")[:-1] + ", DEF>"] = dict(m[k], note=m[k]["note"] + " (flattened walk: 64 tiles' runs per wavefront)")
     m["field_bwd_prep_kernel"] = dict(bound="hbm", bytes=(16 + X + 3 * nS * 16 + 2 * n_dyn) * P, note="dX row read, plane factors + transposed dyn gradient written")
     m["planes_dyn_lds_kernel<true, false>"] = m["planes_dyn_lds_kernel<false, false>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
     m["planes_dyn_lds_kernel<true, true>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32 + 3 * nS * 16 + 2 * n_dyn + 12) * P,
                                                   note="the same + the preparation pass' outputs (static-plane factors, transposed dyn gradient, SoA coordinates) from the one read of the dX rows")
     m["planes_static_lds_kernel"] = dict(bound="hbm", bytes=(3 * nS * 16 + 3 * nS * 8) * P, note="plane-major factors read once per (scale, plane)")
-    m["dynhash_lds_kernel"] = dict(bound="hbm", bytes=(2 * n_dyn + n_dyn * 8) * P, note="transposed gradient + 2 coordinates per (plane, level) pass")
+    m["dynhash_lds_kernel"] = dict(bound="hbm", bytes=(2 * n_dyn + n_dyn * 8) * P, per_step=True,
+                                   note="transposed gradient + 2 coordinates per (plane, level) pass; two launches per step (levels that fit a 64 KB window / larger ones), modelled together")
+    m["sigma_bwd_rows_kernel"] = dict(bound="hbm", bytes=(4 + 4 + 32) * P, note="sigma, d_sigma in; whole dh rows out")
     m["composite_fwd_kernel"] = dict(bound="hbm", bytes=(4 + 4 + 4 + 4) * P, note="sigma, z in; weights, index out")
     m["composite_bwd_kernel"] = dict(bound="hbm", bytes=(4 * 3 + 8 + 4 + 8) * P, note="")
     m["sample_rays_xt_kernel"] = dict(bound="hbm", bytes=(4 + 4 + 16) * P, note="noise in; z, xt out")
@@ -656,6 +659,8 @@ def _run(args):
                 # (duration within a factor two of the longest) are averaged
                 big = [t for t in times if t >= 0.5 * max(times)]
                 avg_ms = sum(big) / len(big)
+                if mod.get("per_step"):  # a stage split over several launches of one kernel: modelled as one unit of work per step
+                    big, avg_ms = [per_step[name]] * args.profile_steps, per_step[name]
                 ach = mod["bytes"] / (avg_ms * 1e-3) / 1e9
                 row.update(bound=mod["bound"], bytes_per_launch=mod["bytes"], modelled_launches_per_step=len(big) / args.profile_steps,
                            modelled_launch_ms=round(avg_ms, 4), achieved=round(ach, 1), peak=peaks[mod["bound"]], unit="GB/s",

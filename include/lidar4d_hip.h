@@ -233,7 +233,8 @@ int l4d_attr_mlp_bwd(const void* x_rows, const int32_t* count, int64_t cap, int3
  * With d_attr given (dy / dx_tail then unused, may be null) the streaming steps either side of the network run inside the
  * kernel (lidar4d.py:210-219 backwards): dy[j][0] = d_attr[idx[j]][channel] * s (1 - s) * loss_scale with
  * s = attr_compact[j][channel] (replaces l4d_attr_scatter_bwd), and the geo-feature gradient goes straight to
- * dh[idx[j]][1 .. 15] (fp16 [samples, 16], pre-zeroed; stored when dh_accumulate = 0, added to what the other network of the
+ * dh[idx[j]][1 .. 15] (fp16 [samples, 16], pre-zeroed; dh_accumulate bit 0: stored (0) / added (1); bit 1: column 0 of dh is kept
+ * (it already holds the density activation's adjoint, l4d_sigma_bwd_rows) instead of zeroed; added to what the other network of the
  * pair stored when 1; replaces l4d_attr_gather_bwd). */
 int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* count, int64_t cap, int32_t T, const void* dir_enc,
                               int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* act,
@@ -244,6 +245,10 @@ int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* count, int64_t 
  * adjoint dh[:,0] = d_sigma * exp(clamp(h0,-15,15)) * loss_scale (fp16) */
 int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* stream);
 int l4d_sigma_bwd(const void* h, const float* d_sigma, int64_t P, float loss_scale, void* dh, void* stream);
+/* The same adjoint as whole rows: dh[p] = [d_sigma[p] * exp(clamp(h0, -15, 15)) * loss_scale, 0 x 15] with exp(h0) = sigma[p] taken
+ * from the forward's sigma (fp32 [P]); replaces the zero fill of dh + l4d_sigma_bwd when it runs BEFORE the attribute networks'
+ * backward, which then keeps column 0 (l4d_attr_mlp_bwd_gathered: dh_accumulate bit 1). */
+int l4d_sigma_bwd_rows(const float* sigma, const float* d_sigma, int64_t P, float loss_scale, void* dh, void* stream);
 
 /* ---- LiDAR4D.density, fused field evaluation : model/lidar4d.py:139-179 ---------------------------
  * One launch evaluates, per sample point, the hex-planes at (x,t) and at the two flow-warped neighbour

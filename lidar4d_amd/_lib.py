@@ -88,6 +88,7 @@ SIGNATURES = {
     "l4d_attr_mlp_bwd_gathered": [P, P, I64, I32, P, I32, P, I32, I32, I32, P, P, P, P, P, F32, P, P, I32, F32, P, I32, P],
     "l4d_sigma_from_h": [P, I64, P, P],
     "l4d_sigma_bwd": [P, P, I64, F32, P, P],
+    "l4d_sigma_bwd_rows": [P, P, I64, F32, P, P],
     "l4d_time_setup": [P, I32, P, P],
     "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P, P, P],
     "l4d_plane_rows_workspace": [FD],

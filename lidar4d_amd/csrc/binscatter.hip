@@ -52,6 +52,12 @@
 #ifndef BS_UNROLL
 #define BS_UNROLL 4
 #endif
+#ifndef BS_P1_UPPER
+#define BS_P1_UPPER 1       // pass 1: wave-uniform skip of the split slots' ranking / staging code (see there)
+#endif
+#ifndef BS_P1_MERGE_TEST
+#define BS_P1_MERGE_TEST 1  // pass 1: cheap first / last lane test in front of the run detection (see there)
+#endif
 #ifndef BS_MIN_WAVES
 #define BS_MIN_WAVES 4  // pass 1: wavefronts per SIMD the register allocation must leave room for (128 registers)
 #endif
@@ -168,9 +174,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
 
   Cell<D> c = locate<D>(xin, desc.scale[lvl]);
   uint32_t keys[NC];
-  // payloads as packed halfs from the moment they are final (two registers per slot instead of four floats across the two
-  // ranking barriers: the kernel sits at its 128-register limit and spilled before)
-  uint32_t pay[NC][NW - 1];
+  float vals[NC][NV];
   bool emit[NC];
   uint32_t pos[NC];
   const bool wave_any = __any(any);
@@ -184,6 +188,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // detection below (three DPP compares, a ballot, the run bookkeeping: ~45 instructions) is skipped when the first and the last
   // lane are more than 48 cells apart along some axis; a heuristic about WORK only, the pair path is always correct)
   bool try_merge = binned && wave_any;
+#if BS_P1_MERGE_TEST
   if (try_merge) {
     uint32_t span = 0u;
 #pragma unroll
@@ -193,6 +198,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     }
     try_merge = span <= 48u;
   }
+#endif
   if (try_merge) {
     bool same = true;  // same cell as the previous lane (the first lane of a row never is: old = ~cell, bound_ctrl off)
 #pragma unroll
@@ -224,7 +230,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       const uint32_t m = k0 ^ k1;
       const bool paired = (m & (m + 1u)) == 0u && m != 0u && (m >> shift) == 0u && __popc(m) <= (int)BS_CODE_SINGLE;
       keys[q] = k0 | ((uint32_t)(__popc(m) - 1) << 24);
-      float v[NV], vu[NV];
+      float* v = vals[q];
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[j] = wyz * gv[j];
       bool nz = false;
@@ -237,62 +243,62 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       keys[q + NC / 2] = k1 | (BS_CODE_SINGLE << 24);
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        vu[j] = v[j] * fx;
+        vals[q + NC / 2][j] = v[j] * fx;
         if (split) v[j] *= 1.0f - fx;
       }
       if (split) keys[q] = k0 | (BS_CODE_SINGLE << 24);
-      pack_payload<NV>(v, pay[q]);
-      pack_payload<NV>(vu, pay[q + NC / 2]);
     }
   } else {
-  float* o_dense = out + (size_t)desc.offset[lvl] * NV;
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     uint32_t gg[D];
     const float w = corner<D>(c, k, gg);
     keys[k] = binned ? grid_index_fast<D>(gg, size - 1u) : grid_index<D>(gg, desc.res[lvl], size, hashed);
-    float vk[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) vk[j] = w * gv[j];
+    for (int j = 0; j < NV; ++j) vals[k][j] = w * gv[j];
     if (binned) {
       emit[k] = any;
       if (use_scan) {
-        row_scan<NV>(runs, vk);
+        row_scan<NV>(runs, vals[k]);
         emit[k] = runs.tail;
       }
     } else {
-      emit[k] = wave_any ? wave_run_reduce<NV>(keys[k], any, vk) : false;
+      emit[k] = wave_any ? wave_run_reduce<NV>(keys[k], any, vals[k]) : false;
     }
     if (emit[k]) {
       bool nz = false;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) nz |= vk[j] != 0.0f;
+      for (int j = 0; j < NV; ++j) nz |= vals[k][j] != 0.0f;
       emit[k] = nz;
     }
-    if (binned) {
-      keys[k] |= BS_CODE_SINGLE << 24;
-      pack_payload<NV>(vk, pay[k]);
-    } else if (emit[k]) {  // dense / tiny level: run-reduced atomics straight into the output
+    if (binned) keys[k] |= BS_CODE_SINGLE << 24;
+  }
+  }
+  if (!binned) {  // dense / tiny level: run-reduced atomics straight into the output (block-uniform branch)
+    float* o = out + (size_t)desc.offset[lvl] * NV;
 #pragma unroll
-      for (int j = 0; j < NV; ++j)
-        if (vk[j] != 0.0f) atomicAdd(o_dense + (size_t)keys[k] * NV + j, vk[j] * out_scale);
-    }
+    for (int k = 0; k < NC; ++k)
+      if (emit[k]) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+          if (vals[k][j] != 0.0f) atomicAdd(o + (size_t)keys[k] * NV + j, vals[k][j] * out_scale);
+      }
+    continue;  // block-uniform: next level
   }
-  }
-  if (!binned) continue;  // block-uniform: next level
   amax = wave_max(amax);
   if (lane == 0 && amax > 0.0f) atomic_max_nonneg(lvl_max + lvl, amax);
 
   // In pair mode the upper half of the slots only holds the second halves of pairs that straddle two bins (one pair in 2^shift):
-  // a wavefront without one skips their ranking and staging code altogether (wave-uniform branch; ~20 % of this kernel's
-  // instructions were exec-masked no-ops there, and the kernel is bound by instruction issue + barriers).
+  // a wavefront without one skips their ranking and staging code altogether (wave-uniform branch instead of exec-masked no-ops).
   bool upper = true;
+#if BS_P1_UPPER
   if (pairs) {
     bool any_split = false;
 #pragma unroll
     for (int q = 0; q < NC / 2; ++q) any_split |= emit[q + NC / 2];
     upper = __any(any_split);
   }
+#endif
   // rank inside the workgroup
 #pragma unroll
   for (int k = 0; k < NC / 2; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
@@ -345,8 +351,10 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       const uint32_t r = boff[b] + pos[k];
       const uint32_t code = keys[k] >> 24;
       stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));
+      uint32_t pay[NW - 1];
+      pack_payload<NV>(vals[k], pay);
 #pragma unroll
-      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = pay[k][q];
+      for (int q = 0; q < NW - 1; ++q) stage[r * NW + 1 + q] = pay[q];
     }
   };
 #pragma unroll

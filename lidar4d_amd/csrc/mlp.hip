@@ -320,8 +320,8 @@ struct AttrBwdEpi {
   const float* d_attr;   // [samples, 2]
   const float* attr_c;   // [rows, 2]
   half_t* dh;            // [samples, 16]
-  int ch, accumulate;
-  float loss_scale;
+  int ch, accumulate;    // accumulate: bit 0 = add to what dh holds (else store), bit 1 = dh column 0 already carries the density
+  float loss_scale;      // activation's adjoint (l4d_sigma_bwd_rows ran first) and is kept instead of being zeroed
 };
 // DxStat: *out = max(*out, max |dx[:, 16 lo_tile : 16 hi_tile]|) over the rows of the launch, as stored (fp16-rounded; +inf for a
 // non-finite value): what the consumer of those columns needs to scale its fixed-point accumulators (field_bwd.hip).
@@ -444,7 +444,9 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
         t.dy[a].x = __float_as_uint(aepi.d_attr[ps * 2 + aepi.ch]);
         t.dy[a].y = __float_as_uint(aepi.attr_c[rc * 2 + aepi.ch]);
         // of the 4-column pieces 16 mt + 4 g of dX exactly one per lane falls into columns n_enc .. n_enc + 15
-        if (aepi.accumulate) t.dh_old[a] = *reinterpret_cast<const uint2*>(aepi.dh + ps * 16 + ((4 * g - src.n_enc) & 15));
+        // (keep-column-0 mode of a storing launch: only the lanes whose piece starts at column 0 need what dh holds)
+        if ((aepi.accumulate & 1) || ((aepi.accumulate & 2) && ((4 * g - src.n_enc) & 15) == 0))
+          t.dh_old[a] = *reinterpret_cast<const uint2*>(aepi.dh + ps * 16 + ((4 * g - src.n_enc) & 15));
       } else {
         t.dy[a] = *reinterpret_cast<const uint4*>(dy + rc * 16 + 8 * (g & 1));
       }
@@ -738,12 +740,12 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
                 if (c0 >= 0 && c0 < 16) {
                   const int64_t ps = src.idx ? (int64_t)ent_cur[a] : rows[a];
                   h4* d = reinterpret_cast<h4*>(aepi.dh + ps * 16 + c0);
-                  if (aepi.accumulate) {
-                    const h4 old = *reinterpret_cast<const h4*>(&cur.dh_old[a]);  // fetched with the tile (c0 == (4 g - n_enc) & 15)
+                  const h4 old = *reinterpret_cast<const h4*>(&cur.dh_old[a]);  // fetched with the tile (c0 == (4 g - n_enc) & 15)
+                  if (aepi.accumulate & 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ov[r] = f2h_grad(h2f(old[r]) + h2f(ov[r]));
                   }
-                  if (c0 == 0) ov[0] = (half_t)0.0f;
+                  if (c0 == 0) ov[0] = (aepi.accumulate & 2) ? old[0] : (half_t)0.0f;
                   *d = ov;
                 }
               } else {

@@ -410,9 +410,33 @@ __global__ void __launch_bounds__(256) sigma_bwd_kernel(const half_t* __restrict
   dh[p * 16] = f2h_grad(g);
 }
 
+// dh[p] = [d_sigma[p] * exp(clamp(h0, -15, 15)) * loss_scale, 0 x 15] as WHOLE 32-byte rows, from sigma = exp(h0) itself (exp is
+// monotone: clamping h0 to [-15, 15] is clamping sigma to [exp(-15), exp(15)], with the same expf at both ends) -- the zero fill of
+// dh and sigma_bwd_kernel's strided 2-byte read / write of every row in one dense pass.  The attribute networks' backward then
+// adds its 15 geo-feature columns and keeps column 0 (l4d_attr_mlp_bwd_gathered, dh_accumulate bit 1).
+__global__ void __launch_bounds__(256) sigma_bwd_rows_kernel(const float* __restrict__ sigma, const float* __restrict__ d_sigma, int64_t P,
+                                                            float loss_scale, half_t* __restrict__ dh) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float e = fminf(fmaxf(sigma[p], expf(-15.0f)), expf(15.0f));
+  const half_t g = f2h_grad(d_sigma[p] * e * loss_scale);
+  uint4 lo = make_uint4((uint32_t)__builtin_bit_cast(unsigned short, g), 0u, 0u, 0u);
+  uint4* dst = reinterpret_cast<uint4*>(dh + p * 16);
+  dst[0] = lo;
+  dst[1] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
+extern "C" int l4d_sigma_bwd_rows(const float* sigma, const float* d_sigma, int64_t P, float loss_scale, void* dh, void* stream) {
+  if (P == 0) return 0;
+  L4D_LAUNCH(sigma_bwd_rows_kernel, dim3((unsigned)ceil_div64(P, 256)), dim3(256), 0, (hipStream_t)stream, sigma, d_sigma, P, loss_scale,
+             (half_t*)dh);
+  L4D_LAUNCH_CHECK("l4d_sigma_bwd_rows");
+  return 0;
+}
+
 extern "C" int l4d_sample_rays(const float* rays_o, const float* rays_d, const float* lin, const float* noise, int64_t N,
                                int32_t T, float near, float far, float bound, float* z_vals, float* xyz, void* stream) {
   if (N == 0) return 0;

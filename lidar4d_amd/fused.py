@@ -180,16 +180,22 @@ class RenderFn(torch.autograd.Function):
                                             model.active_sensor, c(d_depth), c(d_wsum), c(d_image), c(d_weights))
         # attribute networks
         an = model.intensity_net
-        dh = torch.zeros(P, 16, dtype=torch.float16, device=dev)
         n_enc = model.view_encoder.n_output_dims
+        sigma_done = False
         if ctx.gathered and XA is None:
             # rows assembled again; the sigmoid-scatter adjoint in front of each network and the sum + scatter of the two
-            # geo-feature gradients behind them run inside the kernels (first network stores into dh, second adds)
+            # geo-feature gradients behind them run inside the kernels (first network stores into dh, second adds).  dh starts as
+            # whole rows [density activation's adjoint, 0 x 15] (one dense pass instead of a zero fill + a strided column pass
+            # afterwards); the networks keep that column (accumulate bit 1)
+            dh = torch.empty(P, 16, dtype=torch.float16, device=dev)
+            ops.sigma_bwd_rows(sigma.view(-1), d_sigma.view(-1), ls, dh)
+            sigma_done = True
             for ch, (net, a_) in enumerate(((model.raydrop_net, actR), (model.intensity_net, actI))):
                 ops.attr_mlp_bwd_gathered(idx, count, P, T, denc, h, model.geo_feat_dim, an.in_pad, a_, None, store.half(net.params),
                                           an.n_hidden_layers, store.grad_view(net.params), inv, d_attr=d_attr, attr_compact=attr_c,
-                                          channel=ch, loss_scale=ls, dh16=dh, accumulate=ch == 1)
+                                          channel=ch, loss_scale=ls, dh16=dh, accumulate=(1 if ch == 1 else 0) | 2)
         else:
+            dh = torch.zeros(P, 16, dtype=torch.float16, device=dev)
             dyR = torch.empty(P, 16, dtype=torch.float16, device=dev)
             dyI = torch.empty(P, 16, dtype=torch.float16, device=dev)
             ops.attr_scatter_bwd(idx, count, P, d_attr, attr_c, ls, dyR, dyI)
@@ -205,7 +211,8 @@ class RenderFn(torch.autograd.Function):
                 dxaI = ops.mlp_bwd(XA, actI, dyI, store.half(model.intensity_net.params), an.n_hidden_layers,
                                    store.grad_view(model.intensity_net.params), inv, n_rows=count)
                 ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad, n_enc, model.geo_feat_dim, dh)
-        ops.sigma_bwd(h, d_sigma.view(-1), ls, dh)
+        if not sigma_done:
+            ops.sigma_bwd(h, d_sigma.view(-1), ls, dh)
         # sigma network
         # (the backward reports max |dX| of the time-plane columns as it stores them: the field adjoint's fixed-point scale)
         pe = model.planes_encoder

@@ -352,7 +352,7 @@ def attr_mlp_bwd_gathered(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, act
     dx = torch.empty(cap, in_pad - 64, dtype=torch.float16, device=h16.device) if d_attr is None else None
     call("l4d_attr_mlp_bwd_gathered", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad,
          n_hidden, _p(act), _p(dy16), _p(weights16), _p(dx), _p(grad_w), float(inv_loss_scale), _p(d_attr), _p(attr_compact),
-         int(channel), float(loss_scale), _p(dh16), int(bool(accumulate)), _stream())
+         int(channel), float(loss_scale), _p(dh16), int(accumulate), _stream())
     return dx
 
 
@@ -380,6 +380,12 @@ def sigma_from_h(h16):
 def sigma_bwd(h16, d_sigma, loss_scale, dh16):
     _chk(h16, torch.float16, "h"), _chk(d_sigma, torch.float32, "d_sigma"), _chk(dh16, torch.float16, "dh")
     call("l4d_sigma_bwd", _p(h16), _p(d_sigma), h16.shape[0], float(loss_scale), _p(dh16), _stream())
+
+
+def sigma_bwd_rows(sigma, d_sigma, loss_scale, dh16):
+    """dh16 [P,16] := [d_sigma * exp(clamp(h0)) * loss_scale, 0 x 15] in one dense pass (no zero fill, no strided column access)."""
+    _chk(sigma, torch.float32, "sigma"), _chk(d_sigma, torch.float32, "d_sigma"), _chk(dh16, torch.float16, "dh")
+    call("l4d_sigma_bwd_rows", _p(sigma), _p(d_sigma), sigma.numel(), float(loss_scale), _p(dh16), _stream())
 
 
 # ---- fused field -----------------------------------------------------------------------------------

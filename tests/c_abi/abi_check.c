@@ -74,6 +74,7 @@ int main(void) {
       (fn_t)&l4d_side_fork,
       (fn_t)&l4d_side_join,
       (fn_t)&l4d_sigma_bwd,
+      (fn_t)&l4d_sigma_bwd_rows,
       (fn_t)&l4d_sigma_from_h,
       (fn_t)&l4d_streams_config,
       (fn_t)&l4d_streams_join,
