@@ -53,10 +53,10 @@
 #define BS_UNROLL 4
 #endif
 #ifndef BS_P1_UPPER
-#define BS_P1_UPPER 1       // pass 1: wave-uniform skip of the split slots' ranking / staging code (see there)
+#define BS_P1_UPPER 0       // pass 1: wave-uniform skip of the split slots' ranking / staging code -- measured SLOWER (2.21 -> 2.39 ms, gpurun_out/r4h)
 #endif
 #ifndef BS_P1_MERGE_TEST
-#define BS_P1_MERGE_TEST 1  // pass 1: cheap first / last lane test in front of the run detection (see there)
+#define BS_P1_MERGE_TEST 0  // pass 1: cheap first / last lane test in front of the run detection -- measured neutral (2.21 -> 2.20 ms)
 #endif
 #ifndef BS_MIN_WAVES
 #define BS_MIN_WAVES 4  // pass 1: wavefronts per SIMD the register allocation must leave room for (128 registers)
