@@ -4,11 +4,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define L4D_INTERNAL extern "C" __attribute__((visibility("hidden")))  // (as in common.h: helpers the kernels' translation units call)
+
 #include "../../include/lidar4d_hip.h"
 
 static thread_local char g_err[512] = "";
 
-extern "C" void l4d_set_error(int code, const char* where) {
+L4D_INTERNAL void l4d_set_error(int code, const char* where) {
   const char* txt = code > 1 ? hipGetErrorString((hipError_t)code) : "invalid argument";
   snprintf(g_err, sizeof(g_err), "%s: %s (code %d)", where, txt, code);
 }
@@ -38,13 +40,13 @@ extern "C" int l4d_profile_enable(int on) {
 
 // L4D_TRACE=1 (debugging): every launch is announced on stderr and waited for, so that a faulting kernel is the last one named
 static int g_trace = -1;
-extern "C" void l4d_trace_sync(const char* kernel, void* stream) {
+L4D_INTERNAL void l4d_trace_sync(const char* kernel, void* stream) {
   hipError_t e = hipStreamSynchronize((hipStream_t)stream);
   if (e == hipSuccess) e = hipGetLastError();
   fprintf(stderr, "[l4d] done   %s: %s\n", kernel, e == hipSuccess ? "ok" : hipGetErrorString(e));
   fflush(stderr);
 }
-extern "C" int l4d_prof_begin(const char* kernel, void* stream) {
+L4D_INTERNAL int l4d_prof_begin(const char* kernel, void* stream) {
   if (g_trace < 0) {
     const char* e = getenv("L4D_TRACE");
     g_trace = (e && e[0] == '1') ? 1 : 0;
@@ -63,7 +65,7 @@ extern "C" int l4d_prof_begin(const char* kernel, void* stream) {
   return (int)g_prof.size() - 1;
 }
 
-extern "C" void l4d_prof_end(int idx, void* stream) { (void)hipEventRecord(g_prof[idx].stop, (hipStream_t)stream); }
+L4D_INTERNAL void l4d_prof_end(int idx, void* stream) { (void)hipEventRecord(g_prof[idx].stop, (hipStream_t)stream); }
 
 extern "C" int l4d_profile_count(void) { return (int)g_prof.size(); }
 

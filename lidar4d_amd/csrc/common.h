@@ -10,7 +10,9 @@
 
 #define L4D_WAVE 64
 
-extern "C" void l4d_set_error(int code, const char* where);
+// (library-internal helpers: not part of the C ABI, not exported from the shared object)
+#define L4D_INTERNAL extern "C" __attribute__((visibility("hidden")))
+L4D_INTERNAL void l4d_set_error(int code, const char* where);
 
 #define L4D_LAUNCH_CHECK(where)                         \
   do {                                                  \
@@ -28,9 +30,9 @@ extern "C" void l4d_set_error(int code, const char* where);
 extern "C" int l4d_streams_mask(void);
 extern "C" void* l4d_side_fork(void* from, int32_t i);
 extern "C" int l4d_side_join(void* into, int32_t i);
-extern "C" int l4d_prof_begin(const char* kernel, void* stream);
-extern "C" void l4d_prof_end(int idx, void* stream);
-extern "C" void l4d_trace_sync(const char* kernel, void* stream);
+L4D_INTERNAL int l4d_prof_begin(const char* kernel, void* stream);
+L4D_INTERNAL void l4d_prof_end(int idx, void* stream);
+L4D_INTERNAL void l4d_trace_sync(const char* kernel, void* stream);
 #define L4D_LAUNCH(kernel, grid, block, lds, stream, ...)                    \
   do {                                                                       \
     const int prof_idx__ = l4d_prof_begin(#kernel, (void*)(stream));         \

@@ -25,6 +25,14 @@ def test_library_exports_declared_abi():
     bound = set(_lib.SIGNATURES) | {"l4d_version", "l4d_last_error"}
     assert declared == bound, (declared - bound, bound - declared)
     assert _lib.lib().l4d_version() == _lib.ABI_VERSION
+    # ... and nothing else: the helpers the kernels' translation units share (error text, launch profiling) stay inside the
+    # shared object (four unlisted l4d_* exports)
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("l4d_")}
+        assert exported == declared, (exported - declared, declared - exported)
 
 
 def test_ctypes_structs_match_header_layout():
