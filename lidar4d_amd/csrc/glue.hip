@@ -335,7 +335,14 @@ __global__ void __launch_bounds__(1024) flow_loss_finish_kernel(const float* __r
   }
   const float l1 = block_sum_1024(acc, red);
   float mx = 0.0f;
-  for (int64_t i = threadIdx.x; i < n_dy; i += 1024) mx = nonfinite(dy[i]) ? __builtin_inff() : fmaxf(mx, fabsf(dy[i]));
+  {  // (n_dy = 6 n is even and dy is 8-byte aligned: two values per load)
+    const float2_t* dy2 = reinterpret_cast<const float2_t*>(dy);
+    for (int64_t i = threadIdx.x; i < n_dy / 2; i += 1024) {
+      const float2_t v = dy2[i];
+      mx = (nonfinite(v[0]) || nonfinite(v[1])) ? __builtin_inff() : fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    }
+    if ((n_dy & 1) && threadIdx.x == 0) mx = nonfinite(dy[n_dy - 1]) ? __builtin_inff() : fmaxf(mx, fabsf(dy[n_dy - 1]));
+  }
   red[threadIdx.x] = mx;
   __syncthreads();
 #pragma unroll

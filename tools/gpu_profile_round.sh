@@ -44,14 +44,15 @@ for C in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRA
   rm -rf $O/cal_$T
 done
 { grep -E "^calib|bytes per" $O/calib_FETCH_SIZE.log; grep -E "calib_|counter" $O/calib_FETCH_SIZE.txt $O/calib_TCC_EA0_RDREQ_sum.txt; } > $O/${TAG}_counter_calibration.txt
-python bench.py > $O/bench.json 2> $O/bench.err
+L4D_BENCH_DETAIL=$PWD/$O/bench_detail.json python bench.py > $O/bench.json 2> $O/bench.err
 echo "bench rc=$?"; head -c 400 $O/bench.json; echo
 # the other workloads and the data-parallel code path (one forced rank: RCCL init, hook, async all-reduce, both transports)
-python bench.py --graph --steps 20 --warmup 5 --no-cpu-baseline --variant-steps 0 --profile-steps 0 > $O/bench_graph.json 2> $O/bench_graph.err; echo "graph rc=$?"
-python bench.py --workload c2 --steps 10 --no-cpu-baseline --variant-steps 0 > $O/bench_c2.json 2> $O/bench_c2.err; echo "c2 rc=$?"
-python bench.py --workload c5 --steps 5 --warmup 1 --no-cpu-baseline --profile-steps 0 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?"
-python bench.py --workload c3-1k --steps 40 --warmup 5 --no-cpu-baseline --variant-steps 0 --profile-steps 0 > $O/bench_c3_1k.json 2> $O/bench_c3_1k.err; echo "c3-1k rc=$?"
-python bench.py --workload c3-1k --graph --steps 40 --warmup 5 --no-cpu-baseline --variant-steps 0 --profile-steps 0 > $O/bench_c3_1k_graph.json 2> $O/bench_c3_1k_graph.err; echo "c3-1k graph rc=$?"
+L4D_BENCH_DETAIL=$PWD/$O/bench_graph_detail.json python bench.py --graph --steps 20 --warmup 5 --no-cpu-baseline --variant-steps 0 --profile-steps 0 > $O/bench_graph.json 2> $O/bench_graph.err; echo "graph rc=$?"
+L4D_BENCH_DETAIL=$PWD/$O/bench_c2_detail.json python bench.py --workload c2 --steps 10 --no-cpu-baseline --variant-steps 0 > $O/bench_c2.json 2> $O/bench_c2.err; echo "c2 rc=$?"
+L4D_BENCH_DETAIL=$PWD/$O/bench_c5_detail.json python bench.py --workload c5 --steps 5 --warmup 1 --no-cpu-baseline --profile-steps 0 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?"
+L4D_BENCH_DETAIL=$PWD/$O/bench_c3_1k_detail.json python bench.py --workload c3-1k --steps 40 --warmup 5 --no-cpu-baseline --variant-steps 0 --profile-steps 2 > $O/bench_c3_1k.json 2> $O/bench_c3_1k.err; echo "c3-1k rc=$?"
+L4D_BENCH_DETAIL=$PWD/$O/bench_c3_1k_graph_detail.json python bench.py --workload c3-1k --graph --steps 40 --warmup 5 --no-cpu-baseline --variant-steps 0 --profile-steps 0 > $O/bench_c3_1k_graph.json 2> $O/bench_c3_1k_graph.err; echo "c3-1k graph rc=$?"
+export L4D_BENCH_DETAIL=$PWD/$O/bench_dist_detail.json
 D="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --no-cpu-baseline --variant-steps 0 --profile-steps 0"
 L4D_FORCE_DIST=1 $D > $O/bench_dist1.json 2> $O/bench_dist1.err; echo "dist1 rc=$?"
 L4D_FORCE_DIST=1 L4D_GRAD_TRANSPORT=bf16 $D > $O/bench_dist1_bf16.json 2> $O/bench_dist1_bf16.err; echo "dist1 bf16 rc=$?"
