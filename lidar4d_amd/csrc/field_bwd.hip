@@ -847,7 +847,11 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     if (!s_lds) return fail(1);
   }
   // chunking: one chunk per workgroup column; few enough chunks that the flush traffic stays small
-  int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, 8192)));
+  // (one chunk per CU from 2,048 samples per chunk on: at the reference's own batch of 1,024 rays -- 786 k samples -- the former
+  // rule of >= 8,192 samples per chunk left 96 workgroups for 256 CUs in the time-plane kernel, whose grid is the chunks)
+  static int chunk_min = -1;
+  if (chunk_min < 0) { const char* e = getenv("L4D_BWD_CHUNK_MIN"); chunk_min = (e && atoi(e) >= 64) ? atoi(e) : 2048; }
+  int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, chunk_min)));
   const int64_t chunk = ceil_div64(P, n_chunks);
   n_chunks = (int)ceil_div64(P, chunk);
   // consecutive-lane = consecutive-sample-of-one-ray property, needed for the wave-level band skip

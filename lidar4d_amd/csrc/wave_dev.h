@@ -80,6 +80,19 @@ __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
   if (K < 3) asm volatile("s_nop 1");
 #pragma unroll
   for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f2, 2);
+#ifdef L4D_SCAN_ADAPTIVE
+  // steps 3 and 4 only where some run of the wavefront is longer than 4 / 8 lanes (wave-uniform: the flags are 0 everywhere otherwise)
+  if (WIDTH > 4 && __any(r.f4 != 0.0f)) {
+    asm volatile("s_nop 4");
+#pragma unroll
+    for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f4, 4);
+    if (WIDTH > 8 && __any(r.f8 != 0.0f)) {
+      if (K < 3) asm volatile("s_nop 1");
+#pragma unroll
+      for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f8, 8);
+    }
+  }
+#else
   if (WIDTH > 4) {
     if (K < 3) asm volatile("s_nop 1");
 #pragma unroll
@@ -90,6 +103,7 @@ __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f8, 8);
   }
+#endif
 #undef L4D_FMAC_DPP
 }
 

@@ -5,8 +5,10 @@
 
 Roofs (all measured on this chip):
   issue   every wave-level instruction needs an issue slot of its SIMD.  SQ_INSTS_VALU / SALU / LDS / VMEM / SMEM (rocprofv3 --pmc,
-          tools/gpu_pmc_quick.sh "inst") are the kernel's dynamic instruction counts; a SIMD issues at most one VALU instruction per
-          ISSUE_CYCLES cycles (wave64 on a 32-lane SIMD: 2 passes) -> t_issue = INSTS_VALU x ISSUE_CYCLES / (1024 SIMDs x CLOCK).
+          tools/gpu_pmc_quick.sh "inst") are the kernel's dynamic instruction counts; every VALU instruction of a wave64 occupies
+          its SIMD for one quad-cycle = ISSUE_CYCLES cycles (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00 quad-cycles for
+          every kernel of this step, profiles/r04_pmc_sq.txt + r04_pmc_inst.txt; packed fp32 buys nothing)
+          -> t_issue = INSTS_VALU x ISSUE_CYCLES / (1024 SIMDs x CLOCK).
           MFMA kernels: + SQ_INSTS_MFMA x 16 cycles (v_mfma_f32_16x16x32_f16: 4 passes of 4 cycles) on the matrix pipe, which
           runs beside the VALU -> max of the two.
   hbm     compulsory bytes of the byte model (bench.py kernel_models) / 6.3 TB/s achievable.
@@ -20,7 +22,7 @@ import sys
 
 CLOCK = 2.3e9          # sustained shader clock under these kernels (GRBM_GUI_ACTIVE / wall, profiles/*_pmc_mfma)
 SIMDS = 1024
-ISSUE_CYCLES = 2.0     # one wave64 VALU instruction per 2 cycles per SIMD (157 TFLOP/s fp32 vector peak = this rate)
+ISSUE_CYCLES = 4.0     # one wave64 VALU instruction per quad-cycle per SIMD (measured, see above)
 MFMA_CYCLES = 16.0     # v_mfma_f32_16x16x32_f16 on one SIMD
 HBM = 6.3e12
 MISS_LINES = 64e9
@@ -39,7 +41,7 @@ def main():
             if k == name or (name.endswith(">") and k.startswith(name[:-1] + ",")) or (name.endswith(", DEF>") and k.startswith(name[:-4]) and not k.endswith(", 0>")):
                 c = v.get(counter)
                 if c and c["launches"]:
-                    return c["sum"] / c["launches"]
+                    return c["sum"] / c["launches"]  # (all launches: scaled by launches per step below)
         return None
 
     def traf(name):

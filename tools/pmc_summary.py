@@ -38,8 +38,13 @@ STREAM = ("planes_static_lds_kernel", "dynhash_lds_kernel", "dynhash_fwd_lds_ker
 
 
 def per_launch(d, name):
+    """average per launch over the kernel's LARGE launches when the dump separates them (rocpd_pmc.py big_*), else over all"""
     c = d.get(name)
-    return None if not c or not c.get("launches") else c["sum"] / c["launches"]
+    if not c or not c.get("launches"):
+        return None
+    if c.get("big_launches"):
+        return c["big_sum"] / c["big_launches"]
+    return c["sum"] / c["launches"]
 
 
 def main(rd, wr, l2, mfma, out_dir, tag, lib):

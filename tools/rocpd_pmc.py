@@ -2,7 +2,10 @@
 
     python tools/rocpd_pmc.py results.db [--json out.json]
 
---json: {kernel (demangled, as written at the launch site, e.g. "mlp_fwd_kernel<8, 1>"): {counter: {"launches": n, "sum": s}}}
+--json: {kernel (demangled, as written at the launch site, e.g. "mlp_fwd_kernel<8, 1>"): {counter: {"launches": n, "sum": s,
+         "big_launches": nb, "big_sum": sb}}} -- big_*: only the dispatches whose grid is at least half the kernel's largest grid
+         (a step launches some kernels on the render batch AND on small inputs -- the scene-flow loss evaluates the flow field on
+         a frame's point cloud --; a byte model of the render-sized launch must be compared with those launches only)
 """
 import json
 import re
@@ -75,6 +78,17 @@ def main(path, json_out=None):
          f"from {pe} e join {ip} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id "
          f"group by s.kernel_name, p.{name_col} order by 4 desc")
     rows = cur.execute(q).fetchall()
+    big = {}
+    cols_kd = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
+    gcols = [c for c in ("grid_size_x", "grid_size_y", "grid_size_z") if c in cols_kd]
+    if gcols:
+        grid = " * ".join(f"max(d.{c}, 1)" for c in gcols)
+        qb = (f"select s.kernel_name, p.{name_col}, count(distinct d.id), sum(e.value) "
+              f"from {pe} e join {ip} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id "
+              f"join (select kernel_id as kid, max({grid.replace('d.', '')}) as mg from {kd} group by kernel_id) g on g.kid = d.kernel_id "
+              f"where ({grid}) * 2 >= g.mg group by s.kernel_name, p.{name_col}")
+        for kname, cname, n, ssum in cur.execute(qb).fetchall():
+            big[(kname, str(cname))] = (n, ssum)
     names = demangle(sorted({r[0] for r in rows}))
     print(f"{'kernel':56s} {'counter':28s} {'launches':>8s} {'sum':>14s} {'per_launch':>14s} {'kernel_ns/launch':>16s}")
     for r in rows[:240]:
@@ -82,7 +96,10 @@ def main(path, json_out=None):
     if json_out:
         out = {}
         for r in rows:
-            out.setdefault(names[r[0]], {})[str(r[1])] = {"launches": r[2], "sum": r[3], "kernel_ns": r[4]}
+            e = {"launches": r[2], "sum": r[3], "kernel_ns": r[4]}
+            if (r[0], str(r[1])) in big:
+                e["big_launches"], e["big_sum"] = big[(r[0], str(r[1]))]
+            out.setdefault(names[r[0]], {})[str(r[1])] = e
         json.dump(out, open(json_out, "w"), indent=1)
 
 
