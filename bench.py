@@ -148,8 +148,10 @@ def kernel_models(model, P, M):
     m["bin_pass1_kernel<3, 4>"] = dict(bound="hbm", bytes=(16 + 8 * L + L * rec) * P, note="static grid: xt + dX columns read, sorted records written (upper bound)")
     m["bin_pass2_kernel<3, 4>"] = dict(bound="hbm", bytes=L * rec * P, note="static grid: records read, segments reduced in LDS")
     rec2 = 4 * 8
-    m["bin_pass1_kernel<3, 2>"] = dict(bound="hbm", bytes=(16 + 4 * Lf + Lf * rec2) * P, note="flow grid records")
-    m["bin_pass2_kernel<3, 2>"] = dict(bound="hbm", bytes=Lf * rec2 * P, note="flow grid records")
+    # (the flow grid's coarse levels -- 32 ... 345 cells per axis -- hold 5 ... 59 consecutive samples of a ray per cell: their runs
+    # are merged before a record is formed, so far fewer than 4 records per sample and level exist: an upper bound)
+    m["bin_pass1_kernel<3, 2>"] = dict(bound="hbm", bytes=(16 + 4 * Lf + Lf * rec2) * P, upper_bound=True, note="flow grid records (upper bound: merged runs emit fewer)")
+    m["bin_pass2_kernel<3, 2>"] = dict(bound="hbm", bytes=Lf * rec2 * P, upper_bound=True, note="flow grid records (upper bound: merged runs emit fewer)")
     for k in ("bin_pass2_kernel<3, 4>", "bin_pass2_kernel<3, 2>"):  # launch-site names of the compile-time / run-time bin size variants
         m[k[:-1] + ", DEF>"] = m[k[:-1] + ", 0>"] = m[k]
         m[k.replace("pass2_kernel", "pass2_flat_kernel")[:-1] + ", DEF>"] = dict(m[k], note=m[k]["note"] + " (flattened walk: 64 tiles' runs per wavefront)")

@@ -3,7 +3,7 @@
     python tools/rocpd_pmc.py results.db [--json out.json]
 
 --json: {kernel (demangled, as written at the launch site, e.g. "mlp_fwd_kernel<8, 1>"): {counter: {"launches": n, "sum": s,
-         "big_launches": nb, "big_sum": sb}}} -- big_*: only the dispatches whose grid is at least half the kernel's largest grid
+         "big_launches": nb, "big_sum": sb}}} -- big_*: only the dispatches that took at least half as long as the kernel's longest one
          (a step launches some kernels on the render batch AND on small inputs -- the scene-flow loss evaluates the flow field on
          a frame's point cloud --; a byte model of the render-sized launch must be compared with those launches only)
 """
@@ -80,13 +80,12 @@ def main(path, json_out=None):
     rows = cur.execute(q).fetchall()
     big = {}
     cols_kd = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
-    gcols = [c for c in ("grid_size_x", "grid_size_y", "grid_size_z") if c in cols_kd]
-    if gcols:
-        grid = " * ".join(f"max(d.{c}, 1)" for c in gcols)
+    # "large" launches of a kernel: at least half as long as its longest one (grids do not tell: several kernels cap their grid)
+    if "start" in cols_kd and "end" in cols_kd:
         qb = (f"select s.kernel_name, p.{name_col}, count(distinct d.id), sum(e.value) "
               f"from {pe} e join {ip} p on e.pmc_id = p.id join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id "
-              f"join (select kernel_id as kid, max({grid.replace('d.', '')}) as mg from {kd} group by kernel_id) g on g.kid = d.kernel_id "
-              f"where ({grid}) * 2 >= g.mg group by s.kernel_name, p.{name_col}")
+              f"join (select kernel_id as kid, max(end - start) as md from {kd} group by kernel_id) g on g.kid = d.kernel_id "
+              f"where (d.end - d.start) * 2 >= g.md group by s.kernel_name, p.{name_col}")
         for kname, cname, n, ssum in cur.execute(qb).fetchall():
             big[(kname, str(cname))] = (n, ssum)
     names = demangle(sorted({r[0] for r in rows}))
