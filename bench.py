@@ -19,7 +19,10 @@ Rank r draws its own ray indices (all ranks step through the same frame sequence
 everywhere); the flat gradient buffer is SUM-all-reduced over RCCL once per step.  Inputs are resident in HBM before the
 timed region.
 
-Besides the contract's fields the JSON line carries (rank 0, N = 1):
+The ONE stdout line stays under 4 KB (compact_line): the contract's fields plus scalar summaries; everything listed below in
+full goes to the side file bench_detail.json (L4D_BENCH_DETAIL), whose path is the line's ``detail`` field.
+
+Besides the contract's fields the line / the detail record carry (rank 0, N = 1):
   roofline          the dominant single kernel against ITS roof (see ``kernel_models``): HBM-streaming kernels against the
                     8 TB/s HBM peak with their compulsory bytes; gather kernels against the 34.5 TB/s L2 peak with the
                     table-entry bytes the algorithm touches (the tables, 97 MB, sit in L2 / Infinity Cache, so dividing those
