@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int
 static int bs_shift(int NV) {
   const char* e = getenv(NV == 4 ? "L4D_BS_SHIFT4" : NV == 2 ? "L4D_BS_SHIFT2" : "L4D_BS_SHIFT1");
   if (e && atoi(e) >= 9 && atoi(e) <= BS_KEY_BITS) return atoi(e);
-  return NV == 4 ? 11 : NV == 2 ? 12 : 13;
+  return NV == 4 ? 11 : NV == 2 ? 11 : 13;  // (NV = 2, the flow grid: 4,096-entry bins 1.01 ms in the flattened pass 2, 2,048: 0.89, 1,024: 0.93)
 }
 
 // L4D_BS_FLAT=0 selects the run-per-lane-group form of pass 2 (bin_pass2_kernel); default: the flattened walk
@@ -684,10 +684,14 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   {                                                                                                                          \
     L4D_LAUNCH((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
                        g_col, pre_scale, pl.shift, (int64_t)pl.n_wg, offs, bins, lvl_max, out, out_scale);                                     \
-    constexpr int DEF = V == 4 ? 11 : V == 2 ? 12 : 13;  /* bs_shift()'s defaults: compile-time bin size */                       \
+    constexpr int DEF = V == 4 ? 11 : V == 2 ? 11 : 13;  /* bs_shift()'s defaults: compile-time bin size */                       \
     if (pl.shift == DEF && bs_flat()) {                                                                                      \
       (void)hipFuncSetAttribute((const void*)bin_pass2_flat_kernel<D, V, DEF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);  \
       L4D_LAUNCH((bin_pass2_flat_kernel<D, V, DEF>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
+                 lvl_max, out, out_scale);                                                                                   \
+    } else if (bs_flat()) { /* a bin size other than the compiled-in one (L4D_BS_SHIFT*: tuning) */                          \
+      (void)hipFuncSetAttribute((const void*)bin_pass2_flat_kernel<D, V, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);    \
+      L4D_LAUNCH((bin_pass2_flat_kernel<D, V, 0>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins,   \
                  lvl_max, out, out_scale);                                                                                   \
     } else if (pl.shift == DEF) {                                                                                                 \
       (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V, DEF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);       \
