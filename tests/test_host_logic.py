@@ -613,3 +613,35 @@ def test_library_issues_no_memset_or_memcpy_nodes():
     for mod in ("fused.py", "flow_field.py"):
         src = open(os.path.join(root, mod)).read()
         assert not re.search(r"\.abs\(\)\.(a?max)\(", src), mod
+
+
+def test_lidar4d_rejects_hash_encoder_options_the_fused_pipeline_lacks():
+    """HashGridT / HashGrid4D accept feature widths 2 / 4 / 8 and other reductions at operator level, the fused render
+    pipeline is built for the reference model's own layout (lidar4d.py:51-57: F = 4, four bases, concat, decompose) -- anything
+    else must fail in the constructor with a clear message, not later inside the C layer."""
+    from lidar4d_amd import LiDAR4D
+    LiDAR4D(n_levels_hash=4, log2_hashmap_size=10)  # the supported layout at a small size constructs
+    with pytest.raises(ValueError, match="fused pipeline"):
+        LiDAR4D(n_levels_hash=4, log2_hashmap_size=10, n_features_per_level_hash=8)
+
+
+def test_flat_adam_device_schedule_follows_loaded_state():
+    """once the learning-rate schedule lives on the device (FlatAdam.device_schedule: [iterations, factor]), loading an
+    optimiser state must move it along with the host-side iteration count."""
+    from lidar4d_amd import LiDAR4D
+    from lidar4d_amd.trainer import FlatAdam
+    m = LiDAR4D(n_levels_hash=4, log2_hashmap_size=10)
+    opt = FlatAdam(m, lr=1e-2, iters=1000)
+    sched = opt.device_schedule()
+    assert float(sched[0]) == 0.0
+    sd = opt.state_dict()
+    assert not sd["state"]  # (no step taken yet: torch.optim.Adam has no per-parameter state either)
+    for k, (_, prm) in enumerate(opt._torch_layout()):
+        if prm.numel() and id(prm) in opt.store.by_param:
+            sd["state"][k] = {"step": torch.tensor(250.0), "exp_avg": torch.zeros_like(prm), "exp_avg_sq": torch.zeros_like(prm)}
+    opt.load_state_dict(sd)
+    assert opt.step_count == 250 and float(opt.sched[0]) == 250.0
+    assert abs(float(opt.sched[1]) - 0.1 ** 0.25) < 1e-6
+    opt.step_count = 500
+    opt.sync_device_schedule()
+    assert float(opt.sched[0]) == 500.0
