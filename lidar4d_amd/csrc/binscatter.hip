@@ -31,6 +31,7 @@
 #define BS_KEY_BITS 13
 #define BS_FX_ONE 32767.0f
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "hashgrid_dev.h"
@@ -57,6 +58,9 @@
 #endif
 #ifndef BS_P1_MERGE_TEST
 #define BS_P1_MERGE_TEST 0  // pass 1: cheap first / last lane test in front of the run detection -- measured neutral (2.21 -> 2.20 ms)
+#endif
+#ifndef BS_P2_PIPELINE
+#define BS_P2_PIPELINE 1  // flattened pass 2: request the next window of records before the current one is accumulated
 #endif
 #ifndef BS_MIN_WAVES
 #define BS_MIN_WAVES 4  // pass 1: wavefronts per SIMD the register allocation must leave room for (128 registers)
@@ -93,6 +97,10 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   constexpr uint32_t CAP = BS_THREADS * NC;  // records per (workgroup, level) slot: every pair of every lane may have to be split
   __shared__ __attribute__((aligned(16))) uint32_t stage[CAP * NW];
   __shared__ uint32_t total_s;
+  // per-level maximum |g| of this workgroup (bit patterns of non-negative floats: ordered like unsigned integers).  Updating the
+  // global lvl_max[] per wavefront and level meant a load of the current maximum and a wait for it -- one exposed L2 round trip
+  // per level in every wavefront of the workgroup at the same moment, with nothing else to run (two workgroups per CU).
+  __shared__ uint32_t lmax_s[L4D_MAX_LEVELS];
   // One workgroup walks ALL levels of its tile of samples.  (Earlier: one workgroup per (tile, level), ordered level-fast
   // and XCD-aware so that the levels of a tile at least met in one L2.  Every such workgroup started with a cold,
   // 256-byte-strided read of its level's 2-8 bytes of the gradient rows and sat out that latency at two workgroups per
@@ -119,23 +127,44 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   const bool g_in_regs = n_lv * NV <= 32 && (g_stride * 2) % 16 == 0 && (g_col * 2) % 16 == 0;  // block-uniform
   typedef uint32_t GwVec __attribute__((ext_vector_type(GW)));  // a vector, so that a uniform index becomes relative VGPR addressing
   GwVec gw;
+  // (g_in_regs only.  The loads are unconditional -- a piece behind the last level re-reads piece 0 and is never picked: a load
+  // under a condition merges with its default value in register copies, and the copies wait for the load where it is issued)
   auto gw_load = [&](int chunk) {  // dwords 8 chunk .. 8 chunk + 7 of the row's gradient columns
 #pragma unroll
     for (int q = 0; q < GW / 4; ++q) {
-      uint4 u = make_uint4(0, 0, 0, 0);
-      if (g_in_regs && (chunk * 2 + q) * 8 < n_lv * NV) u = *reinterpret_cast<const uint4*>(grow + (chunk * 2 + q) * 8);
+      const int piece = (chunk * 2 + q) * 8 < n_lv * NV ? chunk * 2 + q : 0;  // block-uniform
+      const uint4 u = *reinterpret_cast<const uint4*>(grow + piece * 8);
       gw[4 * q + 0] = u.x; gw[4 * q + 1] = u.y; gw[4 * q + 2] = u.z; gw[4 * q + 3] = u.w;
     }
   };
-  gw_load(0);
+  gw = GwVec{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  if (g_in_regs) gw_load(0);
   auto gw_pick = [&](int k) -> uint32_t { return gw[k & (GW - 1)]; };
   half_t gnext[NV];
-  if (!g_in_regs) {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) gnext[j] = grow[j];
-  }
   for (int i = threadIdx.x; i < BS_MAX_BINS; i += BS_THREADS) hist[i] = 0;
+  if (threadIdx.x < L4D_MAX_LEVELS) lmax_s[threadIdx.x] = 0u;
   __syncthreads();
+  // The level loop exists twice (a generic lambda over GREG = "gradient dwords in the register window"): the loads of the other
+  // shapes' path, in ONE loop with the common path, made the compiler wait for every outstanding memory operation at the join --
+  // the gradient dwords just requested and the previous level's copy-out stores included -- on the common path as well.
+  // COPY-OUT, ONE LEVEL LATE.  A level's staged records (sorted by bin; LDS -> the workgroup's slot, 16 bytes per lane: the slot is
+  // 16-byte aligned and large enough for the rounded-up tail) are stored at the HEAD of the next level, behind the pick of that
+  // level's gradient dwords.  The pick waits for the dwords requested a level earlier, and the compiler's wait there is for every
+  // outstanding memory operation: with the stores issued at a level's end it drained them at the head of the next one, eight
+  // times per workgroup, with nothing else to run at two workgroups per CU.  Issued behind the pick they have a whole level
+  // (three barriers) to complete before the next wait.  Nothing touches `stage` or total_s before the next level's first
+  // barrier, which every wavefront reaches only behind its share of the copy.
+  int copy_lvl = -1;  // block-uniform
+  auto copy_out = [&]() {
+    if (copy_lvl < 0) return;
+    const uint32_t total = total_s;
+    uint32_t* dst = bins + ((uint64_t)copy_lvl * n_wg + tile) * (uint64_t)(CAP * NW);
+    const uint32_t n16 = (total * NW + 3) >> 2;
+    for (uint32_t q = threadIdx.x; q < n16; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
+    copy_lvl = -1;
+  };
+  auto levels = [&](auto greg_tag) {
+  constexpr bool GREG = decltype(greg_tag)::value;
   for (int lvl = 0; lvl < n_lv; ++lvl) {
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   const uint32_t size = desc.size[lvl];
@@ -144,10 +173,18 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // atomic path below -- so that their index is the plain xor-and-mask of hashgrid_dev.h grid_index_fast)
   const bool binned = hashed && is_pow2(size) && nbins <= BS_MAX_BINS && nbins > 1;
 
-  if (g_in_regs) {  // this level's NV halfs out of the preloaded dwords
+  if (!GREG) {  // (shapes outside the register window: this level's values, loaded where they are used)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) gnext[j] = grow[lvl * NV + j];
+  }
+  if (GREG) {  // this level's NV halfs out of the preloaded dwords
     uint32_t w[(NV + 1) / 2];
 #pragma unroll
     for (int q = 0; q < (NV + 1) / 2; ++q) w[q] = gw_pick(NV == 1 ? lvl >> 1 : lvl * (NV / 2) + q);
+    // (picked before the next dwords are requested INTO the same registers: loads scheduled in front of the pick need a second
+    // register set and a copy behind them -- which waits for them on the spot)
+#pragma unroll
+    for (int q = 0; q < (NV + 1) / 2; ++q) asm volatile("" : "+v"(w[q]) : : "memory");
     if (NV == 1 && (lvl & 1)) w[0] >>= 16;
     const half_t* hw = reinterpret_cast<const half_t*>(w);
 #pragma unroll
@@ -156,6 +193,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     const int k_next = NV == 1 ? (lvl + 1) >> 1 : (lvl + 1) * (NV / 2);
     if (lvl + 1 < n_lv && k_next % GW == 0 && (NV > 1 || ((lvl + 1) & 1) == 0)) gw_load(k_next / GW);
   }
+  copy_out();  // the previous level's records (see above)
   float gv[NV];
   bool any = false;
   float amax = 0.0f;
@@ -164,10 +202,6 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     gv[j] = valid ? h2f(gnext[j]) * pre_scale : 0.0f;
     any |= gv[j] != 0.0f;
     amax = amax_nf(amax, gv[j]);
-  }
-  if (!g_in_regs && lvl + 1 < n_lv) {  // the next level's values: in flight during this level's ranking
-#pragma unroll
-    for (int j = 0; j < NV; ++j) gnext[j] = grow[(lvl + 1) * NV + j];
   }
   // (No barrier here: the histogram was left zeroed by the scan of the previous binned level, and this level's staging writes and
   // bin offsets come two barriers down, behind every wavefront's copy-out of the previous level -- three barriers per level, not five.)
@@ -286,7 +320,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     continue;  // block-uniform: next level
   }
   amax = wave_max(amax);
-  if (lane == 0 && amax > 0.0f) atomic_max_nonneg(lvl_max + lvl, amax);
+  if (lane == 0 && amax > 0.0f) atomicMax(&lmax_s[lvl], __float_as_uint(amax));  // (ds_max_u32, nothing returned: no wait)
 
   // In pair mode the upper half of the slots only holds the second halves of pairs that straddle two bins (one pair in 2^shift):
   // a wavefront without one skips their ranking and staging code altogether (wave-uniform branch instead of exec-masked no-ops).
@@ -307,7 +341,6 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     for (int k = NC / 2; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   }
   __syncthreads();
-  const uint64_t wg_slot = (uint64_t)lvl * n_wg + tile;
   if (threadIdx.x < 64) {  // exclusive scan of the bin totals by one wave: BPL consecutive bins per lane
     constexpr int BPL = BS_MAX_BINS / 64;
     uint32_t c[BPL], sum = 0;
@@ -329,19 +362,28 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     // records themselves.  The 2-byte stores below land in lines that the neighbouring tiles (same XCD, dispatched together:
     // xcd_tile) complete within the same L2.
     const uint32_t nwg32 = (uint32_t)n_wg;  // (levels x bins x workgroups < 2^32: checked by the host side)
-    uint16_t* o = offs + (uint64_t)lvl * (BS_MAX_BINS + 1) * n_wg + tile;
+    // scalar base + 32-bit byte offset per lane: as 64-bit per-lane addresses the level-invariant part was hoisted out of the level
+    // loop into two register pairs that did not fit and were reloaded from scratch here -- in the one wavefront that the other
+    // fifteen of the workgroup wait for
+    const uint64_t ob = reinterpret_cast<uint64_t>(offs + (uint64_t)lvl * (BS_MAX_BINS + 1) * n_wg + tile);
+    typedef __attribute__((address_space(1))) char GlobalByte;  // (an integer cast to a plain pointer is a FLAT address)
+    typedef __attribute__((address_space(1))) uint16_t GlobalU16;
+    GlobalByte* o = (GlobalByte*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ob >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob));
     uint32_t excl = inc - sum;
+    uint32_t lane_off = (uint32_t)(lane * BPL) * nwg32 * 2u;
+    asm volatile("" : "+v"(lane_off));  // (opaque per level: hoisted out of the level loop the offsets become 64-bit register pairs again)
 #pragma unroll
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
       boff[b] = excl;
-      if (b <= nbins) o[(uint32_t)b * nwg32] = (uint16_t)excl;
+      if (b <= nbins) *(GlobalU16*)(o + (lane_off + (uint32_t)q * nwg32 * 2u)) = (uint16_t)excl;
       excl += c[q];
     }
     if (lane == 63) {
       total_s = inc;
       boff[BS_MAX_BINS] = inc;
-      if (nbins == BS_MAX_BINS) o[(uint32_t)BS_MAX_BINS * nwg32] = (uint16_t)inc;
+      if (nbins == BS_MAX_BINS) *(GlobalU16*)(o + (uint32_t)BS_MAX_BINS * nwg32 * 2u) = (uint16_t)inc;
     }
   }
   __syncthreads();
@@ -364,12 +406,17 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     for (int k = NC / 2; k < NC; ++k) stage_slot(k);
   }
   __syncthreads();
-  const uint32_t total = total_s;
-  uint32_t* dst = bins + wg_slot * (uint64_t)(CAP * NW);
-  // already sorted by bin; 16 bytes per lane (the slot is 16-byte aligned and large enough for the rounded-up tail)
-  const uint32_t n16 = (total * NW + 3) >> 2;
-  for (uint32_t q = threadIdx.x; q < n16; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
+  copy_lvl = lvl;  // the staged records leave at the head of the next level (or behind the loop)
   }  // levels
+  };
+  if (g_in_regs) levels(std::true_type{});
+  else levels(std::false_type{});
+  copy_out();
+  __syncthreads();
+  if ((int)threadIdx.x < n_lv) {
+    const uint32_t m = lmax_s[threadIdx.x];
+    if (m != 0u) atomic_max_nonneg(lvl_max + threadIdx.x, __uint_as_float(m));
+  }
 }
 
 // CSHIFT > 0: the bin size is a compile-time constant, so the [value][entry] accumulator addresses are ONE register (entry * 8) plus
@@ -537,8 +584,14 @@ __global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int
   owner_tag[wave][lane] = 0xFFFFFFFFu;
   __syncthreads();
   const float fxs = fx_scale(gmax * 16.5f, 30);
-  auto add = [&](uint32_t w0, const uint32_t* wd) {  // as in bin_pass2_kernel
-    const half_t* hv = reinterpret_cast<const half_t*>(wd);
+  // one record = NW words, kept as ONE register tuple from its load to its use (separate scalars made the register allocator copy
+  // the words out of the load's destination right behind the load, i.e. wait for it there)
+  typedef uint32_t RecVec __attribute__((ext_vector_type(NW)));
+  auto add = [&](const RecVec rv) {  // as in bin_pass2_kernel
+    const uint32_t w0 = rv[0];
+    // (the halfs are taken out of the payload WORDS here, with shifts: read through a half_t pointer the words were split into
+    // 16-bit pieces where they are loaded)
+    auto hv_at = [&](int j) -> half_t { return __builtin_bit_cast(half_t, (unsigned short)(rv[1 + (j >> 1)] >> (16 * (j & 1)))); };
     const uint32_t local = w0 & ((1u << BS_KEY_BITS) - 1u), code = (w0 >> BS_KEY_BITS) & 15u;
     const bool single = code == BS_CODE_SINGLE;
     const float f1 = single ? 0.0f : (float)(w0 >> (BS_KEY_BITS + 4)) * (1.0f / BS_FX_ONE);
@@ -548,7 +601,7 @@ __global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int
     unsigned long long* a1 = reinterpret_cast<unsigned long long*>(acc) + other;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const float v = h2f(hv[j]);
+      const float v = h2f(hv_at(j));
       if (v != 0.0f) {
         const float2_t p = float2_t{s0, s1} * v;  // one v_pk_mul_f32
         atomicAdd(a0 + j * seg, (unsigned long long)(long long)fx_round(p[0]));
@@ -566,57 +619,89 @@ __global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int
   int w_n = wave * 64 + lane;
   uint32_t s0_n = 0u, s1_n = 0u;
   if (wave < n_batches && w_n < n_wg) { s0_n = o0[w_n]; s1_n = o1[w_n]; }
-  for (int batch = wave; batch < n_batches; batch += n_waves) {
-    const uint32_t s0 = s0_n, c = s1_n - s0_n;
-    const int tile0 = batch * 64;
-    {
-      const int wn = (batch + n_waves) * 64 + lane;
-      s0_n = s1_n = 0u;
-      if (batch + n_waves < n_batches && wn < n_wg) { s0_n = o0[wn]; s1_n = o1[wn]; }
-    }
-    // inclusive prefix sum of the run lengths over the wavefront (DPP: row scan, then the row totals carried upwards)
-    uint32_t inc = c;
-#define L4D_ADD_DPP(ctrl, rmask) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, ctrl, rmask, 0xf, true)
-    L4D_ADD_DPP(0x111, 0xf);  // row_shr:1 (bound_ctrl: lanes without a source add 0)
-    L4D_ADD_DPP(0x112, 0xf);
-    L4D_ADD_DPP(0x114, 0xf);
-    L4D_ADD_DPP(0x118, 0xf);
-    L4D_ADD_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-    L4D_ADD_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
-#undef L4D_ADD_DPP
-    const uint32_t P0 = inc - c;                                                   // records of the batch in front of this tile's run
-    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);         // records of the batch
-    const int base = (int)s0 - (int)P0;                                            // record position q -> index in the tile's slot
-    for (uint32_t q0 = 0; q0 < T; q0 += 64) {
-      ++stamp;
-      // this tile's run enters the window [q0, q0 + 64) at position max(P0, q0) - q0, if it overlaps it at all
-      if (c != 0u && P0 < q0 + 64u && P0 + c > q0) owner_tag[wave][P0 > q0 ? P0 - q0 : 0u] = (stamp << 8) | (uint32_t)lane;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const uint32_t tv = owner_tag[wave][lane];
-      int own = (tv >> 8) == stamp ? (int)(tv & 255u) : -1;
-#define L4D_MAXI_DPP(ctrl, rmask) own = max(own, __builtin_amdgcn_update_dpp(-1, own, ctrl, rmask, 0xf, false))
-      L4D_MAXI_DPP(0x111, 0xf);
-      L4D_MAXI_DPP(0x112, 0xf);
-      L4D_MAXI_DPP(0x114, 0xf);
-      L4D_MAXI_DPP(0x118, 0xf);
-      L4D_MAXI_DPP(0x142, 0xa);
-      L4D_MAXI_DPP(0x143, 0xc);
-#undef L4D_MAXI_DPP
-      const uint32_t q = q0 + (uint32_t)lane;
-      const bool ok = q < T;  // (then own >= 0: position q0 lies inside a run, whose tile stamped position 0)
-      const int ob = __shfl(base, ok ? own : lane, 64);
-      uint32_t key = BS_CODE_SINGLE << BS_KEY_BITS, wd[NW - 1];
-#pragma unroll
-      for (int k = 0; k < NW - 1; ++k) wd[k] = 0u;
-      if (ok) {
-        const uint32_t* rec = lvl_bins + (uint64_t)(uint32_t)(tile0 + own) * SLOT + (uint32_t)(ob + (int)q) * NW;
-        key = rec[0];
-#pragma unroll
-        for (int k = 0; k < NW - 1; ++k) wd[k] = rec[1 + k];
+  // Walk state (wave-uniform): the open batch of 64 tiles and the window position inside its concatenated runs.
+  int batch = wave - n_waves, tile0 = 0, base = 0;
+  uint32_t c = 0u, P0 = 0u, T = 0u, q0 = 0u;
+  // fetch: the next window of 64 records (opening the next batches as needed) -- finds every position's owner and ISSUES the record
+  // loads into (key, wd); nothing here waits for them.  false: no records left.
+  auto fetch = [&](RecVec& rv, bool& ok) -> bool {
+    while (q0 >= T) {  // (wave-uniform)
+      batch += n_waves;
+      if (batch >= n_batches) return false;
+      const uint32_t s0 = s0_n;
+      c = s1_n - s0_n;
+      tile0 = batch * 64;
+      {
+        const int wn = (batch + n_waves) * 64 + lane;
+        s0_n = s1_n = 0u;
+        if (batch + n_waves < n_batches && wn < n_wg) { s0_n = o0[wn]; s1_n = o1[wn]; }
       }
-      add(key, wd);
+      // inclusive prefix sum of the run lengths over the wavefront (DPP: row scan, then the row totals carried upwards)
+      uint32_t inc = c;
+#define L4D_ADD_DPP(ctrl, rmask) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, ctrl, rmask, 0xf, true)
+      L4D_ADD_DPP(0x111, 0xf);  // row_shr:1 (bound_ctrl: lanes without a source add 0)
+      L4D_ADD_DPP(0x112, 0xf);
+      L4D_ADD_DPP(0x114, 0xf);
+      L4D_ADD_DPP(0x118, 0xf);
+      L4D_ADD_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+      L4D_ADD_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef L4D_ADD_DPP
+      P0 = inc - c;                                                   // records of the batch in front of this tile's run
+      T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);         // records of the batch
+      base = (int)s0 - (int)P0;                                       // record position q -> index in the tile's slot
+      q0 = 0u;
     }
+    ++stamp;
+    // this tile's run enters the window [q0, q0 + 64) at position max(P0, q0) - q0, if it overlaps it at all
+    if (c != 0u && P0 < q0 + 64u && P0 + c > q0) owner_tag[wave][P0 > q0 ? P0 - q0 : 0u] = (stamp << 8) | (uint32_t)lane;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t tv = owner_tag[wave][lane];
+    int own = (tv >> 8) == stamp ? (int)(tv & 255u) : -1;
+#define L4D_MAXI_DPP(ctrl, rmask) own = max(own, __builtin_amdgcn_update_dpp(-1, own, ctrl, rmask, 0xf, false))
+    L4D_MAXI_DPP(0x111, 0xf);
+    L4D_MAXI_DPP(0x112, 0xf);
+    L4D_MAXI_DPP(0x114, 0xf);
+    L4D_MAXI_DPP(0x118, 0xf);
+    L4D_MAXI_DPP(0x142, 0xa);
+    L4D_MAXI_DPP(0x143, 0xc);
+#undef L4D_MAXI_DPP
+    const uint32_t q = q0 + (uint32_t)lane;
+    ok = q < T;  // (then own >= 0: position q0 lies inside a run, whose tile stamped position 0)
+    const int ob = __shfl(base, ok ? own : lane, 64);
+    // UNCONDITIONAL loads (lanes behind the batch's last record read the level's first record and ignore it): loads inside an
+    // `if (ok)` made the compiler wait for them at the end of that block -- the merge with the default values is a copy
+    const uint32_t* rec = ok ? lvl_bins + (uint64_t)(uint32_t)(tile0 + own) * SLOT + (uint32_t)(ob + (int)q) * NW : lvl_bins;
+    __builtin_memcpy(&rv, rec, NW * sizeof(uint32_t));  // one global_load_dwordx2 / x3 (4-byte aligned; a 3-vector's size is 16)
+    q0 += 64u;
+    return true;
+  };
+#if BS_P2_PIPELINE
+  // Two windows in flight: the records of window n + 1 are requested before window n is accumulated (~100 VALU instructions and up
+  // to 2 NV LDS atomics per record), two register sets in turn so that no copy waits for a load.  (One window at a time, every
+  // wavefront sat out a full memory latency per 64 records: 1.86 ms against an issue floor of 1.0, profiles/r04_floor_table.md.)
+  RecVec rec_a = {}, rec_b = {};
+  bool ok_a, ok_b;
+  // The empty asm is where a window's records are waited for: BEFORE the next window is requested, so that exactly one request is
+  // outstanding at every wait (the compiler's s_waitcnt at a control-flow join is vmcnt(0): with two requests in flight it waited
+  // for the newer one as well, right behind its issue); the request then has the whole accumulation of the previous window to land.
+  bool more = fetch(rec_a, ok_a);
+  while (more) {
+    asm volatile("" : "+v"(rec_a));
+    const bool more_b = fetch(rec_b, ok_b);
+    if (ok_a) add(rec_a);
+    if (!more_b) break;
+    asm volatile("" : "+v"(rec_b));
+    more = fetch(rec_a, ok_a);
+    if (ok_b) add(rec_b);
   }
+#else
+  {
+    RecVec rec_a = {};
+    bool ok_a;
+    while (fetch(rec_a, ok_a))
+      if (ok_a) add(rec_a);
+  }
+#endif
   __syncthreads();
   const double inv = (double)out_scale / (double)fxs;
   float* o = out + ((size_t)desc.offset[lvl] + lo) * NV;

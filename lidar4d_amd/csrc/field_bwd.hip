@@ -604,6 +604,9 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
     const bool active = pr < hi_p;
     const int64_t p = active ? pr : hi_p - 1;
     const float ca = xt[(int64_t)a * P + p], cb = xt[(int64_t)b * P + p];
+    // (requested together with the coordinates: behind the band test below it was a second memory latency per iteration; the
+    // wave-level test above has already sent nearly every wavefront that gets here into the band)
+    const uint4 u = *reinterpret_cast<const uint4*>(gvs + ((int64_t)(s * 3 + j) * P + p) * C);  // dense: 16 B per lane, consecutive
     Tap t;
     axis_tap(cb, H, t.y0, t.y1, t.wy0, t.wy1, t.my);
     const bool in0 = active && t.y0 >= row0 && t.y0 < row0 + nrows;
@@ -612,7 +615,6 @@ __global__ void __launch_bounds__(1024) planes_static_lds_kernel(FieldDesc fd, B
     axis_tap(ca, W, t.x0, t.x1, t.wx0, t.wx1, t.mx);
     float gv[C];
     {
-      const uint4 u = *reinterpret_cast<const uint4*>(gvs + ((int64_t)(s * 3 + j) * P + p) * C);  // dense: 16 B per lane, consecutive
       const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
       for (int k = 0; k < C; ++k) gv[k] = h2f(h[k]);
@@ -661,6 +663,9 @@ struct HashTasks {
   int hoff[MAX_TASKS];  // offset of (plane, level) in Hbuf
 };
 
+#ifndef DH_UNROLL
+#define DH_UNROLL 4  // samples per lane whose loads are in flight together (1 = the earlier load -> use chain)
+#endif
 // xt here: the [3][P] coordinate arrays the prep kernel wrote (xsoa)
 __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTasks tasks, const float* __restrict__ xt, int64_t P,
                                                          int64_t chunk, const half_t* __restrict__ gdynT,
@@ -688,17 +693,38 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
   auto walk = [&](auto fast_tag) {  // FAST: hashed level with a power-of-two table (block-uniform; hashgrid_dev.h grid_index_fast)
     constexpr bool FAST = decltype(fast_tag)::value;
-    for (int64_t p = lo_p + threadIdx.x; p < hi_p; p += blockDim.x) {  // hashed 2-D cells: no same-address pile-up
-      const float go = h2f(gcol[p]);
-      if (go == 0.0f) continue;
-      const float q[2] = {xt[(int64_t)ca * P + p], xt[(int64_t)cb * P + p]};
-      Cell<2> c = locate<2>(q, scale);
+    // DH_UNROLL samples per lane and iteration, ALL their loads issued before the first use: at the four wavefronts per SIMD that a
+    // 1,024-thread workgroup with 128 KB of LDS leaves, a load -> use -> load chain paid one memory latency (~1 us under load) per
+    // sample and wavefront -- the kernel ran at twice its issue floor (profiles/r04_floor_table.md).  Integer accumulation: the
+    // order of the adds does not matter, the result is bit-identical.
+    for (int64_t p0 = lo_p + threadIdx.x; p0 < hi_p; p0 += (int64_t)DH_UNROLL * blockDim.x) {  // hashed 2-D cells: no same-address pile-up
+      uint32_t gh[DH_UNROLL];  // (the half's bits)
+      float qa[DH_UNROLL], qb[DH_UNROLL];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        uint32_t gv[2];
-        const float w = corner<2>(c, k, gv);
-        const int idx = (int)(FAST ? grid_index_fast<2>(gv, size - 1u) : grid_index<2>(gv, res, size, hashed)) - lo;
-        if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)(long long)fx_round(go * w * fxs));
+      for (int u = 0; u < DH_UNROLL; ++u) {
+        const int64_t p = p0 + (int64_t)u * blockDim.x;
+        const int64_t pc = p < hi_p ? p : p0;  // past the end: a valid address, the value is dropped below
+        gh[u] = reinterpret_cast<const unsigned short*>(gcol)[pc];
+        qa[u] = xt[(int64_t)ca * P + pc];
+        qb[u] = xt[(int64_t)cb * P + pc];
+      }
+      // every value passes through an empty asm before its first use: otherwise the compiler tests the first gradient as soon as
+      // it is loaded and sinks that sample's coordinate loads behind the test -- two dependent latencies again
+#pragma unroll
+      for (int u = 0; u < DH_UNROLL; ++u) asm volatile("" : "+v"(gh[u]), "+v"(qa[u]), "+v"(qb[u]));
+#pragma unroll
+      for (int u = 0; u < DH_UNROLL; ++u) {
+        const float go = p0 + (int64_t)u * blockDim.x < hi_p ? h2f(__builtin_bit_cast(half_t, (unsigned short)gh[u])) : 0.0f;
+        if (go == 0.0f) continue;
+        const float q[2] = {qa[u], qb[u]};
+        Cell<2> c = locate<2>(q, scale);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t gv[2];
+          const float w = corner<2>(c, k, gv);
+          const int idx = (int)(FAST ? grid_index_fast<2>(gv, size - 1u) : grid_index<2>(gv, res, size, hashed)) - lo;
+          if (idx >= 0 && idx < cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[idx]), (unsigned long long)(long long)fx_round(go * w * fxs));
+        }
       }
     }
   };

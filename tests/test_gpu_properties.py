@@ -133,3 +133,72 @@ def test_backward_deterministic_and_finite(big):
     scale = float(grads[0].abs().max())
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * scale
     assert float(grads[0].abs().sum()) > 0
+
+
+def test_c5_full_frame_inference(big):
+    """BASELINE C5 at its full size on one GPU: a 64 x 2048 novel-view frame (131,072 rays x 768 samples = 100 M points) through
+    Trainer.test_step (runner.py:438-470: staged render in 32 chunks of 4,096 rays, U-Net refinement of the ray-drop image,
+    masking), range image -> points (utils/convert.py:37-62) and the chamfer / F-score meter (utils/metrics.py:249-270).  The
+    oracle cannot run this size; the pieces are pinned at small size (tests/test_next_rows.py).  Here the frame is checked through
+    its chunks (a chunk of the staged frame == the unstaged render of those 4,096 rays, bit for bit: rays are independent),
+    through test_step's masking rule, and through properties of the meter (identity, symmetry, a brute-force sample)."""
+    from lidar4d_amd import convert
+    from lidar4d_amd.data import KITTI360_FOV, KITTI360_SCALE, SyntheticKitti360
+    from lidar4d_amd.metrics import PointsMeter
+    from lidar4d_amd.trainer import Trainer
+    model, _ = big
+    H, W, CH = 64, 2048, 4096
+    data = SyntheticKitti360(DEV, W=W, num_rays=H * W, num_frames=51)
+    was_training = model.training
+    model.eval()
+    try:
+        tr = Trainer(model, data, chamfer=False, flow=False, ema_decay=None)
+        fr = data.frame(12)
+        assert fr["rays_d_lidar"].shape == (1, H * W, 3) and fr["images_lidar"].shape == (1, H, W, 3)
+        with torch.no_grad():
+            rd, ri, dep = tr.test_step(fr, refine=True)
+            raw_rd, raw_i, raw_dep = tr.test_step(fr, refine=False, alpha_r=0.0)
+        assert rd.shape == (1, H, W) and ri.shape == (1, H, W) and dep.shape == (1, H, W)
+        for a in (rd, ri, dep, raw_rd, raw_i, raw_dep):
+            assert bool(torch.isfinite(a).all())
+        assert float(rd.min()) >= 0 and float(rd.max()) <= 1 and float(raw_dep.max()) > 0
+        # first, a middle and the last chunk of the staged frame == the unstaged render of the same rays
+        for k in (0, 17, 31):
+            s = slice(k * CH, (k + 1) * CH)
+            with torch.no_grad():
+                one = model.render(fr["rays_o_lidar"][:, s], fr["rays_d_lidar"][:, s], fr["time"], staged=False, perturb=False, num_steps=T)
+            assert torch.equal(one["depth_lidar"].view(-1), raw_dep.view(-1)[s]), k
+            assert torch.equal(one["image_lidar"].view(-1, 2)[:, 0], raw_rd.view(-1)[s]) and torch.equal(one["image_lidar"].view(-1, 2)[:, 1], raw_i.view(-1)[s]), k
+        # the refined ray-drop image is the U-Net's output on the stacked raw images; depth and intensity are masked by it
+        with torch.no_grad():
+            rd_ref = model.unet(torch.cat([raw_rd, raw_i, raw_dep], 0).unsqueeze(0)).squeeze(0)
+        assert torch.allclose(rd, rd_ref, atol=1e-5)
+        keep = (rd > 0.5).to(raw_dep.dtype)
+        assert torch.equal(dep, raw_dep * keep) and torch.equal(ri, raw_i * keep)
+        # meter on full-size clouds: prediction = ground truth with 2 % range noise and two dropped rows
+        gt = fr["images_lidar"]
+        gt_depth = gt[..., 2] * gt[..., 0]
+        pred = gt_depth * (1 + 0.02 * (torch.rand_like(gt_depth) - 0.5))
+        pred[0, :2] = 0
+        meter = PointsMeter(scale=KITTI360_SCALE, intrinsics=KITTI360_FOV)
+        meter.update(pred, gt_depth)
+        meter.update(gt_depth, pred)
+        meter.update(gt_depth, gt_depth)
+        v = torch.stack(meter.V).cpu().numpy()
+        assert np.isfinite(v).all() and v[0, 0] > 0 and 0 < v[0, 1] <= 1
+        np.testing.assert_allclose(v[1], v[0], rtol=1e-6)      # chamfer distance and F-score are symmetric in their arguments
+        np.testing.assert_allclose(v[2], [0.0, 1.0], atol=1e-9)  # identical clouds
+        # nearest-neighbour distances of a sample of the predicted cloud against a brute-force torch search over the whole target
+        from lidar4d_amd.chamfer import chamfer_3DDist
+        p = convert.pano_to_lidar(pred[0] / KITTI360_SCALE, KITTI360_FOV)
+        q = convert.pano_to_lidar(gt_depth[0] / KITTI360_SCALE, KITTI360_FOV)
+        assert p.shape[0] == int((pred[0] != 0).sum()) and q.shape[0] == int((gt_depth[0] != 0).sum()) and q.shape[0] > H * W // 4
+        d1, _, i1, _ = chamfer_3DDist()(p[None], q[None])
+        pick = torch.randperm(p.shape[0], device=DEV)[:512]
+        diff = p[pick, None, :].double() - q[None, :, :].double()
+        brute, _ = (diff * diff).sum(-1).min(1)
+        np.testing.assert_allclose(d1[0, pick].double().cpu().numpy(), brute.cpu().numpy(), rtol=1e-4, atol=1e-7)
+        got = (p[pick].double() - q[i1[0, pick].long()].double()).pow(2).sum(-1)
+        np.testing.assert_allclose(got.cpu().numpy(), brute.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    finally:
+        model.train(was_training)
