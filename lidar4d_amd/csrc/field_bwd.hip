@@ -68,7 +68,9 @@ __device__ __forceinline__ void group_taps(const FieldDesc& fd, int s, const flo
 __device__ __forceinline__ void write_seg_bounds(float* __restrict__ segb, int64_t pr, int64_t P, int lane, const float4_t& c4) {
   // lanes of a wave hold consecutive samples starting at a multiple of 64 (all callers); lanes past P carry the last valid sample
   if (!segb || (lane != 0 && lane != 63) || pr - lane >= P) return;
-  const int64_t n_seg = (P + 63) >> 6, seg = pr >> 6;
+  const int64_t n_seg = (P + 63) >> 6;
+  int64_t seg = pr >> 6;
+  asm volatile("" : "+v"(seg));  // (opaque per call: hoisted out of the caller's sample loop, the three 64-bit addresses cost a scratch slot there)
 #pragma unroll
   for (int a = 0; a < 3; ++a) segb[((int64_t)a * n_seg + seg) * 2 + (lane == 63 ? 1 : 0)] = c4[a];
 }
@@ -287,8 +289,10 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
     if (PREP) {
       const int lane = __lane_id();
       if (active) {
+        int64_t pr_o = pr;
+        asm volatile("" : "+v"(pr_o));  // (opaque per iteration: hoisted out of the loop the three 64-bit addresses did not fit and one was reloaded from scratch here, behind a wait that also drained the stores in front of it)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) po.xsoa[(int64_t)a * P + pr] = c4[a];
+        for (int a = 0; a < 3; ++a) po.xsoa[(int64_t)a * P + pr_o] = c4[a];
       }
       if (pr - lane < hi_p) write_seg_bounds(po.segb, pr, P, lane, c4);  // (lanes past the chunk carry its last sample)
       const float xs0[4] = {c4[0], c4[1], c4[2], t0};
@@ -332,10 +336,15 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       // 24 wave-level maxima per iteration were a quarter of this part's instructions) and a sticky flag for inf / nan (the
       // packed maximum drops nan), which turns the maximum into +inf at the end: the step is skipped whichever level overflowed.
       const half2_t c0h = {(half_t)c0, (half_t)c0};
+      // (the three 16-byte pieces are requested together -- a piece behind the last level re-reads piece 0 and is skipped below:
+      // requested one by one, each in front of its own use, they were three memory round trips in a row per iteration)
+      uint4 ud[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) ud[q] = *reinterpret_cast<const uint4*>(row + colD + (q * 8 < L3 ? q * 8 : 0));
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         if (q * 8 < L3) {  // uniform
-          const uint4 u = *reinterpret_cast<const uint4*>(row + colD + q * 8);
+          const uint4 u = ud[q];
           const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
