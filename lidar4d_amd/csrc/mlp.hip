@@ -341,6 +341,9 @@ struct BwdFrags {
 // encoding has no trainable input).
 // MLP_BWD_NARROW_WAVES: waves per SIMD the 16-wide (flow) network's backward is compiled for.  Its accumulators are small, but
 // the compiler keeps the LDS weight fragments in registers across the tile loop as long as it has any (446 of 512).
+#ifndef MLP_BWD_PIN
+#define MLP_BWD_PIN 1  // backward kernels: wait for the prefetched next tile in front of the current tile's dX stores (see there)
+#endif
 #ifndef MLP_BWD_NARROW_WAVES
 #define MLP_BWD_NARROW_WAVES 1
 #endif
@@ -517,6 +520,31 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
       }
     }
   };
+  // pin_tile: an empty asm per register group of a prefetched tile = its first "use", so that the wait for its loads stands where
+  // the caller puts it.  The next tile (requested at the head of an iteration) is taken over in front of the current tile's dX
+  // stores, where nothing else is outstanding: left to its first real use -- the head of the next iteration -- the wait drained
+  // the stores issued just before it, and in the narrow (flow) network's kernel the compiler, seeing loads pending on the loop's
+  // entry edge, waited for part of a tile right behind its own request.  (The first tile is pinned before the loop for that.)
+  // Only where dX is at most two column tiles (the attribute networks' 16 geometry columns, the flow network's 16 inputs): their
+  // stores sit at the very end of an iteration.  The sigma network stores 8 tiles over the last third of its iteration; pinned in
+  // front of the first of them its next tile would have had 160 instructions to arrive -- it keeps the wait at the loop head.
+  constexpr bool PIN_NEXT = PREFETCH && MLP_BWD_PIN && (COL_HI - DX_LO) <= 2;
+  auto pin_tile = [&](TileIn& t, int32_t (&e)[2]) {
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int ks = 0; ks < KS_IN; ++ks) asm volatile("" : "+v"(reinterpret_cast<U4&>(t.x[a][ks])));
+      asm volatile("" : "+v"(reinterpret_cast<U4&>(t.dy[a])));
+#pragma unroll
+      for (int l = 0; l < NACT; ++l)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(reinterpret_cast<U4&>(t.h[l][a][ks])));
+      if (ATTR_EPI) asm volatile("" : "+v"(reinterpret_cast<U2&>(t.dh_old[a])));
+      if (GATHER) asm volatile("" : "+v"(e[a]));
+    }
+  };
   const int64_t tile_stride = (int64_t)gridDim.x * 4;
   int64_t mtile = (int64_t)blockIdx.x * 4 + wave;
   TileIn cur;
@@ -525,6 +553,10 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
     load_entries(mtile, ent_cur);
     load_entries(mtile + tile_stride, ent_nxt);
     load_tile(mtile, ent_cur, cur);
+  }
+  if (PIN_NEXT) {
+    pin_tile(cur, ent_nxt);
+    if (GATHER) asm volatile("" : "+v"(ent_cur[0]), "+v"(ent_cur[1]));
   }
   for (; mtile < n_macro; mtile += tile_stride) {
     // the weight fragments are re-read from LDS in every tile: hoisted out of the loop they end up parked in AGPRs and cost 4
@@ -782,6 +814,7 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) dW1[mt][nt - COL_LO] = MFMA(dzT[mt], xT, dW1[mt][nt - COL_LO]);
       }
+      if (PIN_NEXT) pin_tile(nxt, ent_nn);  // the NEXT tile's inputs are taken over here, in front of this tile's dX stores (see pin_tile)
       if (dx || ATTR_EPI) {
         constexpr int DX_PITCH = DX_LO == COL_LO ? IN_PAD : (COL_HI - DX_LO) * 16;  // full rows, or only the tiles from DX_LO on
         constexpr int DX_T0 = DX_LO == COL_LO ? 0 : DX_LO;

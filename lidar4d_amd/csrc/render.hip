@@ -72,15 +72,20 @@ __device__ __forceinline__ float alpha_of(float delta, float sigma, float densit
   return 1.0f - expf(e);
 }
 
-__global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restrict__ sigma, const float* __restrict__ z_vals,
+#define CF_RAYS 16  // rays (wavefronts) per workgroup of composite_fwd_kernel
+__global__ void __launch_bounds__(64 * CF_RAYS) composite_fwd_kernel(const float* __restrict__ sigma, const float* __restrict__ z_vals,
                                                            int64_t N, int T, float sample_dist, float density_scale,
                                                            int active, float* __restrict__ weights,
                                                            float* __restrict__ weights_sum, float* __restrict__ depth,
                                                            uint8_t* __restrict__ mask, int32_t* __restrict__ mask_idx,
                                                            int32_t* __restrict__ mask_count) {
-  const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= N) return;
+  // The work list's slots are reserved per WORKGROUP (16 rays): one returning atomic per ray on the one counter was 16,384
+  // same-address atomics per launch, served one after the other -- 0.2 ms whatever the rest of the kernel did.
+  __shared__ int wave_keep[CF_RAYS], block_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t ray_raw = (int64_t)blockIdx.x * CF_RAYS + wave;
+  const bool live = ray_raw < N;                 // (wave-uniform; a wavefront behind the last ray walks the last ray and stores nothing:
+  const int64_t ray = live ? ray_raw : N - 1;    //  every wavefront has to reach the barriers below)
   const float* sg = sigma + ray * T;
   const float* zv = z_vals + ray * T;
   float carry = 1.0f;  // transmittance entering the chunk
@@ -132,38 +137,53 @@ __global__ void __launch_bounds__(256) composite_fwd_kernel(const float* __restr
         ws[k] = w;
         wsum += w;
         dsum += w * z;
-        m = w > 1e-4f;
+        m = live && w > 1e-4f;
       }
       keep[k] = __ballot(m);
       n_keep += __popcll(keep[k]);
     }
-    // wave-level compaction: ONE atomicAdd per ray segment reserves the slots -- requested before the stores, consumed behind them
-    const bool compact = mask_idx && n_keep > 0;  // wave-uniform
-    int base = 0;
-    if (compact && lane == 0) base = atomicAdd(mask_count, n_keep);
+    // compaction: the workgroup's wavefronts post their counts, ONE atomicAdd reserves the slots of all of them (requested before
+    // the stores below, consumed behind them), every wavefront takes its share in ray order
+    if (mask_idx) {  // (uniform)
+      if (lane == 0) wave_keep[wave] = n_keep;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int tot = 0;
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      if (k >= c) continue;  // wave-uniform
-      const int j = seg0 + k * 64 + lane;
-      if (j < seg0 + seg_len) {
-        weights[ray * T + j] = ws[k];
-        if (mask) mask[ray * T + j] = (keep[k] >> lane) & 1ull ? 1 : 0;
+        for (int w = 0; w < CF_RAYS; ++w) tot += wave_keep[w];
+        block_base = tot > 0 ? atomicAdd(mask_count, tot) : 0;
       }
     }
-    if (compact) {
-      base = __shfl(base, 0, 64);
+    if (live) {
 #pragma unroll
       for (int k = 0; k < MAXC; ++k) {
-        if (k >= c) continue;
-        const unsigned long long below = keep[k] & ((1ull << lane) - 1ull);
-        if ((keep[k] >> lane) & 1ull) mask_idx[base + __popcll(below)] = (int32_t)(ray * T + seg0 + k * 64 + lane);
-        base += __popcll(keep[k]);
+        if (k >= c) continue;  // wave-uniform
+        const int j = seg0 + k * 64 + lane;
+        if (j < seg0 + seg_len) {
+          weights[ray * T + j] = ws[k];
+          if (mask) mask[ray * T + j] = (keep[k] >> lane) & 1ull ? 1 : 0;
+        }
       }
+    }
+    if (mask_idx) {
+      __syncthreads();
+      int base = block_base;
+      for (int w = 0; w < wave; ++w) base += wave_keep[w];  // (wave-uniform)
+      if (n_keep > 0) {
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+          if (k >= c) continue;
+          const unsigned long long below = keep[k] & ((1ull << lane) - 1ull);
+          if ((keep[k] >> lane) & 1ull) mask_idx[base + __popcll(below)] = (int32_t)(ray * T + seg0 + k * 64 + lane);
+          base += __popcll(keep[k]);
+        }
+      }
+      __syncthreads();  // (wave_keep / block_base are rewritten by the next segment of a long ray)
     }
   }
   wsum = wave_sum(wsum);
   dsum = wave_sum(dsum);
-  if (lane == 0) {
+  if (lane == 0 && live) {
     if (weights_sum) weights_sum[ray] = wsum;
     if (depth) depth[ray] = dsum;
   }
@@ -521,7 +541,7 @@ extern "C" int l4d_composite_fwd(const float* sigma, const float* z_vals, int64_
   if (mask_count) {
     l4d_fill_async(mask_count, 0u, sizeof(int32_t), (hipStream_t)stream);
   }
-  L4D_LAUNCH(composite_fwd_kernel, dim3((unsigned)ceil_div64(N, 4)), dim3(256), 0, (hipStream_t)stream, sigma, z_vals,
+  L4D_LAUNCH(composite_fwd_kernel, dim3((unsigned)ceil_div64(N, CF_RAYS)), dim3(64 * CF_RAYS), 0, (hipStream_t)stream, sigma, z_vals,
                      N, T, sample_dist, density_scale, active_sensor, weights, weights_sum, depth, mask, mask_idx, mask_count);
   L4D_LAUNCH_CHECK("l4d_composite_fwd");
   return 0;
