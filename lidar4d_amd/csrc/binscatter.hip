@@ -351,12 +351,17 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       if (b < nbins) hist[b] = 0u;  // ready for the next level (every rank of this level has been handed out: barrier above)
       sum += c[q];
     }
+    // inclusive prefix over the wavefront with DPP (row scan, then the row totals carried upwards: six VALU instructions; as in
+    // pass 2).  Six ds_bpermute round trips here were ~800 cycles of the ONE wavefront that the workgroup's other fifteen wait for.
     uint32_t inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t a = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += a;
-    }
+#define L4D_ADD_DPP(ctrl, rmask) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, ctrl, rmask, 0xf, true)
+    L4D_ADD_DPP(0x111, 0xf);  // row_shr:1 (bound_ctrl: lanes without a source add 0)
+    L4D_ADD_DPP(0x112, 0xf);
+    L4D_ADD_DPP(0x114, 0xf);
+    L4D_ADD_DPP(0x118, 0xf);
+    L4D_ADD_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    L4D_ADD_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef L4D_ADD_DPP
     // Bin offsets are stored TRANSPOSED, offs[level][bin][workgroup]: pass 2 walks one bin over all workgroups, and read from
     // a [workgroup][bin] table every run cost it a 64-byte sector for two 2-byte numbers -- as many fabric requests as the run's
     // records themselves.  The 2-byte stores below land in lines that the neighbouring tiles (same XCD, dispatched together:
