@@ -215,6 +215,9 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 #define PSTAT_MERGE 16
 #endif
 #ifndef PDYN_THREADS
+#ifndef PDYN_PREFETCH
+#define PDYN_PREFETCH 0  // (experiment, not measured yet) time-plane kernel: the gradient row's 16-byte piece of the NEXT scale is requested while the current scale is worked on
+#endif
 #define PDYN_THREADS 768  // 12 waves on the one workgroup a CU can hold (138 KB of LDS; 155 VGPRs allow 3 per SIMD): 3.00 -> 2.73 ms against 512
 #endif
 // PREP: the kernel also does the prep kernel's work for its samples -- static planes' product-rule factors gvs, the transposed
@@ -286,6 +289,18 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
     }
     const half_t* row = dX + p * in_pad;
+#if PDYN_PREFETCH
+    // pieces 0 .. nS-1: the static planes' gradient columns, nS .. 2 nS - 1: the time planes' (contiguous in the row)
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    U4 piece_next;
+    __builtin_memcpy(&piece_next, row + (PREP ? 0 : nS * C), 16);
+    auto next_piece = [&](int k) -> U4 {  // hands out piece k (requested one scale ago) and requests piece k + 1
+      U4 cur = piece_next;
+      asm volatile("" : "+v"(cur));  // (the wait for piece k stands here, in front of the request for piece k + 1)
+      __builtin_memcpy(&piece_next, row + min(k + 1, 2 * nS - 1) * C, 16);
+      return cur;
+    };
+#endif
     if (PREP) {
       const int lane = __lane_id();
       if (active) {
@@ -299,7 +314,11 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       for (int s = 0; s < nS; ++s) {  // static planes: gradient of plane j = dX_s * (product of the other two planes' values)
         float gs[C];
         {
+#if PDYN_PREFETCH
+          const U4 u = next_piece(s);
+#else
           const uint4 u = *reinterpret_cast<const uint4*>(row + s * C);
+#endif
           const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
           for (int k = 0; k < C; ++k) gs[k] = active ? h2f(h[k]) : 0.0f;
@@ -366,7 +385,11 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
     for (int s = 0; s < nS; ++s) {
       float gd[C];
       {
+#if PDYN_PREFETCH
+        const U4 u = next_piece(nS + s);
+#else
         uint4 u = *reinterpret_cast<const uint4*>(row + (nS + s) * C);
+#endif
         const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
         for (int k = 0; k < C; ++k) gd[k] = active ? h2f(h[k]) : 0.0f;
