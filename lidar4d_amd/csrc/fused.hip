@@ -231,9 +231,6 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
 // rounds to fp16, rounding point R2 -- carried across table parts; xy stays on the direct path in the encode kernel.)
 // Frames whose slice pair differs from the current frame's (only when a slice boundary lies between the neighbour
 // times) take the direct global path.  Output: column-major hdT[col][P] fp16, merged into X by the encode kernel.
-#ifndef DHF_LATE_STORE
-#define DHF_LATE_STORE 0
-#endif
 #define DH_THREADS 1024
 #define DH_MAX_ENTRIES 8192  // per slice: 2 slices x 8192 x 8 B = 128 KB
 // Coordinates for the LDS kernel, as dense arrays: xs[3][P] fp32 (the sample point) and flowT[6][P] fp16 (the two flow vectors,
@@ -347,32 +344,6 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
     }
   };
   auto walk = [&](auto fast_tag) {
-#if DHF_LATE_STORE
-    // (experiment, not measured yet) an iteration's two results are stored BEHIND the next iteration's loads: stored at the end of
-    // their own iteration they are older than those loads, and the in-order counter makes the first wait for a coordinate wait
-    // for the stores' acknowledgement as well
-    half_t r0 = (half_t)0.0f, r1 = (half_t)0.0f;
-    int64_t s0 = -1, s1 = -1;
-    for (int64_t p0 = lo_p + threadIdx.x; p0 < hi_p; p0 += 2 * DH_THREADS) {
-      const int64_t p1 = p0 + DH_THREADS;
-      const bool ok1 = p1 < hi_p;
-      const int64_t q1 = ok1 ? p1 : p0;
-      float xa0[3], xb0[3], xa1[3], xb1[3];
-      load(p0, xa0, xb0);
-      load(q1, xa1, xb1);
-      if (s0 >= 0) out[s0] = r0;
-      if (s1 >= 0) out[s1] = r1;
-      r0 = eval(fast_tag, xa0, xb0);
-      s0 = p0;
-      s1 = -1;
-      if (ok1) {
-        r1 = eval(fast_tag, xa1, xb1);
-        s1 = p1;
-      }
-    }
-    if (s0 >= 0) out[s0] = r0;
-    if (s1 >= 0) out[s1] = r1;
-#else
     for (int64_t p0 = lo_p + threadIdx.x; p0 < hi_p; p0 += 2 * DH_THREADS) {
       const int64_t p1 = p0 + DH_THREADS;
       const bool ok1 = p1 < hi_p;
@@ -383,7 +354,6 @@ __global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc f
       out[p0] = eval(fast_tag, xa0, xb0);
       if (ok1) out[p1] = eval(fast_tag, xa1, xb1);
     }
-#endif
   };
   if (fast_level) walk(std::true_type{});
   else walk(std::false_type{});

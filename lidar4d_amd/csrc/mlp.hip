@@ -341,9 +341,6 @@ struct BwdFrags {
 // encoding has no trainable input).
 // MLP_BWD_NARROW_WAVES: waves per SIMD the 16-wide (flow) network's backward is compiled for.  Its accumulators are small, but
 // the compiler keeps the LDS weight fragments in registers across the tile loop as long as it has any (446 of 512).
-#ifndef MLP_BWD_DELAY_DX
-#define MLP_BWD_DELAY_DX 0  // (experiment, not measured yet) wide-dX backward (the sigma network): a tile's dX is stored behind the NEXT tile's loads
-#endif
 #ifndef MLP_BWD_PIN
 #define MLP_BWD_PIN 1  // backward kernels: wait for the prefetched next tile in front of the current tile's dX stores (see there)
 #endif
@@ -557,27 +554,10 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
     load_entries(mtile + tile_stride, ent_nxt);
     load_tile(mtile, ent_cur, cur);
   }
-  if (PIN_NEXT || (MLP_BWD_DELAY_DX && PREFETCH && !ATTR_EPI && !GATHER)) {
+  if (PIN_NEXT) {
     pin_tile(cur, ent_nxt);
     if (GATHER) asm volatile("" : "+v"(ent_cur[0]), "+v"(ent_cur[1]));
   }
-  // (MLP_BWD_DELAY_DX) dX of the previous tile, held in registers until the next tile's loads have been requested: stored at the end
-  // of its own iteration it is older than nothing, and the loop head's wait for the prefetched tile drains it right behind its issue
-  constexpr bool DELAY_DX = MLP_BWD_DELAY_DX && PREFETCH && !ATTR_EPI && !GATHER && !PIN_NEXT;
-  constexpr int NDX = DELAY_DX ? COL_HI - DX_LO : 1;
-  h4 pend_v[2][NDX];
-  int64_t pend_row[2] = {-1, -1};
-  auto flush_dx = [&]() {
-    constexpr int DX_PITCH_ = DX_LO == COL_LO ? IN_PAD : (COL_HI - DX_LO) * 16;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      if (pend_row[a] >= 0) {
-#pragma unroll
-        for (int q = 0; q < NDX; ++q) *reinterpret_cast<h4*>(dx + pend_row[a] * DX_PITCH_ + 16 * (q + DX_LO - (DX_LO == COL_LO ? 0 : DX_LO)) + 4 * g) = pend_v[a][q];
-      }
-      pend_row[a] = -1;
-    }
-  };
   for (; mtile < n_macro; mtile += tile_stride) {
     // the weight fragments are re-read from LDS in every tile: hoisted out of the loop they end up parked in AGPRs and cost 4
     // v_accvgpr_read per use instead of one ds_read_b128
@@ -588,7 +568,6 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
       finish_tile(mtile, cur);
       load_tile(mtile + tile_stride, ent_nxt, nxt);  // past the end: the last tile once more, never used
       load_entries(mtile + 2 * tile_stride, ent_nn);
-      if (DELAY_DX && dx) flush_dx();
     } else {
       load_entries(mtile, ent_cur);
       load_tile(mtile, ent_cur, cur);
@@ -865,12 +844,7 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
                   *d = ov;
                 }
               } else {
-                if (DELAY_DX) {
-                  pend_v[a][DELAY_DX ? mt - DX_LO : 0] = ov;
-                  pend_row[a] = rows[a];
-                } else {
-                  *reinterpret_cast<h4*>(dx + rows[a] * DX_PITCH + 16 * (mt - DX_T0) + 4 * g) = ov;
-                }
+                *reinterpret_cast<h4*>(dx + rows[a] * DX_PITCH + 16 * (mt - DX_T0) + 4 * g) = ov;
                 if (!GATHER && dstat.out && mt >= dstat.lo_tile && mt < dstat.hi_tile) {
 #pragma unroll
                   for (int r = 0; r < 4; ++r) dx_amax = amax_nf(dx_amax, h2f(ov[r]));
@@ -881,7 +855,6 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
       }
     }
     if (PREFETCH) {
-      if (DELAY_DX) pin_tile(nxt, ent_nn);  // (no store of this iteration is outstanding: they leave behind the next tile's loads)
       cur = nxt;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -891,7 +864,6 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
     }
   }
 
-  if (DELAY_DX && dx) flush_dx();
   if (!GATHER && dstat.out) {  // wave-uniform
     dx_amax = wave_max(dx_amax);
     if (lane == 0 && dx_amax > 0.0f) atomic_max_nonneg(dstat.out, dx_amax);
