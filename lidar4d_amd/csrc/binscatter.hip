@@ -59,6 +59,9 @@
 #ifndef BS_P1_MERGE_TEST
 #define BS_P1_MERGE_TEST 0  // pass 1: cheap first / last lane test in front of the run detection -- measured neutral (2.21 -> 2.20 ms)
 #endif
+#ifndef BS_P1_WAVESCAN
+#define BS_P1_WAVESCAN 0  // (experiment, not measured yet) pass 1: every wavefront scans the bin totals itself -- two barriers per level instead of three, no single-wavefront phase
+#endif
 #ifndef BS_P2_PIPELINE
 #define BS_P2_PIPELINE 1  // flattened pass 2: request the next window of records before the current one is accumulated
 #endif
@@ -92,7 +95,11 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // wave-level atomic meets 2-4 equal addresses, and the prefix pass, its barrier and 7/8 of the zeroing were pure overhead per
   // level.)  The order of the records inside a run now depends on atomic arrival; pass 2 sums in integers, so nothing downstream
   // depends on it.
+#if BS_P1_WAVESCAN
+  __shared__ uint32_t hist2[2][BS_MAX_BINS], boffw[BS_THREADS / 64][BS_MAX_BINS];  // two histograms in turn, one offset table per wavefront
+#else
   __shared__ uint32_t hist[BS_MAX_BINS], boff[BS_MAX_BINS + 1];
+#endif
   // typically NC / 2 records per lane: NC / 2 pair records, or NC single records per run with <= 32 runs per wave
   constexpr uint32_t CAP = BS_THREADS * NC;  // records per (workgroup, level) slot: every pair of every lane may have to be split
   __shared__ __attribute__((aligned(16))) uint32_t stage[CAP * NW];
@@ -141,7 +148,12 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   if (g_in_regs) gw_load(0);
   auto gw_pick = [&](int k) -> uint32_t { return gw[k & (GW - 1)]; };
   half_t gnext[NV];
+#if BS_P1_WAVESCAN
+  for (int i = threadIdx.x; i < 2 * BS_MAX_BINS; i += BS_THREADS) (&hist2[0][0])[i] = 0;
+  int hb = 0;  // histogram of the current binned level (block-uniform)
+#else
   for (int i = threadIdx.x; i < BS_MAX_BINS; i += BS_THREADS) hist[i] = 0;
+#endif
   if (threadIdx.x < L4D_MAX_LEVELS) lmax_s[threadIdx.x] = 0u;
   __syncthreads();
   // The level loop exists twice (a generic lambda over GREG = "gradient dwords in the register window"): the loads of the other
@@ -334,6 +346,10 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   }
 #endif
   // rank inside the workgroup
+#if BS_P1_WAVESCAN
+  uint32_t* hist = hist2[hb];
+  uint32_t* boff = boffw[threadIdx.x >> 6];
+#endif
 #pragma unroll
   for (int k = 0; k < NC / 2; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   if (upper) {
@@ -341,14 +357,27 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     for (int k = NC / 2; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   }
   __syncthreads();
+#if BS_P1_WAVESCAN
+  // EVERY wavefront scans the 256 totals (4 LDS reads, 6 DPP adds, 4 LDS writes into its own offset table): no barrier between the
+  // scan and the staging, no phase in which fifteen wavefronts wait for one.  The first wavefront also stores the offsets for
+  // pass 2 and clears the OTHER histogram -- last read a level ago, next ranked into behind this level's second barrier.
+  const bool scan_io = threadIdx.x < 64;
+  {
+#else
+  const bool scan_io = true;
   if (threadIdx.x < 64) {  // exclusive scan of the bin totals by one wave: BPL consecutive bins per lane
+#endif
     constexpr int BPL = BS_MAX_BINS / 64;
     uint32_t c[BPL], sum = 0;
 #pragma unroll
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
       c[q] = b < nbins ? hist[b] : 0u;
+#if BS_P1_WAVESCAN
+      if (scan_io) hist2[hb ^ 1][b] = 0u;
+#else
       if (b < nbins) hist[b] = 0u;  // ready for the next level (every rank of this level has been handed out: barrier above)
+#endif
       sum += c[q];
     }
     // inclusive prefix over the wavefront with DPP (row scan, then the row totals carried upwards: six VALU instructions; as in
@@ -382,16 +411,22 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
       boff[b] = excl;
-      if (b <= nbins) *(GlobalU16*)(o + (lane_off + (uint32_t)q * nwg32 * 2u)) = (uint16_t)excl;
+      if (scan_io && b <= nbins) *(GlobalU16*)(o + (lane_off + (uint32_t)q * nwg32 * 2u)) = (uint16_t)excl;
       excl += c[q];
     }
-    if (lane == 63) {
+    if (scan_io && lane == 63) {
       total_s = inc;
+#if !BS_P1_WAVESCAN
       boff[BS_MAX_BINS] = inc;
+#endif
       if (nbins == BS_MAX_BINS) *(GlobalU16*)(o + (uint32_t)BS_MAX_BINS * nwg32 * 2u) = (uint16_t)inc;
     }
   }
+#if BS_P1_WAVESCAN
+  hb ^= 1;
+#else
   __syncthreads();
+#endif
   auto stage_slot = [&](int k) {
     if (emit[k]) {
       const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
