@@ -76,6 +76,9 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 // The split (l4d_density_encode_fwd with side streams) exists for two reasons: the plane part does not need the xz / yz columns
 // that dynhash_fwd_lds_kernel produces, so the two run CONCURRENTLY (texel-bandwidth-bound next to VALU / LDS-bound), and the
 // hash part alone needs half the registers, i.e. twice the wavefronts to hide its L2-missing gathers behind.
+#ifndef ENC_HDT_EARLY
+#define ENC_HDT_EARLY 0
+#endif
 template <bool USE_HDT, bool ROWS, int PART = 0>
 __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
@@ -166,10 +169,36 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
   const int col_dyn0 = col;
   {
     const TimeCoef tc0 = time_coef(t0, fd.n_slices), tc1 = time_coef(t1, fd.n_slices), tc2 = time_coef(t2, fd.n_slices);
+#if ENC_HDT_EARLY
+    // (experiment, not measured yet) the xz / yz columns that dynhash_fwd_lds_kernel produced are requested HERE, in front of the xy
+    // stack's gathers, and written into the row behind them: read level by level where they are used they were four dependent
+    // round trips at the end of a kernel that holds two wavefronts per SIMD
+    constexpr int HDT_MAX = 8;
+    const int L0_ = fd.hd[0].n_levels, L1_ = fd.hd[1].n_levels, L2_ = fd.hd[2].n_levels;
+    const bool hdt_early = USE_HDT && L1_ <= HDT_MAX && L2_ <= HDT_MAX;  // block-uniform
+    unsigned short hd_early[2][HDT_MAX];
+    if (hdt_early) {
+#pragma unroll
+      for (int j = 0; j < HDT_MAX; ++j) {
+        hd_early[0][j] = reinterpret_cast<const unsigned short*>(hdT)[(int64_t)(L0_ + min(j, L1_ - 1)) * P + p];
+        hd_early[1][j] = reinterpret_cast<const unsigned short*>(hdT)[(int64_t)(L0_ + L1_ + min(j, L2_ - 1)) * P + p];
+      }
+      asm volatile("" ::: "memory");  // (the requests stay up here: no memory operation may cross, and nothing here waits for them)
+    }
+#endif
 #pragma unroll
     for (int plane = 0; plane < 3; ++plane) {
       const int L = fd.hd[plane].n_levels;
       if (USE_HDT && plane > 0) {  // xz / yz: evaluated by dynhash_fwd_lds_kernel from LDS-resident slice tables
+#if ENC_HDT_EARLY
+        if (hdt_early) {
+#pragma unroll
+          for (int j = 0; j < HDT_MAX; ++j)
+            if (j < L) row[col + j] = __builtin_bit_cast(half_t, hd_early[plane - 1][j]);
+          col += L;
+          continue;
+        }
+#endif
         for (int lvl = 0; lvl < L; ++lvl) row[col + lvl] = hdT[(int64_t)(col - col_dyn0 + lvl) * P + p];
         col += L;
         continue;
