@@ -392,6 +392,13 @@ def compact_line(detail, args):
             if len(json.dumps(line)) <= LINE_LIMIT:
                 break
             line[k] = "see " + detail_ref
+        if len(json.dumps(line)) > LINE_LIMIT:  # config / roofline / cpu_baseline themselves are oversized: contract fields + pointer only
+            keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data")
+            line = {k: line[k] for k in keep if k in line}
+            line["config"] = {"workload": str(detail.get("config", {}).get("workload", ""))[:200]}
+            line["roofline"] = line["cpu_baseline"] = "see " + detail_ref
+            line["detail"] = detail_ref
     return line
 
 

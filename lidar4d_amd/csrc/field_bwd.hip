@@ -66,8 +66,9 @@ __device__ __forceinline__ void group_taps(const FieldDesc& fd, int s, const flo
 // -- 129 band passes x 196,608 segments x 2 sectors = 3.2 GB, most of what its counters showed above the compulsory bytes
 // (9.95 GB fetched for 3.62 GB, profiles/r03_pmc_rd.txt).  4.7 MB here, read densely.
 __device__ __forceinline__ void write_seg_bounds(float* __restrict__ segb, int64_t pr, int64_t P, int lane, const float4_t& c4) {
-  // lanes of a wave hold consecutive samples starting at a multiple of 64 (all callers); lanes past P carry the last valid sample
-  if (!segb || (lane != 0 && lane != 63) || pr - lane >= P) return;
+  // lanes of a wave hold consecutive samples starting at a multiple of 64 (callers whose chunks are not whole segments pass
+  // segb = nullptr, and a wave that does not start on a segment writes nothing); lanes past P carry the last valid sample
+  if (!segb || (lane != 0 && lane != 63) || pr - lane >= P || ((pr - lane) & 63) != 0) return;
   const int64_t n_seg = (P + 63) >> 6;
   int64_t seg = pr >> 6;
   asm volatile("" : "+v"(seg));  // (opaque per call: hoisted out of the caller's sample loop, the three 64-bit addresses cost a scratch slot there)
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 #endif
 #ifndef PDYN_THREADS
 #ifndef PDYN_PREFETCH
-#define PDYN_PREFETCH 0  // (experiment, not measured yet) time-plane kernel: the gradient row's 16-byte piece of the NEXT scale is requested while the current scale is worked on
+#define PDYN_PREFETCH 1  // measured 3.89 -> 3.67 ms (gpurun_out/s1, round 5; round 4: 3.94 -> 3.64): time-plane kernel: the gradient row's 16-byte piece of the NEXT scale is requested while the current scale is worked on
 #endif
 #define PDYN_THREADS 768  // 12 waves on the one workgroup a CU can hold (138 KB of LDS; 155 VGPRs allow 3 per SIMD): 3.00 -> 2.73 ms against 512
 #endif
@@ -936,7 +937,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       for (int j = 0; j < 3; ++j) lds += TFRAMES * d.planes.res[s][j] * 8 * 4;
     if (lds > 160 * 1024) { l4d_set_error(1, "l4d_density_encode_bwd: time planes exceed LDS"); return fail(1); }  // (checked above)
     const PlaneRows pr = make_plane_rows(d, plane_rows);
-    const PrepOut po{gvs, gdynT, xsoa, stats, segb};
+    const PrepOut po{gvs, gdynT, xsoa, stats, wave_skip ? segb : nullptr};  // (read only under wave_skip; chunks of another size do not start on segments)
     if (plane_rows) {
       L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, stream, d, pr, tinfo, plane_rows);
       if (fused_prep) {

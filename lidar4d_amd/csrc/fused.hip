@@ -79,12 +79,16 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 #ifndef ENC_HDT_EARLY
 #define ENC_HDT_EARLY 0
 #endif
-template <bool USE_HDT, bool ROWS, int PART = 0>
+// HSPRE: the static grid's columns come from the level-major pre-pass (hashgrid.hip hashgrid_fwd_levels_kernel, hsT[level][P][4]
+// fp16) instead of being gathered here: 8 bytes per level and sample, dense, and the kernel's own gathers (xy stack, planes) no
+// longer share the L2s with 33 MB of static tables.
+template <bool USE_HDT, bool ROWS, int PART = 0, bool HSPRE = false>
 __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
                                                                         const float* __restrict__ tinfo, int64_t P,
                                                                         const half_t* __restrict__ hdT,
-                                                                        half_t* __restrict__ X, int in_pad, PlaneRows prows) {
+                                                                        half_t* __restrict__ X, int in_pad, PlaneRows prows,
+                                                                        const half_t* __restrict__ hsT) {
   constexpr int C = 8;
   // the row is staged and written out in two parts (planes | everything else) so that the staging buffer is half as
   // large: LDS is what limits this kernel's occupancy (gather latency needs waves in flight)
@@ -153,7 +157,11 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
   // ---- static 3-D hash grid (hash_field.py:141-144) ----
   {
     const float xs[3] = {x0[0], x0[1], x0[2]};
-    for (int lvl = 0; lvl < fd.hs.n_levels; ++lvl) {
+    for (int lvl = 0; HSPRE && lvl < fd.hs.n_levels; ++lvl) {
+      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<u32x2_t*>(row + col + lvl * 4) = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(hsT) + (int64_t)lvl * P + p);
+    }
+    for (int lvl = 0; !HSPRE && lvl < fd.hs.n_levels; ++lvl) {
       float a[4];
       level_lookup<3, 4>(fd.hs_table + (size_t)fd.hs.offset[lvl] * 4, fd.hs.scale[lvl], fd.hs.res[lvl], fd.hs.size[lvl],
                          (fd.hs.hashed_mask >> lvl) & 1u, xs, a);
@@ -464,9 +472,22 @@ extern "C" int l4d_dyn_pairs_build(const void* const* slice_tables, int32_t n_sl
 }
 
 // hd_scratch of l4d_density_encode_fwd: the LDS kernel's output columns [n_dyn][P] fp16, then the coordinates [3][P] fp32 and flow vectors [6][P] fp16
-extern "C" int64_t l4d_density_encode_fwd_workspace(const l4d_field_desc* f, int64_t P) {
+// ... then (round 5) the static grid's level-major columns [n_levels][P][4] fp16
+static inline int64_t enc_ws_hs_offset(const l4d_field_desc* f, int64_t P) {
   const int64_t n_dyn = f->hash_dynamic[0].n_levels + f->hash_dynamic[1].n_levels + f->hash_dynamic[2].n_levels;
-  return (n_dyn * P * 2 + 255) / 256 * 256 + (3 * P * 4 + 255) / 256 * 256 + 6 * P * 2;
+  return (n_dyn * P * 2 + 255) / 256 * 256 + (3 * P * 4 + 255) / 256 * 256 + (6 * P * 2 + 255) / 256 * 256;
+}
+extern "C" int64_t l4d_density_encode_fwd_workspace(const l4d_field_desc* f, int64_t P) {
+  return enc_ws_hs_offset(f, P) + (int64_t)f->hash_static.n_levels * P * 8;
+}
+
+L4D_INTERNAL int l4d_hashgrid_levels_launch(const GridDesc* g, int n_dims, int n_features, const float* x, int64_t P, int x_stride,
+                                            const int* cols3, const void* table, void* lvlT, void* stream);
+// static grid through the level-major pre-pass (default; L4D_ENC_HS_SPLIT=0: gathered inside the encode kernel as in rounds 1-4)
+static int enc_hs_split() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("L4D_ENC_HS_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
 }
 
 extern "C" int64_t l4d_plane_rows_workspace(const l4d_field_desc* f) {
@@ -487,9 +508,13 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
   }
   hipStream_t main_s = (hipStream_t)stream;
   // side stream: the LDS evaluation of the xz / yz stacks runs next to the plane part of the encode (l4d_streams_config bit 0)
+  // static grid: level-major pre-pass into the workspace (needs the workspace, F = 4 and the one-kernel form of the encode);
+  // l4d_streams_config bit 2: that pre-pass (L2 gathers) runs NEXT TO the LDS kernel (VALU / LDS-bound) instead of behind it
+  const bool hs_pre = hd_scratch && plane_rows && !(l4d_streams_mask() & 1) && enc_hs_split() && f->hash_static.n_features == 4 && P >= ENC_SPLIT_MIN_POINTS;
+  const bool hs_side = hs_pre && (l4d_streams_mask() & 4);
   const bool split = hd_scratch && (l4d_streams_mask() & 1) && P >= ENC_SPLIT_MIN_POINTS;
   hipStream_t dh_s = main_s;
-  if (split) {
+  if (split || hs_side) {
     dh_s = (hipStream_t)l4d_side_fork(stream, 0);
     if (!dh_s) return 1;
   }
@@ -509,6 +534,13 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
     L4D_LAUNCH(dynhash_fwd_lds_kernel, dim3(n_chunks, d.hd[1].n_levels + d.hd[2].n_levels), dim3(DH_THREADS),
                2 * DH_MAX_ENTRIES * 8, dh_s, d, xs, flowT, tinfo, P, chunk, (half_t*)hd_scratch);
   }
+  half_t* hsT = hs_pre ? (half_t*)((char*)hd_scratch + enc_ws_hs_offset(f, P)) : nullptr;
+  if (hs_pre) {
+    const int cols3[3] = {0, 1, 2};
+    const int rc = l4d_hashgrid_levels_launch(&d.hs, 3, 4, xt, P, 4, cols3, d.hs_table, hsT, main_s);
+    if (hs_side && l4d_side_join(stream, 0)) return 1;  // (also on the error path: the launch stream is ordered behind the side stream again)
+    if (rc) return 1;
+  }
   const PlaneRows pr = make_plane_rows(d, plane_rows);
   if (plane_rows)  // tinfo[0..2] = t, t1, t2: frames without a neighbour get a row nobody reads
     L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, main_s, d, pr, tinfo, plane_rows);
@@ -517,8 +549,11 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
   const int enc_lds = ENC_THREADS * (std::max(colsA, in_pad - colsA) + 8) * 2;
 #define ENC_LAUNCH(HDT, ROWS, PART)                                                                                         \
   L4D_LAUNCH((density_encode_fwd_kernel<HDT, ROWS, PART>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,                \
-             (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr)
-  if (split) {  // plane columns while the side stream evaluates the xz / yz stacks, then the hash columns
+             (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr)
+  if (hs_pre) {
+    L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, true>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
+               (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT);
+  } else if (split) {  // plane columns while the side stream evaluates the xz / yz stacks, then the hash columns
     if (plane_rows) ENC_LAUNCH(true, true, 1);
     else ENC_LAUNCH(true, false, 1);
     if (l4d_side_join(stream, 0)) return 1;

@@ -85,23 +85,36 @@ template <> struct NtVec<2> { typedef uint32_t type; };
 template <> struct NtVec<4> { typedef u32x2_t type; };
 template <> struct NtVec<8> { typedef u32x4_t type; };
 
-// Level <-> XCD pinning.  A level's table (4 MB at 2^19 entries x 8 B) is as large as one XCD's L2, and all eight XCDs
-// read every table: measured (tools/ubench/gather.hip), a gather that misses L2 costs 4.6x one that hits (64 G vs 292 G
-// lane-loads/s chip-wide), and the fine levels miss nearly always.  The dispatcher places block b on XCD b % 8, so here
-// block b works on level (b % 8) + 8 k only: each XCD's L2 then holds ONE level's table at a time and the gathers hit it.
-// The coordinate stream is read with non-temporal loads (it must not evict the table), results go level-major to a
-// scratch array (coalesced 2F-byte stores) and a second, streaming kernel assembles the [P, L * F] rows.
-// (Placement is a performance assumption only: any block -> XCD map gives the same result.)
+// Level-major evaluation into a scratch array lvlT[level][P][F]; a second, streaming kernel (or the fused encode kernel)
+// assembles rows from it.  A level's table (4 MB at 2^19 entries x 8 B) is as large as one XCD's L2, and a gather costs one
+// 128-byte LINE at whichever boundary it crosses: 264 G lane-loads/s chip-wide = the L2's 34 TB/s when the line is L2-resident,
+// 65 G/s = the fabric's 8.3 TB/s when it comes from the Infinity Cache -- for 4, 8 and 16 bytes per lane and for every cache
+// policy alike (tools/ubench/gather_policy.hip, profiles/r05_ubench_gather_policy.txt).  With all levels evaluated per sample
+// (the row kernels, the fused encode) every L2 sees all tables and the fine levels miss nearly always.  Two block orders:
+//   ORDER 0 (rounds 2-4): level l on the workgroups that land on XCD l % 8 (the dispatcher places block b on XCD b % 8): each L2
+//     holds ONE table, but the levels run side by side and a fine level then has ONE XCD's gather rate (33 G/s) for all its
+//     samples -- the launch lasts as long as the finest level on an eighth of the chip;
+//   ORDER 1 (round 5): the levels one after the other, chip-wide: the workgroups in flight at any moment (2,048 of 49,152 per
+//     level) all read the SAME table, every L2 holds a copy of it, and every level has the whole chip's gather rate.
+// The coordinate stream is read with non-temporal loads (it must not evict the table), results go out as coalesced 2F-byte
+// non-temporal stores.  (Placement is a performance assumption only: any block -> XCD map gives the same result.)
 template <int D, int F>
-__global__ void __launch_bounds__(256) hashgrid_fwd_xcd_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
-                                                              Cols cols, const half_t* __restrict__ table, int64_t n_tiles,
-                                                              half_t* __restrict__ lvlT) {
-  const int xcd = blockIdx.x & 7;
-  const int64_t q = blockIdx.x >> 3;
-  const int li = (int)(q / n_tiles);
-  const int64_t tile = q - (int64_t)li * n_tiles;
-  const int lvl = xcd + 8 * li;
-  if (lvl >= desc.n_levels) return;
+__global__ void __launch_bounds__(256) hashgrid_fwd_levels_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
+                                                                 Cols cols, const half_t* __restrict__ table, int64_t n_tiles,
+                                                                 half_t* __restrict__ lvlT, int order) {
+  int lvl;
+  int64_t tile;
+  if (order == 0) {
+    const int xcd = blockIdx.x & 7;
+    const int64_t q = blockIdx.x >> 3;
+    const int li = (int)(q / n_tiles);
+    tile = q - (int64_t)li * n_tiles;
+    lvl = xcd + 8 * li;
+    if (lvl >= desc.n_levels) return;
+  } else {
+    lvl = (int)(blockIdx.x / n_tiles);
+    tile = blockIdx.x - (int64_t)lvl * n_tiles;
+  }
   const int64_t p = tile * blockDim.x + threadIdx.x;
   if (p >= P) return;
   float xin[D];
@@ -115,6 +128,37 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_xcd_kernel(GridDesc desc, co
   for (int f = 0; f < F; ++f) h[f] = f2h(acc[f]);
   typedef typename NtVec<F>::type V;
   __builtin_nontemporal_store(*reinterpret_cast<V*>(h), reinterpret_cast<V*>(lvlT + ((int64_t)lvl * P + p) * F));
+}
+
+// block order of the level-major kernel: L4D_HG_ORDER=0 restores the XCD-pinned order of rounds 2-4 (A/B; default 1)
+static int hg_order() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("L4D_HG_ORDER"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+
+// lvlT[level][P][F] <- grid (library-internal: also the first stage of l4d_density_encode_fwd's static-grid columns)
+L4D_INTERNAL int l4d_hashgrid_levels_launch(const GridDesc* g, int n_dims, int n_features, const float* x, int64_t P, int x_stride,
+                                            const int* cols3, const void* table, void* lvlT, void* stream) {
+  Cols c;
+  for (int d = 0; d < 3; ++d) c.c[d] = d < n_dims ? cols3[d] : 0;
+  const int64_t n_tiles = ceil_div64(P, 256);
+  const int order = hg_order();
+  const int64_t n_blocks = order == 0 ? n_tiles * ((g->n_levels + 7) / 8) * 8 : n_tiles * g->n_levels;
+  if (n_blocks > 0x7fffffffLL) { l4d_set_error(1, "hashgrid levels: too many workgroups"); return 1; }
+  dim3 grid((unsigned)n_blocks), block(256);
+#define CALL(D, F)                                                                                                             \
+  L4D_LAUNCH((hashgrid_fwd_levels_kernel<D, F>), grid, block, 0, (hipStream_t)stream, *g, x, P, x_stride, c, (const half_t*)table, \
+             n_tiles, (half_t*)lvlT, order);
+  if (n_dims == 2 && n_features == 2) { CALL(2, 2) }
+  else if (n_dims == 2 && n_features == 4) { CALL(2, 4) }
+  else if (n_dims == 2 && n_features == 8) { CALL(2, 8) }
+  else if (n_dims == 3 && n_features == 2) { CALL(3, 2) }
+  else if (n_dims == 3 && n_features == 4) { CALL(3, 4) }
+  else if (n_dims == 3 && n_features == 8) { CALL(3, 8) }
+  else { l4d_set_error(1, "hashgrid: unsupported n_dims/n_features"); return 1; }
+#undef CALL
+  return 0;
 }
 
 // rows [P, out_stride] <- level-major lvlT [L][P][F]; one thread per point, row staged in LDS, coalesced 16-byte stores
@@ -335,15 +379,7 @@ extern "C" int l4d_hashgrid_fwd_ws(const l4d_grid_desc* desc, const float* x, in
   if (!workspace || width % 8 || out_stride % 8 || ((uintptr_t)out & 15) || (desc->n_features != 4 && desc->n_features != 8 && desc->n_features != 2))
     return l4d_hashgrid_fwd(desc, x, P, x_stride, cols, table, out, out_stride, stream);
   GridDesc g = make_grid_desc(desc);
-  Cols c = make_cols(cols, desc->n_dims);
-  const int64_t n_tiles = ceil_div64(P, 256);
-  const int rounds = (desc->n_levels + 7) / 8;
-  dim3 grid((unsigned)(n_tiles * rounds * 8)), block(256);
-#define CALL(D, F)                                                                                                        \
-  L4D_LAUNCH((hashgrid_fwd_xcd_kernel<D, F>), grid, block, 0, (hipStream_t)stream, g, x, P, x_stride, c, (const half_t*)table, \
-             n_tiles, (half_t*)workspace);
-  DISPATCH_DF(desc->n_dims, desc->n_features, CALL)
-#undef CALL
+  if (l4d_hashgrid_levels_launch(&g, desc->n_dims, desc->n_features, x, P, x_stride, cols, table, workspace, stream)) return 1;
   const int lds = HG_ROWS_THREADS * (width + 8) * 2;
   dim3 rgrid((unsigned)ceil_div64(P, HG_ROWS_THREADS)), rblock(HG_ROWS_THREADS);
   if (desc->n_features == 2)

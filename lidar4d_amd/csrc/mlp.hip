@@ -109,6 +109,7 @@ __device__ __forceinline__ h8 relu_pack(const f4& lo, const f4& hi) {
 // val where act > 0, else 0, on packed halfs: act holds ReLU outputs (relu_pack: +0 or positive, never -0), so "positive" is
 // "bit pattern non-zero": mask = min(bits, 1) * 0xFFFF per 16-bit half (v_pk_min_u16, v_pk_mul_lo_u16), then one AND per pair --
 // three packed instructions per pair instead of two compares + two selects.
+static_assert(!(MLP_MASK_PK && MLP_RELU_PK), "keep_where_pos needs activations that are never -0; relu_pack (v_pk_max_f16) can produce -0");
 __device__ __forceinline__ h8 keep_where_pos(h8 val, h8 act) {
   typedef unsigned short us8v __attribute__((ext_vector_type(8)));
   const us8v one = 1, ones = 0xFFFF;

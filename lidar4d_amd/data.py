@@ -157,7 +157,9 @@ class SyntheticKitti360:
     def batch_for(self, frame):
         pose = self.poses[frame:frame + 1]
         t = self.times[frame]
-        if self.fused_batch and torch.device(self.device).type == "cuda" and self.patch_size_lidar == 1 and not self.sort_pixels:
+        # (num_rays <= 0 = "every pixel of the frame" in get_lidar_rays, kitti360_dataset.py:150-180: that case takes the torch path)
+        if (self.fused_batch and self.num_rays > 0 and torch.device(self.device).type == "cuda" and self.patch_size_lidar == 1
+                and not self.sort_pixels):
             # the two draws of get_lidar_rays (same generator consumption), then ONE launch for pixel index, direction,
             # rotation, origin and the ground-truth gather (csrc/glue.hip: 33 torch launches otherwise)
             from . import ops

@@ -135,3 +135,29 @@ def test_fused_flow_loss_equals_torch_path():
             assert float(a.abs().max()) > 0 and err <= 2e-2, (frame, n, err)  # fp16 adjoints: a different power of two may be chosen
             l2 = float((a - b).norm() / a.norm())
             assert l2 <= 5e-3, (frame, n, l2)
+
+
+@pytest.mark.parametrize("tag", ["default", "flow_mid", "flow_first", "flow_last", "urf", "crit_huber_bce_l1", "patch_l1", "everything"])
+def test_training_losses_vs_reference_train_step_on_device(tag):
+    """The reference's own train_step loss block (tests/golden/train_step_losses.npz, oracle/make_golden_train.py) against
+    lidar4d_amd.trainer's terms on the device: the chamfer terms through the HIP kernel (csrc/chamfer.hip) instead of the
+    oracle's brute force the fixture was generated with -- value and every gradient."""
+    from tests import train_golden
+    c = train_golden.load(tag)
+    loss, leaves = train_golden.evaluate(c, device=DEV)
+    train_golden.check(c, loss, leaves, rtol=1e-4)
+
+
+def test_fused_primary_losses_vs_reference_train_step():
+    """The fused primary-loss node (l4d_lidar_losses + l4d_chamfer_fwd + l4d_ray_chamfer_grad: what the benchmarked step runs)
+    against the reference's train_step on the default criteria: loss value, d loss / d depth, d loss / d image."""
+    from lidar4d_amd.trainer import primary_losses
+    from tests import train_golden
+    c = train_golden.load("default")
+    o = train_golden.opt_of(c)
+    depth = c["depth"].to(DEV).requires_grad_(True)
+    image = c["image"].to(DEV).requires_grad_(True)
+    data = {"images_lidar": c["images"].to(DEV), "rays_d_lidar": c["rays_d"].to(DEV)}
+    loss = primary_losses({"depth_lidar": depth, "image_lidar": image}, data, float(o["scale"]), chamfer=True, world=1,
+                          alpha_d=o["alpha_d"], alpha_r=o["alpha_r"], alpha_i=o["alpha_i"], smooth=o["smooth_factor"])
+    train_golden.check(c, loss, {"g_depth": depth, "g_image": image}, rtol=1e-4)

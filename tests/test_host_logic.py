@@ -185,73 +185,46 @@ def test_raydrop_meter_formulas():
     assert m.N == 0 and m.V == []
 
 
-def test_urf_loss_formula():
-    """trainer.urf_loss against a literal transcription of runner.py:255-276 (pure torch: runs anywhere)."""
-    from lidar4d_amd.trainer import urf_loss
-    g = torch.Generator().manual_seed(5)
-    n, T = 12, 40
-    z = torch.sort(torch.rand(n, T, generator=g) * 0.8 + 0.01, dim=1).values
-    w = torch.rand(n, T, generator=g, dtype=torch.float32).requires_grad_(True)
-    depth = torch.rand(1, n, generator=g) * 0.8
-    depth[0, :3] = 0.0  # dropped rays
-    for step, iters in ((0, 100), (50, 100), (500, 100)):
-        eps = 0.02 * 0.1 ** min(step / iters, 1)
-        d = depth.reshape(n, 1)
-        depth_mask = d > 0.0
-        mask_empty = (z < (d - eps)) | (z > (d + eps))
-        loss_empty = ((mask_empty * w) ** 2).sum() / depth_mask.sum()
-        mask_near = (z > (d - eps)) & (z < (d + eps))
-        distance = mask_near * (z - d)
-        sigma = eps / 3.0
-        distr = 1.0 / (sigma * np.sqrt(2 * np.pi)) * torch.exp(-(distance ** 2 / (2 * sigma ** 2)))
-        distr = distr / distr.max()
-        distr = distr * mask_near
-        loss_near = ((mask_near * w - distr) ** 2).sum() / depth_mask.sum()
-        want = 0.1 * loss_empty + 0.1 * loss_near
-        got = urf_loss({"weights": w, "z_vals": z}, depth, step, iters)
-        assert torch.allclose(got, want, rtol=1e-6), (float(got), float(want))
-    got.backward()
-    assert w.grad is not None and torch.isfinite(w.grad).all()
+class _OracleChamfer:
+    """chamfer_3DDist stand-in for CPU tests: the oracle's brute force (the product's operator is HIP-only)."""
+
+    def __call__(self, a, b):
+        from oracle import chamfer_ref
+        return chamfer_ref.chamfer(a, b)
 
 
-@pytest.mark.parametrize("sobel,kind", [(False, "l1"), (True, "l1"), (False, "mse"), (False, "cos")])
-def test_depth_grad_loss_formula(sobel, kind):
-    """trainer.depth_grad_loss against a literal transcription of runner.py:277-367 (pure torch)."""
-    import torch.nn.functional as F
-    from lidar4d_amd.trainer import depth_grad_loss
-    g = torch.Generator().manual_seed(9)
-    px, py, n_patch, scale = 2, 8, 6, 0.0105
-    n = n_patch * px * py
-    gt_raydrop = (torch.rand(1, n, generator=g) > 0.2).float()
-    gt_depth = (0.3 + 0.002 * torch.arange(n).float().view(1, n) % 0.05 + 0.01 * torch.rand(1, n, generator=g)) * scale * 30 * gt_raydrop
-    pred_depth = ((gt_depth + 0.001 * torch.randn(1, n, generator=g)) * gt_raydrop).requires_grad_(True)
-    # --- transcription
-    pd = pred_depth.view(-1, px, py, 1).permute(0, 3, 1, 2).contiguous() / scale
-    kx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=torch.float32).unsqueeze(0).unsqueeze(0)
-    ky = torch.tensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], dtype=torch.float32).unsqueeze(0).unsqueeze(0)
-    if sobel:
-        pgx, pgy = F.conv2d(pd, kx, padding=1), F.conv2d(pd, ky, padding=1)
-    else:
-        pgy = torch.abs(pd[:, :, :-1, :] - pd[:, :, 1:, :])
-        pgx = torch.abs(pd[:, :, :, :-1] - pd[:, :, :, 1:])
-    dy, dx = torch.abs(pgy), torch.abs(pgx)
-    want = 0.1 * (torch.mean(dx) + torch.mean(dy))  # tv term switched on below
-    gd = gt_depth.view(-1, px, py, 1).permute(0, 3, 1, 2).contiguous() / scale
-    gr = gt_raydrop.view(-1, px, py, 1).permute(0, 3, 1, 2).contiguous()
-    ggx = F.conv2d(gd, kx, padding=1) if sobel else gd[:, :, :, :-1] - gd[:, :, :, 1:]
-    mask_x = torch.where(torch.abs(ggx) < 0.01, 1, 0)
-    mask_dx = gr * mask_x if sobel else gr[:, :, :, :-1] * mask_x
-    crit = {"l1": torch.nn.L1Loss(reduction="none"), "mse": torch.nn.MSELoss(reduction="none"), "cos": torch.nn.CosineSimilarity()}[kind]
-    if kind == "cos":
-        gl = 1 - crit((pgx * mask_dx).reshape(n_patch, -1), (ggx * mask_dx).reshape(n_patch, -1))
-    else:
-        gl = crit(pgx * mask_dx, ggx * mask_dx)
-    want = want + 0.1 * gl.sum()
-    got = depth_grad_loss(pred_depth, gt_depth, gt_raydrop, [px, py], scale, kind=kind, sobel_grad=sobel, tv_loss=True)
-    assert torch.allclose(got, want, rtol=1e-5, atol=1e-7), (float(got), float(want))
-    got.backward()
-    assert torch.isfinite(pred_depth.grad).all()
-    assert float(depth_grad_loss(pred_depth, gt_depth, gt_raydrop, 1, scale)) == 0.0
+def _train_cases():
+    from tests import train_golden
+    return train_golden.cases()
+
+
+@pytest.mark.parametrize("tag", ["default", "flow_mid", "flow_first", "flow_last", "urf", "crit_huber_bce_l1", "crit_mse_l1_huber", "patch_l1",
+                                 "patch_sobel_cos_all", "patch_mse_tv", "everything"])
+def test_training_losses_vs_reference_train_step(tag, monkeypatch):
+    """lidar4d_amd.trainer's loss terms against the loss block of the REFERENCE's own Trainer.train_step
+    (model/runner.py:179-367, run by oracle/make_golden_train.py on seeded tensors): value and d(loss) / d(every render and flow
+    output), for the default criteria, the other criterion choices of main_lidar4d.py:183-196, the scene-flow term at a middle /
+    first / last frame, the line-of-sight term and the patch-gradient terms with all their switches."""
+    from tests import train_golden
+    import lidar4d_amd.chamfer as chamfer_mod
+    assert tag in train_golden.cases()
+    monkeypatch.setattr(chamfer_mod, "chamfer_3DDist", _OracleChamfer)
+    c = train_golden.load(tag)
+    assert bool(c["render_perturb"]) and not bool(c["render_staged"])  # what the training render call must pass (runner.py:183-191)
+    loss, leaves = train_golden.evaluate(c)
+    train_golden.check(c, loss, leaves)
+
+
+@pytest.mark.parametrize("tag", ["default", "flow_mid", "flow_first", "flow_last", "urf", "crit_huber_bce_l1", "patch_l1"])
+def test_trainer_compute_loss_vs_reference_train_step(tag, monkeypatch):
+    """The same fixture through Trainer.compute_loss (how the terms are COMBINED: which are on, the frame index, the ground
+    points' random time, the 1 / world factors at world = 1), for the option sets compute_loss exposes."""
+    from tests import train_golden
+    import lidar4d_amd.chamfer as chamfer_mod
+    monkeypatch.setattr(chamfer_mod, "chamfer_3DDist", _OracleChamfer)
+    c = train_golden.load(tag)
+    loss, leaves = train_golden.evaluate(c, compute_loss=True)
+    train_golden.check(c, loss, leaves)
 
 
 def test_flat_ema_matches_torch_ema_rule():
@@ -550,26 +523,11 @@ def test_frame_index_is_the_fp32_product_of_the_reference():
     assert wrong64 > 20  # what the float64 evaluation would have got wrong
 
 
-def test_lidar_loss_criteria_match_the_reference_table():
-    """main_lidar4d.py:183-196: the criterion dict {l1, mse, bce (with logits), huber (delta 0.2 * scale)}, reduction none, as
-    runner.py:199-213 combines them (ray-drop prediction through a sigmoid first when its loss is bce)."""
+def test_lidar_loss_rejects_unknown_criteria():
     from lidar4d_amd.trainer import lidar_loss
-    g = torch.Generator().manual_seed(5)
-    n, scale = 64, 0.0105
-    img = torch.rand(1, n, 3, generator=g)
-    img[..., 0] = (img[..., 0] > 0.3).float()
-    out = {"image_lidar": torch.rand(1, n, 2, generator=g), "depth_lidar": torch.rand(1, n, generator=g)}
-    table = {"l1": torch.nn.L1Loss(reduction="none"), "mse": torch.nn.MSELoss(reduction="none"),
-             "bce": torch.nn.BCEWithLogitsLoss(reduction="none"), "huber": torch.nn.HuberLoss(reduction="none", delta=0.2 * scale)}
-    for kd, kr, ki in (("l1", "mse", "mse"), ("huber", "bce", "l1"), ("mse", "l1", "huber"), ("bce", "huber", "bce")):
-        gt_r = img[:, :, 0]
-        pr = torch.sigmoid(out["image_lidar"][:, :, 0]) if kr == "bce" else out["image_lidar"][:, :, 0]
-        want = (1.0 * table[kd](out["depth_lidar"] * gt_r, img[:, :, 2] * gt_r) + 0.01 * table[kr](pr, gt_r.clamp(0.2, 0.8)) +
-                0.1 * table[ki](out["image_lidar"][:, :, 1] * gt_r, img[:, :, 1] * gt_r)).sum()
-        got = lidar_loss(out, img, depth_loss=kd, raydrop_loss=kr, intensity_loss=ki, scale=scale)
-        assert torch.allclose(got, want, rtol=1e-6), (kd, kr, ki)
+    out = {"image_lidar": torch.rand(1, 4, 2), "depth_lidar": torch.rand(1, 4)}
     with pytest.raises(ValueError):
-        lidar_loss(out, img, depth_loss="l3")
+        lidar_loss(out, torch.rand(1, 4, 3), depth_loss="l3")
 
 
 def test_flat_adam_ranges_partition_the_arena():
