@@ -38,36 +38,12 @@
 #include "wave_dev.h"
 #include "binscatter.h"
 
-#ifndef BS_THREADS
 #define BS_THREADS 512
-#endif
-#ifndef BS_MAX_BINS
 #define BS_MAX_BINS 256
-#endif
-#ifndef BS_GROUP
 #define BS_GROUP 8
-#endif
-#ifndef BS_XCD_BINS
 #define BS_XCD_BINS 1
-#endif
-#ifndef BS_UNROLL
 #define BS_UNROLL 4
-#endif
-#ifndef BS_P1_UPPER
-#define BS_P1_UPPER 0       // pass 1: wave-uniform skip of the split slots' ranking / staging code -- measured SLOWER (2.21 -> 2.39 ms, gpurun_out/r4h)
-#endif
-#ifndef BS_P1_MERGE_TEST
-#define BS_P1_MERGE_TEST 0  // pass 1: cheap first / last lane test in front of the run detection -- measured neutral (2.21 -> 2.20 ms)
-#endif
-#ifndef BS_P1_WAVESCAN
-#define BS_P1_WAVESCAN 0  // (experiment, not measured yet) pass 1: every wavefront scans the bin totals itself -- two barriers per level instead of three, no single-wavefront phase
-#endif
-#ifndef BS_P2_PIPELINE
-#define BS_P2_PIPELINE 1  // flattened pass 2: request the next window of records before the current one is accumulated
-#endif
-#ifndef BS_MIN_WAVES
 #define BS_MIN_WAVES 4  // pass 1: wavefronts per SIMD the register allocation must leave room for (128 registers)
-#endif
 
 template <int NV>
 struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
@@ -95,11 +71,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // wave-level atomic meets 2-4 equal addresses, and the prefix pass, its barrier and 7/8 of the zeroing were pure overhead per
   // level.)  The order of the records inside a run now depends on atomic arrival; pass 2 sums in integers, so nothing downstream
   // depends on it.
-#if BS_P1_WAVESCAN
-  __shared__ uint32_t hist2[2][BS_MAX_BINS], boffw[BS_THREADS / 64][BS_MAX_BINS];  // two histograms in turn, one offset table per wavefront
-#else
   __shared__ uint32_t hist[BS_MAX_BINS], boff[BS_MAX_BINS + 1];
-#endif
   // typically NC / 2 records per lane: NC / 2 pair records, or NC single records per run with <= 32 runs per wave
   constexpr uint32_t CAP = BS_THREADS * NC;  // records per (workgroup, level) slot: every pair of every lane may have to be split
   __shared__ __attribute__((aligned(16))) uint32_t stage[CAP * NW];
@@ -148,12 +120,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   if (g_in_regs) gw_load(0);
   auto gw_pick = [&](int k) -> uint32_t { return gw[k & (GW - 1)]; };
   half_t gnext[NV];
-#if BS_P1_WAVESCAN
-  for (int i = threadIdx.x; i < 2 * BS_MAX_BINS; i += BS_THREADS) (&hist2[0][0])[i] = 0;
-  int hb = 0;  // histogram of the current binned level (block-uniform)
-#else
   for (int i = threadIdx.x; i < BS_MAX_BINS; i += BS_THREADS) hist[i] = 0;
-#endif
   if (threadIdx.x < L4D_MAX_LEVELS) lmax_s[threadIdx.x] = 0u;
   __syncthreads();
   // The level loop exists twice (a generic lambda over GREG = "gradient dwords in the register window"): the loads of the other
@@ -234,17 +201,6 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // detection below (three DPP compares, a ballot, the run bookkeeping: ~45 instructions) is skipped when the first and the last
   // lane are more than 48 cells apart along some axis; a heuristic about WORK only, the pair path is always correct)
   bool try_merge = binned && wave_any;
-#if BS_P1_MERGE_TEST
-  if (try_merge) {
-    uint32_t span = 0u;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int c0l = __builtin_amdgcn_readlane((int)c.cell[d], 0), c63 = __builtin_amdgcn_readlane((int)c.cell[d], 63);
-      span = max(span, (uint32_t)abs(c63 - c0l));
-    }
-    try_merge = span <= 48u;
-  }
-#endif
   if (try_merge) {
     bool same = true;  // same cell as the previous lane (the first lane of a row never is: old = ~cell, bound_ctrl off)
 #pragma unroll
@@ -337,19 +293,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // In pair mode the upper half of the slots only holds the second halves of pairs that straddle two bins (one pair in 2^shift):
   // a wavefront without one skips their ranking and staging code altogether (wave-uniform branch instead of exec-masked no-ops).
   bool upper = true;
-#if BS_P1_UPPER
-  if (pairs) {
-    bool any_split = false;
-#pragma unroll
-    for (int q = 0; q < NC / 2; ++q) any_split |= emit[q + NC / 2];
-    upper = __any(any_split);
-  }
-#endif
   // rank inside the workgroup
-#if BS_P1_WAVESCAN
-  uint32_t* hist = hist2[hb];
-  uint32_t* boff = boffw[threadIdx.x >> 6];
-#endif
 #pragma unroll
   for (int k = 0; k < NC / 2; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   if (upper) {
@@ -357,27 +301,15 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     for (int k = NC / 2; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   }
   __syncthreads();
-#if BS_P1_WAVESCAN
-  // EVERY wavefront scans the 256 totals (4 LDS reads, 6 DPP adds, 4 LDS writes into its own offset table): no barrier between the
-  // scan and the staging, no phase in which fifteen wavefronts wait for one.  The first wavefront also stores the offsets for
-  // pass 2 and clears the OTHER histogram -- last read a level ago, next ranked into behind this level's second barrier.
-  const bool scan_io = threadIdx.x < 64;
-  {
-#else
   const bool scan_io = true;
   if (threadIdx.x < 64) {  // exclusive scan of the bin totals by one wave: BPL consecutive bins per lane
-#endif
     constexpr int BPL = BS_MAX_BINS / 64;
     uint32_t c[BPL], sum = 0;
 #pragma unroll
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
       c[q] = b < nbins ? hist[b] : 0u;
-#if BS_P1_WAVESCAN
-      if (scan_io) hist2[hb ^ 1][b] = 0u;
-#else
       if (b < nbins) hist[b] = 0u;  // ready for the next level (every rank of this level has been handed out: barrier above)
-#endif
       sum += c[q];
     }
     // inclusive prefix over the wavefront with DPP (row scan, then the row totals carried upwards: six VALU instructions; as in
@@ -416,17 +348,11 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     }
     if (scan_io && lane == 63) {
       total_s = inc;
-#if !BS_P1_WAVESCAN
       boff[BS_MAX_BINS] = inc;
-#endif
       if (nbins == BS_MAX_BINS) *(GlobalU16*)(o + (uint32_t)BS_MAX_BINS * nwg32 * 2u) = (uint16_t)inc;
     }
   }
-#if BS_P1_WAVESCAN
-  hb ^= 1;
-#else
   __syncthreads();
-#endif
   auto stage_slot = [&](int k) {
     if (emit[k]) {
       const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
@@ -715,7 +641,6 @@ __global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int
     q0 += 64u;
     return true;
   };
-#if BS_P2_PIPELINE
   // Two windows in flight: the records of window n + 1 are requested before window n is accumulated (~100 VALU instructions and up
   // to 2 NV LDS atomics per record), two register sets in turn so that no copy waits for a load.  (One window at a time, every
   // wavefront sat out a full memory latency per 64 records: 1.86 ms against an issue floor of 1.0, profiles/r04_floor_table.md.)
@@ -734,14 +659,6 @@ __global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int
     more = fetch(rec_a, ok_a);
     if (ok_b) add(rec_b);
   }
-#else
-  {
-    RecVec rec_a = {};
-    bool ok_a;
-    while (fetch(rec_a, ok_a))
-      if (ok_a) add(rec_a);
-  }
-#endif
   __syncthreads();
   const double inv = (double)out_scale / (double)fxs;
   float* o = out + ((size_t)desc.offset[lvl] + lo) * NV;

@@ -203,24 +203,9 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 // same two texels -- 144 instead of 480 texel loads per sample in a kernel that is bound by their latency.
 #define TFRAMES 3
 // lanes a run of equal texels is merged over before the LDS atomics (16 = a whole DPP row: 4 scan steps per value; 8: 3 steps)
-#ifndef PDYN_MERGE
 #define PDYN_MERGE 16
-#endif
-#ifndef PDYN_FMA
-#define PDYN_FMA 1  // measured: 4.12 -> 3.97 ms (gpurun_out/r4a)
-#endif
-#ifndef PDYN_PK
-#define PDYN_PK 0  // per-channel arithmetic as packed fp32 pairs: 19 % fewer instructions in the scale loop, measured 3.91 -> 4.04 ms
-#endif             // (gpurun_out/r4e, r4f): v_pk_* fp32 issues at half rate here and brings hazard s_nops; kept as a knob
-#ifndef PSTAT_MERGE
 #define PSTAT_MERGE 16
-#endif
-#ifndef PDYN_THREADS
-#ifndef PDYN_PREFETCH
-#define PDYN_PREFETCH 1  // measured 3.89 -> 3.67 ms (gpurun_out/s1, round 5; round 4: 3.94 -> 3.64): time-plane kernel: the gradient row's 16-byte piece of the NEXT scale is requested while the current scale is worked on
-#endif
 #define PDYN_THREADS 768  // 12 waves on the one workgroup a CU can hold (138 KB of LDS; 155 VGPRs allow 3 per SIMD): 3.00 -> 2.73 ms against 512
-#endif
 // PREP: the kernel also does the prep kernel's work for its samples -- static planes' product-rule factors gvs, the transposed
 // dynamic-hash gradient gdynT, the SoA coordinates, the statistics of both -- while the sample's dX row and coordinates are in
 // registers anyway: one pass over dX instead of two, one launch less, and the plane gathers of that part (texel-bandwidth-bound)
@@ -239,12 +224,10 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
                                                             int64_t P, int64_t chunk, const half_t* __restrict__ dX,
                                                             int in_pad, float pscale, const float* __restrict__ stats,
                                                             half_t* __restrict__ dflow16, PlaneRows prows, PrepOut po) {
-#if PDYN_FMA
   // value arithmetic of THIS function body may contract a * b + c into one fma (texel interpolation, the coordinate adjoint's dot
   // products): gradient values move in their last bit; cell / texel indices come from axis_tap (planes_dev.h), which is
   // compiled under the file-wide -ffp-contract=off and still rounds like the forward pass
 #pragma clang fp contract(fast)
-#endif
   constexpr int C = 8;
   extern __shared__ int lds_i[];
   const int nS = fd.planes.n_scales;
@@ -290,7 +273,6 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
     }
     const half_t* row = dX + p * in_pad;
-#if PDYN_PREFETCH
     // pieces 0 .. nS-1: the static planes' gradient columns, nS .. 2 nS - 1: the time planes' (contiguous in the row)
     typedef uint32_t U4 __attribute__((ext_vector_type(4)));
     U4 piece_next;
@@ -301,7 +283,6 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       __builtin_memcpy(&piece_next, row + min(k + 1, 2 * nS - 1) * C, 16);
       return cur;
     };
-#endif
     if (PREP) {
       const int lane = __lane_id();
       if (active) {
@@ -315,11 +296,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       for (int s = 0; s < nS; ++s) {  // static planes: gradient of plane j = dX_s * (product of the other two planes' values)
         float gs[C];
         {
-#if PDYN_PREFETCH
           const U4 u = next_piece(s);
-#else
-          const uint4 u = *reinterpret_cast<const uint4*>(row + s * C);
-#endif
           const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
           for (int k = 0; k < C; ++k) gs[k] = active ? h2f(h[k]) : 0.0f;
@@ -386,11 +363,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
     for (int s = 0; s < nS; ++s) {
       float gd[C];
       {
-#if PDYN_PREFETCH
         const U4 u = next_piece(nS + s);
-#else
-        uint4 u = *reinterpret_cast<const uint4*>(row + (nS + s) * C);
-#endif
         const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
         for (int k = 0; k < C; ++k) gd[k] = active ? h2f(h[k]) : 0.0f;
@@ -406,14 +379,6 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
         float dv[3][C];  // ROWS: row[x1] - row[x0] per channel (d value / d ix)
         (void)dv;
         int cis[3];
-#if PDYN_PK
-        // Packed fp32 (v_pk_mul / v_pk_fma / v_pk_add: two channels per instruction at the issue cost of one).  A wave64 VALU
-        // instruction occupies its SIMD for ~4 cycles whatever it computes (SQ_INSTS_VALU x 4.35 cycles = this kernel's
-        // SQ_ACTIVE_INST_VALU), and two thirds of this kernel's instructions are per-channel multiplies and adds.
-        float2_t v2[3][C / 2], dv2[3][C / 2], cg2[C / 2];
-#pragma unroll
-        for (int k2 = 0; k2 < C / 2; ++k2) cg2[k2] = float2_t{gd[2 * k2], gd[2 * k2 + 1]} * coef;
-#endif
         if (ROWS) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
@@ -425,60 +390,28 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
 #pragma unroll
             for (int q = 0; q < C / 4; ++q) {
               const float4_t a = p0[q], c = p1[q];
-#if PDYN_PK
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                const float2_t a2 = {a[2 * h], a[2 * h + 1]}, c2 = {c[2 * h], c[2 * h + 1]};
-                v2[j][q * 2 + h] = a2 * taps[j].wx0 + c2 * taps[j].wx1;
-                dv2[j][q * 2 + h] = c2 - a2;
-              }
-#else
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
                 v[j][q * 4 + k] = a[k] * taps[j].wx0 + c[k] * taps[j].wx1;
                 dv[j][q * 4 + k] = c[k] - a[k];
               }
-#endif
             }
           }
         } else {
           group_taps<C>(fd, s, xe, true, taps, v, cis);
-#if PDYN_PK
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int k2 = 0; k2 < C / 2; ++k2) v2[j][k2] = float2_t{v[j][2 * k2], v[j][2 * k2 + 1]};
-#endif
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const Tap& t = taps[j];
           const int W = fd.planes.res[s][j];
           float gv[C];
-#if PDYN_PK
-          float2_t gv2[C / 2];
-#pragma unroll
-          for (int k2 = 0; k2 < C / 2; ++k2) {
-            gv2[k2] = cg2[k2] * v2[(j + 1) % 3][k2] * v2[(j + 2) % 3][k2];
-            gv[2 * k2] = gv2[k2][0];
-            gv[2 * k2 + 1] = gv2[k2][1];
-          }
-#else
 #pragma unroll
           for (int k = 0; k < C; ++k) gv[k] = coef * gd[k] * v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
-#endif
           if (e > 0) {  // coordinate adjoint of the warped lookups (time plane j pairs spatial axis j with t)
             float gix = 0.0f, giy = 0.0f;
             if (ROWS) {
-#if PDYN_PK
-              float2_t g2 = dv2[j][0] * gv2[0];
-#pragma unroll
-              for (int k2 = 1; k2 < C / 2; ++k2) g2 = dv2[j][k2] * gv2[k2] + g2;
-              gix = g2[0] + g2[1];
-#else
 #pragma unroll
               for (int k = 0; k < C; ++k) gix += dv[j][k] * gv[k];
-#endif
             } else {
               TapVals<C> tv;
               float dummy[C];
@@ -494,17 +427,8 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
             const int xq = qx == 0 ? t.x0 : t.x1;
             const float wxf = (qx == 0 ? t.wx0 : t.wx1) * fxs;
             float vals[C];
-#if PDYN_PK
-#pragma unroll
-            for (int k2 = 0; k2 < C / 2; ++k2) {
-              const float2_t vv = gv2[k2] * wxf;
-              vals[2 * k2] = vv[0];
-              vals[2 * k2 + 1] = vv[1];
-            }
-#else
 #pragma unroll
             for (int k = 0; k < C; ++k) vals[k] = gv[k] * wxf;
-#endif
             row_scan<C, PDYN_MERGE>(runs, vals);
             if (!runs.tail) continue;  // (inactive lanes carry zeros and a valid clamped key: harmless in any run)
             // (For a given k the lanes of an atomic -- run tails at different texels -- share the four banks = k (mod 8).  Rotating
@@ -512,12 +436,8 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
             // offset is two more VALU instructions per atomic in a kernel that is bound by exactly those, while a constant k rides
             // in the instruction's offset field.)
             int* dst = acc + xq * C;
-#ifndef ABL_NO_LDS_ATOMICS
 #pragma unroll
             for (int k = 0; k < C; ++k) atomicAdd(dst + k, fx_round(vals[k]));
-#else
-            asm volatile("" ::"v"(dst), "v"(vals[0]), "v"(vals[7]));
-#endif
           }
         }
       }
@@ -696,9 +616,7 @@ struct HashTasks {
   int hoff[MAX_TASKS];  // offset of (plane, level) in Hbuf
 };
 
-#ifndef DH_UNROLL
 #define DH_UNROLL 4  // samples per lane whose loads are in flight together (1 = the earlier load -> use chain)
-#endif
 // xt here: the [3][P] coordinate arrays the prep kernel wrote (xsoa)
 __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTasks tasks, const float* __restrict__ xt, int64_t P,
                                                          int64_t chunk, const half_t* __restrict__ gdynT,
@@ -968,9 +886,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     for (int s = 0; s < d.planes.n_scales; ++s)
       for (int j = 0; j < 3; ++j) {
         const int W = d.planes.res[s][CA[j]], H = d.planes.res[s][CB[j]];
-#ifndef PLANES_BAND_KB
 #define PLANES_BAND_KB 64  // two workgroups per CU: measured 2.37 -> 2.07 ms against 128 KB bands (32 KB: 2.80)
-#endif
         int rows = std::max(1, (PLANES_BAND_KB * 1024) / (W * 8 * 4));
         rows = std::min(rows, H);
         for (int r0 = 0; r0 < H; r0 += rows) {
@@ -987,9 +903,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   // dynamic hash
   {
     int hoff = 0, hoff_plane[3];
-#ifndef DYNHASH_LDS_KB
 #define DYNHASH_LDS_KB 64  // two workgroups per CU: measured 2.10 -> 1.85 ms against 128 KB parts
-#endif
     for (int p = 0; p < 3; ++p) {
       hoff_plane[p] = hoff;
       hoff += (int)(d.hd[p].offset[d.hd[p].n_levels - 1] + d.hd[p].size[d.hd[p].n_levels - 1]);

@@ -23,9 +23,6 @@ __global__ void time_setup_kernel(const float* __restrict__ t, int num_frames, f
   tinfo[5] = (float)f;
 }
 
-#ifndef ENC_SCHED_LEVEL
-#define ENC_SCHED_LEVEL 0
-#endif
 template <int C>
 __device__ __forceinline__ void planes_group(const FieldDesc& fd, int s, const float coord[4], bool time_group, float out[C]) {
 #pragma unroll
@@ -41,13 +38,7 @@ __device__ __forceinline__ void planes_group(const FieldDesc& fd, int s, const f
     sample_plane<C>(fd.planes_cl + fd.planes.off[s][ci], W, t, v);
 #pragma unroll
     for (int k = 0; k < C; ++k) out[k] = j == 0 ? v[k] : out[k] * v[k];
-#if ENC_SCHED_LEVEL >= 2
-    __builtin_amdgcn_sched_barrier(0);
-#endif
   }
-#if ENC_SCHED_LEVEL >= 1
-  __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 
 __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
@@ -61,28 +52,20 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 // levels).  Written straight to HBM those partial-line stores cost 17.7 GB of write traffic for a 3.2 GB matrix
 // (profiles/r01_pmc_WRITE_SIZE_c3_v6.txt), so the row is staged in LDS (row pitch in_pad + 8 halfs: 16-B aligned, spreads
 // the lanes' rows over the banks) and each wave then writes its 64 rows as full 16-B-per-lane coalesced stores.
-#ifndef ENC_THREADS
 #define ENC_THREADS 64  // one wave per workgroup: measured best (64: 13.8 ms, 128: 14.1, 256: 14.5 for the entry point)
-#endif
 #define ENC_MAX_IN_PAD 192  // widest network input row (BASELINE config C2: L = 16 hash levels -> 176 columns)
-#ifndef ENC_WAVES_PER_EU
 #define ENC_WAVES_PER_EU 2
-#endif
 #define ENC_SPLIT_MIN_POINTS (1 << 18)  // below this the extra launch and the re-read of xt / flow cost more than the overlap buys
-#ifndef ENC_WAVES_PER_EU_HASH
 #define ENC_WAVES_PER_EU_HASH 4
-#endif
 // PART: 0 = the whole row in one kernel; 1 = the plane columns [0, 2 nS C) only; 2 = everything behind them (hash grids, ones).
 // The split (l4d_density_encode_fwd with side streams) exists for two reasons: the plane part does not need the xz / yz columns
 // that dynhash_fwd_lds_kernel produces, so the two run CONCURRENTLY (texel-bandwidth-bound next to VALU / LDS-bound), and the
 // hash part alone needs half the registers, i.e. twice the wavefronts to hide its L2-missing gathers behind.
-#ifndef ENC_HDT_EARLY
-#define ENC_HDT_EARLY 0
-#endif
-// HSPRE: the static grid's columns come from the level-major pre-pass (hashgrid.hip hashgrid_fwd_levels_kernel, hsT[level][P][4]
+// HSMODE 1: the static grid's columns come from the level-major pre-pass (hashgrid.hip hashgrid_fwd_levels_kernel, hsT[level][P][4]
 // fp16) instead of being gathered here: 8 bytes per level and sample, dense, and the kernel's own gathers (xy stack, planes) no
-// longer share the L2s with 33 MB of static tables.
-template <bool USE_HDT, bool ROWS, int PART = 0, bool HSPRE = false>
+// longer share the L2s with 33 MB of static tables.  HSMODE 2: gathered here, x-neighbour pairs in one 16-byte load where they
+// share an aligned pair (hashgrid_dev.h PAIRLD).  HSMODE 0: gathered here, one 8-byte load per corner (rounds 1-4).
+template <bool USE_HDT, bool ROWS, int PART = 0, int HSMODE = 0>
 __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
                                                                         const float* __restrict__ tinfo, int64_t P,
@@ -157,14 +140,15 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
   // ---- static 3-D hash grid (hash_field.py:141-144) ----
   {
     const float xs[3] = {x0[0], x0[1], x0[2]};
+    constexpr bool HSPRE = HSMODE == 1;
     for (int lvl = 0; HSPRE && lvl < fd.hs.n_levels; ++lvl) {
       typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2_t*>(row + col + lvl * 4) = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(hsT) + (int64_t)lvl * P + p);
     }
     for (int lvl = 0; !HSPRE && lvl < fd.hs.n_levels; ++lvl) {
       float a[4];
-      level_lookup<3, 4>(fd.hs_table + (size_t)fd.hs.offset[lvl] * 4, fd.hs.scale[lvl], fd.hs.res[lvl], fd.hs.size[lvl],
-                         (fd.hs.hashed_mask >> lvl) & 1u, xs, a);
+      level_lookup<3, 4, HSMODE == 2>(fd.hs_table + (size_t)fd.hs.offset[lvl] * 4, fd.hs.scale[lvl], fd.hs.res[lvl], fd.hs.size[lvl],
+                                      (fd.hs.hashed_mask >> lvl) & 1u, xs, a);
       half4_t h;
 #pragma unroll
       for (int f = 0; f < 4; ++f) h[f] = f2h(a[f]);
@@ -177,36 +161,10 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
   const int col_dyn0 = col;
   {
     const TimeCoef tc0 = time_coef(t0, fd.n_slices), tc1 = time_coef(t1, fd.n_slices), tc2 = time_coef(t2, fd.n_slices);
-#if ENC_HDT_EARLY
-    // (experiment, not measured yet) the xz / yz columns that dynhash_fwd_lds_kernel produced are requested HERE, in front of the xy
-    // stack's gathers, and written into the row behind them: read level by level where they are used they were four dependent
-    // round trips at the end of a kernel that holds two wavefronts per SIMD
-    constexpr int HDT_MAX = 8;
-    const int L0_ = fd.hd[0].n_levels, L1_ = fd.hd[1].n_levels, L2_ = fd.hd[2].n_levels;
-    const bool hdt_early = USE_HDT && L1_ <= HDT_MAX && L2_ <= HDT_MAX;  // block-uniform
-    unsigned short hd_early[2][HDT_MAX];
-    if (hdt_early) {
-#pragma unroll
-      for (int j = 0; j < HDT_MAX; ++j) {
-        hd_early[0][j] = reinterpret_cast<const unsigned short*>(hdT)[(int64_t)(L0_ + min(j, L1_ - 1)) * P + p];
-        hd_early[1][j] = reinterpret_cast<const unsigned short*>(hdT)[(int64_t)(L0_ + L1_ + min(j, L2_ - 1)) * P + p];
-      }
-      asm volatile("" ::: "memory");  // (the requests stay up here: no memory operation may cross, and nothing here waits for them)
-    }
-#endif
 #pragma unroll
     for (int plane = 0; plane < 3; ++plane) {
       const int L = fd.hd[plane].n_levels;
       if (USE_HDT && plane > 0) {  // xz / yz: evaluated by dynhash_fwd_lds_kernel from LDS-resident slice tables
-#if ENC_HDT_EARLY
-        if (hdt_early) {
-#pragma unroll
-          for (int j = 0; j < HDT_MAX; ++j)
-            if (j < L) row[col + j] = __builtin_bit_cast(half_t, hd_early[plane - 1][j]);
-          col += L;
-          continue;
-        }
-#endif
         for (int lvl = 0; lvl < L; ++lvl) row[col + lvl] = hdT[(int64_t)(col - col_dyn0 + lvl) * P + p];
         col += L;
         continue;
@@ -481,6 +439,7 @@ extern "C" int64_t l4d_density_encode_fwd_workspace(const l4d_field_desc* f, int
   return enc_ws_hs_offset(f, P) + (int64_t)f->hash_static.n_levels * P * 8;
 }
 
+L4D_INTERNAL int l4d_hs_pairld();
 L4D_INTERNAL int l4d_hashgrid_levels_launch(const GridDesc* g, int n_dims, int n_features, const float* x, int64_t P, int x_stride,
                                             const int* cols3, const void* table, void* lvlT, void* stream);
 // static grid through the level-major pre-pass (default; L4D_ENC_HS_SPLIT=0: gathered inside the encode kernel as in rounds 1-4)
@@ -551,8 +510,11 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
   L4D_LAUNCH((density_encode_fwd_kernel<HDT, ROWS, PART>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,                \
              (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr)
   if (hs_pre) {
-    L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, true>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
+    L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 1>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
                (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT);
+  } else if (!split && hd_scratch && plane_rows && l4d_hs_pairld()) {
+    L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 2>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
+               (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr);
   } else if (split) {  // plane columns while the side stream evaluates the xz / yz stacks, then the hash columns
     if (plane_rows) ENC_LAUNCH(true, true, 1);
     else ENC_LAUNCH(true, false, 1);

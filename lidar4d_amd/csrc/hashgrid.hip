@@ -98,7 +98,7 @@ template <> struct NtVec<8> { typedef u32x4_t type; };
 //     level) all read the SAME table, every L2 holds a copy of it, and every level has the whole chip's gather rate.
 // The coordinate stream is read with non-temporal loads (it must not evict the table), results go out as coalesced 2F-byte
 // non-temporal stores.  (Placement is a performance assumption only: any block -> XCD map gives the same result.)
-template <int D, int F>
+template <int D, int F, bool PAIRLD = false>
 __global__ void __launch_bounds__(256) hashgrid_fwd_levels_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
                                                                  Cols cols, const half_t* __restrict__ table, int64_t n_tiles,
                                                                  half_t* __restrict__ lvlT, int order) {
@@ -121,8 +121,8 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_levels_kernel(GridDesc desc,
 #pragma unroll
   for (int d = 0; d < D; ++d) xin[d] = __builtin_nontemporal_load(x + p * x_stride + cols.c[d]);
   float acc[F];
-  level_lookup<D, F>(table + (size_t)desc.offset[lvl] * F, desc.scale[lvl], desc.res[lvl], desc.size[lvl],
-                     (desc.hashed_mask >> lvl) & 1u, xin, acc);
+  level_lookup<D, F, PAIRLD>(table + (size_t)desc.offset[lvl] * F, desc.scale[lvl], desc.res[lvl], desc.size[lvl],
+                             (desc.hashed_mask >> lvl) & 1u, xin, acc);
   half_t h[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) h[f] = f2h(acc[f]);
@@ -134,6 +134,13 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_levels_kernel(GridDesc desc,
 static int hg_order() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("L4D_HG_ORDER"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+
+// x-neighbour pairs in one 16-byte load where aligned (hashgrid_dev.h PAIRLD; F = 4): L4D_HS_PAIRLD=0 switches it off (A/B)
+L4D_INTERNAL int l4d_hs_pairld() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("L4D_HS_PAIRLD"); v = (e && e[0] == '0') ? 0 : 1; }
   return v;
 }
 
@@ -150,7 +157,13 @@ L4D_INTERNAL int l4d_hashgrid_levels_launch(const GridDesc* g, int n_dims, int n
 #define CALL(D, F)                                                                                                             \
   L4D_LAUNCH((hashgrid_fwd_levels_kernel<D, F>), grid, block, 0, (hipStream_t)stream, *g, x, P, x_stride, c, (const half_t*)table, \
              n_tiles, (half_t*)lvlT, order);
-  if (n_dims == 2 && n_features == 2) { CALL(2, 2) }
+  if (n_features == 4 && l4d_hs_pairld()) {
+    if (n_dims == 2)
+      L4D_LAUNCH((hashgrid_fwd_levels_kernel<2, 4, true>), grid, block, 0, (hipStream_t)stream, *g, x, P, x_stride, c, (const half_t*)table, n_tiles, (half_t*)lvlT, order);
+    else
+      L4D_LAUNCH((hashgrid_fwd_levels_kernel<3, 4, true>), grid, block, 0, (hipStream_t)stream, *g, x, P, x_stride, c, (const half_t*)table, n_tiles, (half_t*)lvlT, order);
+  }
+  else if (n_dims == 2 && n_features == 2) { CALL(2, 2) }
   else if (n_dims == 2 && n_features == 4) { CALL(2, 4) }
   else if (n_dims == 2 && n_features == 8) { CALL(2, 8) }
   else if (n_dims == 3 && n_features == 2) { CALL(3, 2) }

@@ -99,59 +99,54 @@ __device__ __forceinline__ float corner(const Cell<D>& c, int corner_id, uint32_
   return w;
 }
 
-// Two x-neighbouring entries in one load.  On a hashed level with a power-of-two table the vertex (x, ...) and its neighbour
-// (x + 1, ...) sit in entries i and i ^ 1 whenever x is even (the hash leaves the first coordinate unmultiplied: x ^ rest), i.e.
-// in one aligned pair.  A random gather costs one slot of the address path per lane and line whatever it fetches
-// (profiles/r02_ubench_gather.txt), so lanes whose cell has an even x issue 2^(D-1) loads instead of 2^D: a quarter of a
-// level's gathers (and of its L2 misses) would go away -- MEASURED SLOWER (forward encode 6.24 -> 6.55 ms): the lanes with an
-// odd x still need their two loads, so a wavefront issues three load instructions per corner pair instead of two, and the
-// address path charges per instruction, not per active lane.  Off; kept for the record (tools/build_abl.sh -DL4D_PAIR_LOADS=1).
-#ifndef L4D_PAIR_LOADS
-#define L4D_PAIR_LOADS 0
-#endif
-template <int F>
-struct PairVec;
-template <>
-struct PairVec<2> { typedef uint2 type; };
-template <>
-struct PairVec<4> { typedef uint4 type; };
-template <>
-struct PairVec<8> { typedef uint4 type; };  // unused: a pair of 16-byte entries is two loads anyway
-
+// Two x-neighbouring entries per load where they share an aligned pair.  On a hashed level with a power-of-two table the vertex
+// (x, ...) and its neighbour (x + 1, ...) sit in entries i and i ^ m, m = 2^(trailing ones of x + 1) - 1 (the hash leaves the first
+// coordinate unmultiplied: x ^ rest): for an even x that is the aligned pair (i, i ^ 1) = ONE 16-byte load.  A gather costs the
+// address path ~2.1 clocks per distinct address of an instruction whatever its width (tools/ubench/gather_policy.hip), so PAIRLD:
+// every lane loads the 16-byte pair that holds its first corner (all lanes: one instruction), and only the lanes with an odd x
+// issue a second, 8-byte load for the neighbour: 1.5 address slots per corner pair on average instead of 2.  (Round 2 tried the
+// divergent form -- even lanes one 16-byte load, odd lanes two 8-byte loads: three instructions per corner pair -- inside the
+// fused encode kernel and lost, 6.24 -> 6.55 ms.)  Same accumulation order as the plain path: bit-identical results.
 // fp32-accumulated interpolation of one level; result NOT yet rounded.  PAIRS: the 3-D grids (the 2-D x time stacks have
 // their own pair layout -- two time slices per entry -- and their fallback path has no register to spare).
-template <int D, int F, bool PAIRS = (D == 3)>
+template <int D, int F, bool PAIRLD = false>
 __device__ __forceinline__ void level_lookup(const half_t* level_table, float scale, uint32_t res, uint32_t size,
                                              bool hashed, const float x[D], float out[F]) {
   Cell<D> c = locate<D>(x, scale);
 #pragma unroll
   for (int f = 0; f < F; ++f) out[f] = 0.0f;
   typedef typename EntryVec<F>::type EV;
-  if (L4D_PAIR_LOADS && PAIRS && F <= 4 && hashed && (size & (size - 1)) == 0) {  // uniform over the level
-    typedef typename PairVec<F>::type PV;
-    const bool even = (c.cell[0] & 1u) == 0;
+  if (PAIRLD && F == 4 && hashed && (size & (size - 1)) == 0) {  // uniform over the level
+    constexpr int NP = 1 << (D - 1);
+    const bool odd_x = (c.cell[0] & 1u) != 0;
+    float w0[NP], w1[NP];
+    uint32_t i0[NP];
+    uint4 pr[NP];
+    uint2 nb[NP];
+    // all requests first, unconditionally (a load under a condition is waited for where it is issued): the lanes with an even
+    // x request entry 0 as their "neighbour" -- ONE address for all of them, i.e. one slot of the address path
 #pragma unroll
-    for (int k = 0; k < (1 << D); k += 2) {  // corners k, k + 1 differ in x only; same accumulation order as below
+    for (int q = 0; q < NP; ++q) {  // corners 2q, 2q + 1 differ in x only
       uint32_t g0[D], g1[D];
-      const float w0 = corner<D>(c, k, g0), w1 = corner<D>(c, k + 1, g1);
-      const uint32_t i0 = grid_index<D>(g0, res, size, true);
-      EV e[2];
-      if (even) {
-        const PV r = *reinterpret_cast<const PV*>(level_table + (size_t)(i0 & ~1u) * F);
-        const EV lo = *reinterpret_cast<const EV*>(&r), hi = *(reinterpret_cast<const EV*>(&r) + 1);
-        const bool odd = i0 & 1u;  // selects, not an indexed register array (that would live in scratch)
-        e[0] = odd ? hi : lo;
-        e[1] = odd ? lo : hi;
-      } else {
-        e[0] = *reinterpret_cast<const EV*>(level_table + (size_t)i0 * F);
-        e[1] = *reinterpret_cast<const EV*>(level_table + (size_t)grid_index<D>(g1, res, size, true) * F);
-      }
-      const half_t* h0 = reinterpret_cast<const half_t*>(&e[0]);
-      const half_t* h1 = reinterpret_cast<const half_t*>(&e[1]);
+      w0[q] = corner<D>(c, 2 * q, g0);
+      w1[q] = corner<D>(c, 2 * q + 1, g1);
+      i0[q] = grid_index_fast<D>(g0, size - 1u);
+      const uint32_t i1 = odd_x ? grid_index_fast<D>(g1, size - 1u) : 0u;
+      pr[q] = *reinterpret_cast<const uint4*>(level_table + (size_t)(i0[q] & ~1u) * 4);  // entries (i0 & ~1), (i0 | 1)
+      nb[q] = *reinterpret_cast<const uint2*>(level_table + (size_t)i1 * 4);
+    }
 #pragma unroll
-      for (int f = 0; f < F; ++f) out[f] = fmix(h0[f], w0, out[f]);
+    for (int q = 0; q < NP; ++q) {  // same accumulation order as the plain path
+      const bool hi0 = i0[q] & 1u;
+      const uint2 e0 = hi0 ? make_uint2(pr[q].z, pr[q].w) : make_uint2(pr[q].x, pr[q].y);
+      const uint2 pe = hi0 ? make_uint2(pr[q].x, pr[q].y) : make_uint2(pr[q].z, pr[q].w);  // even x: the neighbour is i0 ^ 1
+      const uint2 e1 = odd_x ? nb[q] : pe;
+      const half_t* h0 = reinterpret_cast<const half_t*>(&e0);
+      const half_t* h1 = reinterpret_cast<const half_t*>(&e1);
 #pragma unroll
-      for (int f = 0; f < F; ++f) out[f] = fmix(h1[f], w1, out[f]);
+      for (int f = 0; f < F; ++f) out[f] = fmix(h0[f], w0[q], out[f]);
+#pragma unroll
+      for (int f = 0; f < F; ++f) out[f] = fmix(h1[f], w1[q], out[f]);
     }
     return;
   }

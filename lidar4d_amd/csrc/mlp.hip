@@ -32,12 +32,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define HID 64
-#ifndef MLP_RELU_PK
-#define MLP_RELU_PK 1  // ReLU as one packed fp16 maximum per pair of halfs (relu_pack)
-#endif
-#ifndef MLP_MASK_PK
-#define MLP_MASK_PK 0  // ReLU masks of the backward on the bit patterns (keep_where_pos): would need activations that are never -0; measured
-#endif                 // mixed anyway (attribute backward 2.82 -> 2.71 ms, flow backward 1.26 -> 1.30: the compiler turns it into compares again)
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ int perm_row(int mt, int i) { return 32 * (mt >> 1) + 8 * (i >> 2) + 4 * (mt & 1) + (i & 3); }
@@ -80,7 +74,6 @@ __device__ __forceinline__ h8 ident_frag(int lane, int half_sel) {
 
 __device__ __forceinline__ h8 relu_pack(const f4& lo, const f4& hi) {
   h8 v;
-#if MLP_RELU_PK
   // Convert first, then ONE packed fp16 maximum per pair (v_cvt_pk_f16_f32 + v_pk_max_f16: half the instructions of eight
   // v_max_f32 + four conversions; same values: rounding is monotone and keeps zero).  Measured over the step's MLP kernels:
   // -0.30 ms (gpurun_out/r4j).  The integer form (max of the bit patterns as int16) made the compiler split the conversions
@@ -96,27 +89,11 @@ __device__ __forceinline__ h8 relu_pack(const f4& lo, const f4& hi) {
     v[2 * q] = a[0]; v[2 * q + 1] = a[1];
     v[4 + 2 * q] = b[0]; v[4 + 2 * q + 1] = b[1];
   }
-#else
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    v[r] = f2h(fmaxf(lo[r], 0.0f));
-    v[4 + r] = f2h(fmaxf(hi[r], 0.0f));
-  }
-#endif
   return v;
 }
 
-// val where act > 0, else 0, on packed halfs: act holds ReLU outputs (relu_pack: +0 or positive, never -0), so "positive" is
-// "bit pattern non-zero": mask = min(bits, 1) * 0xFFFF per 16-bit half (v_pk_min_u16, v_pk_mul_lo_u16), then one AND per pair --
-// three packed instructions per pair instead of two compares + two selects.
-static_assert(!(MLP_MASK_PK && MLP_RELU_PK), "keep_where_pos needs activations that are never -0; relu_pack (v_pk_max_f16) can produce -0");
-__device__ __forceinline__ h8 keep_where_pos(h8 val, h8 act) {
-  typedef unsigned short us8v __attribute__((ext_vector_type(8)));
-  const us8v one = 1, ones = 0xFFFF;
-  const us8v m = __builtin_elementwise_min(__builtin_bit_cast(us8v, act), one) * ones;
-  return __builtin_bit_cast(h8, (us8v)(__builtin_bit_cast(us8v, val) & m));
-}
-
+// (ReLU masks of the backward as bit-pattern operations on the packed halfs: measured mixed -- attribute backward 2.82 -> 2.71 ms, flow
+// backward 1.26 -> 1.30 -- because the compiler turns them back into compares; removed in round 5.)
 __device__ __forceinline__ float clamp_h(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
 
 // Input rows of the attribute networks assembled on the fly (model/lidar4d.py:196-213: row j of the work list =
@@ -342,12 +319,8 @@ struct BwdFrags {
 // encoding has no trainable input).
 // MLP_BWD_NARROW_WAVES: waves per SIMD the 16-wide (flow) network's backward is compiled for.  Its accumulators are small, but
 // the compiler keeps the LDS weight fragments in registers across the tile loop as long as it has any (446 of 512).
-#ifndef MLP_BWD_PIN
 #define MLP_BWD_PIN 1  // backward kernels: wait for the prefetched next tile in front of the current tile's dX stores (see there)
-#endif
-#ifndef MLP_BWD_NARROW_WAVES
 #define MLP_BWD_NARROW_WAVES 1
-#endif
 // ATTR_EPI (attribute networks, with GATHER): the two streaming steps around the network live in the kernel --
 //   in:  dy[row][0] = d_attr[sample][ch] * s (1 - s) * loss_scale with s = attr_compact[row][ch] (adjoint of the sigmoid +
 //        scatter, lidar4d.py:210-219), other columns 0, instead of a [rows, 16] matrix that is 15/16 zeros;
@@ -667,11 +640,9 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           c[mt] = MFMA(FR(L::WOT_P + mt), dzf[a][0], (f4{0, 0, 0, 0}));
-#if !MLP_MASK_PK
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (!(hf[a][mt >> 1][4 * (mt & 1) + r] > (half_t)0.0f)) c[mt][r] = 0.0f;
-#endif
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -680,9 +651,6 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
             nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
             nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
           }
-#if MLP_MASK_PK
-          nz[a][ks] = keep_where_pos(nz[a][ks], hf[a][ks]);  // (element e of nz[a][ks] belongs to element e of hf[a][ks])
-#endif
         }
       }
 #pragma unroll
@@ -691,17 +659,9 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
         f4 t1 = MFMA(dzf[1][0], FR(L::WOT_N + nt), (f4{0, 0, 0, 0}));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#if MLP_MASK_PK
-          dzT[nt][r] = f2h_grad(t0[r]);
-          dzT[nt][4 + r] = f2h_grad(t1[r]);
-#else
           dzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h_grad(t0[r]) : (half_t)0.0f;
           dzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h_grad(t1[r]) : (half_t)0.0f;
-#endif
         }
-#if MLP_MASK_PK
-        dzT[nt] = keep_where_pos(dzT[nt], hT[nt]);
-#endif
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -748,11 +708,9 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
         for (int mt = 0; mt < 4; ++mt) {
           c[mt] = MFMA(FR(fb + mt * 2 + 0), dzf[a][0], (f4{0, 0, 0, 0}));
           c[mt] = MFMA(FR(fb + mt * 2 + 1), dzf[a][1], c[mt]);
-#if !MLP_MASK_PK
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (!(hf[a][mt >> 1][4 * (mt & 1) + r] > (half_t)0.0f)) c[mt][r] = 0.0f;
-#endif
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -761,9 +719,6 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
             nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
             nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
           }
-#if MLP_MASK_PK
-          nz[a][ks] = keep_where_pos(nz[a][ks], hf[a][ks]);
-#endif
         }
       }
 #pragma unroll
@@ -774,17 +729,9 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
         t1 = MFMA(dzf[1][1], FR(fb + 8 + nt * 2 + 1), t1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#if MLP_MASK_PK
-          nzT[nt][r] = f2h_grad(t0[r]);
-          nzT[nt][4 + r] = f2h_grad(t1[r]);
-#else
           nzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h_grad(t0[r]) : (half_t)0.0f;
           nzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h_grad(t1[r]) : (half_t)0.0f;
-#endif
         }
-#if MLP_MASK_PK
-        nzT[nt] = keep_where_pos(nzT[nt], hT[nt]);
-#endif
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)

@@ -80,19 +80,6 @@ __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
   if (K < 3) asm volatile("s_nop 1");
 #pragma unroll
   for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f2, 2);
-#ifdef L4D_SCAN_ADAPTIVE
-  // steps 3 and 4 only where some run of the wavefront is longer than 4 / 8 lanes (wave-uniform: the flags are 0 everywhere otherwise)
-  if (WIDTH > 4 && __any(r.f4 != 0.0f)) {
-    asm volatile("s_nop 4");
-#pragma unroll
-    for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f4, 4);
-    if (WIDTH > 8 && __any(r.f8 != 0.0f)) {
-      if (K < 3) asm volatile("s_nop 1");
-#pragma unroll
-      for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f8, 8);
-    }
-  }
-#else
   if (WIDTH > 4) {
     if (K < 3) asm volatile("s_nop 1");
 #pragma unroll
@@ -103,7 +90,6 @@ __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) L4D_FMAC_DPP(v[k], r.f8, 8);
   }
-#endif
 #undef L4D_FMAC_DPP
 }
 
@@ -116,13 +102,9 @@ __device__ __forceinline__ float amax_nf(float m, float v) { return nonfinite(v)
 // sample in the time-plane kernel alone) and are bound by VALU issue; exact ties round up instead of to even, which changes
 // nothing that is measurable (the quantum is 2^-26 ... 2^-30 of the largest gradient) and keeps sums exact and order-independent.
 __device__ __forceinline__ int fx_round(float x) {
-#ifdef L4D_FX_ROUND_RN
-  return __float2int_rn(x);
-#else
   int r;
   asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
   return r;
-#endif
 }
 
 // fixed-point scale: largest power of two s with bound * s < 2^bits (bound > 0)
