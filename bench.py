@@ -58,8 +58,9 @@ HBM_PEAK_GBS = 8000.0     # HBM3E 8.0 TB/s spec (6.3 TB/s measured achievable)
 L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth, 8 XCDs
 LDS_PEAK_GBS = 150000.0   # ds_read_b64/b128 streaming, 256 CUs
 MFMA_F16_PEAK_TFLOPS = 2500.0
-GATHER_PEAK_G = 292.0     # measured here (tools/ubench/gather.hip, profiles/r02_ubench_gather.txt): G lane-loads/s of a wave-level
-                          # gather whose 64 lanes touch 64 different L2-resident lines (8 or 16 B per lane alike); 64 G/s when they miss L2
+GATHER_PEAK_G = 292.0     # measured here (tools/ubench/gather.hip, gather_policy.hip; profiles/r02_ubench_gather.txt, r05_ubench_gather_policy.txt):
+                          # G lane-loads/s of a wave-level gather whose 64 lanes touch 64 different L2-resident lines -- 4, 8 or 16 B per lane and
+                          # every cache policy alike (= the L2's 34 TB/s in 128-byte lines); 65 G/s when they come from the Infinity Cache
 
 WORKLOADS = {
     # name: (model kwargs, rays per GPU per step, description)
@@ -86,8 +87,12 @@ def kernel_models(model, P, M):
     """Per-kernel roof and byte model: {kernel name: dict(bound, bytes, [alg], note)} per LAUNCH at P sample points and M
     attribute rows (samples with weight > 1e-4).  ``bytes`` is what the roof is charged with:
       bound "hbm": COMPULSORY HBM bytes (inputs read once + outputs written once; tables excluded: they are cache resident)
-      bound "l2" : table-entry bytes the algorithm gathers (SURVEY 8d: fp16 hash entries 8 / 16 B, fp32 plane texels 32 B);
-                   ``hbm`` then gives the kernel's compulsory HBM bytes for the secondary figure
+      bound "fabric": gather kernels.  ``bytes`` = table-entry bytes the algorithm gathers (fp16 hash entries 8 / 16 B, fp32
+                   plane texels 32 B); ``hbm`` = the kernel's compulsory HBM bytes.  The tables (97 MB) sit in L2 / Infinity Cache, and a
+                   gather moves a 128-byte LINE at whichever boundary it crosses, so the roof that binds is the fabric between L2 and
+                   Infinity Cache / HBM (8 TB/s, the HBM figure): the headline fraction is COUNTER bytes / time / 8 TB/s when a counter
+                   file of this build exists (profiles/hbm_traffic_rNN.json), else the compulsory HBM bytes; the algorithmic bytes
+                   against the 34.5 TB/s L2 peak are reported next to it (``algorithmic``)
       bound "lds": table-entry bytes served from LDS
     Kernel names are the launch sites' (csrc), the same rocprofv3's kernel trace shows."""
     he, pe = model.hash_encoder, model.planes_encoder
@@ -105,16 +110,28 @@ def kernel_models(model, P, M):
     m = {}
     # gathers always issued: static grid 8 corners + current-frame xy stack 4 corners per level; the two warped frames' 4 + 4 are
     # issued only where the warped point leaves the current point's cell (all reused while the flow is zero, as at initialisation)
-    enc = dict(bound="l2", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P, gathers=(L * 8 + L * 4) * P,
+    enc = dict(bound="fabric", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P, gathers=(L * 8 + L * 4) * P,
                note="planes + static hash + xy dynamic hash gathers (time planes via per-call 1-D rows, both time slices of a corner "
                     "in one 16-B load); row staged in LDS, written once")
     m["density_encode_fwd_kernel<true, true, 0>"] = enc
     m["density_encode_fwd_kernel<true, false, 0>"] = enc
-    m["density_encode_fwd_kernel<false, false, 0>"] = dict(bound="l2", bytes=(enc_alg + lds_alg) * P, hbm=(16 + 32 + X) * P, note="all gathers direct")
+    m["density_encode_fwd_kernel<true, true, 0, 0>"] = m["density_encode_fwd_kernel<true, true, 0, 2>"] = enc
+    # round 5: the static grid through a level-major pre-pass (hashgrid_fwd_levels_kernel); the encode kernel gathers the hex-planes and
+    # the xy stack and takes the static grid's columns from the pre-pass
+    m["density_encode_fwd_kernel<true, true, 0, 1>"] = dict(bound="fabric", bytes=(enc_alg - L * 8 * 8) * P, hbm=(16 + 32 + X + 2 * 2 * L + 8 * L) * P, gathers=L * 4 * P,
+                                                           note="planes + xy dynamic hash gathers; static-grid columns read from the level-major pre-pass (8 B per level); row staged in LDS, written once")
+    hs_lv = dict(bound="fabric", bytes=L * 8 * 8 * P, hbm=(L * 12 + L * 8) * P, gathers=L * 8 * P,
+                 note="static 3-D grid, one level at a time chip-wide (every L2 holds that level's 4 MB table): 8 corners x 8 B per level; "
+                      "x-neighbour pairs in one 16-byte load where aligned (6 address slots per level instead of 8)")
+    m["hashgrid_fwd_levels_kernel<3, 4, true>"] = m["hashgrid_fwd_levels_kernel<3, 4>"] = hs_lv
+    m["hashgrid_t_fwd_levels_kernel<3, 8>"] = dict(bound="fabric", bytes=Lf * 8 * 16 * P, hbm=(Lf * 12 + Lf * 4) * P, gathers=Lf * 8 * P,
+                                                   note="flow grid + interpT, one level at a time chip-wide, level-major fp16 output (rows assembled by hashgrid_rows_from_levels_kernel)")
+    m["hashgrid_rows_from_levels_kernel<2>"] = dict(bound="hbm", bytes=(Lf * 4 + Lf * 4) * P, note="level-major columns in, rows out")
+    m["density_encode_fwd_kernel<false, false, 0>"] = dict(bound="fabric", bytes=(enc_alg + lds_alg) * P, hbm=(16 + 32 + X) * P, note="all gathers direct")
     m["density_encode_fwd_kernel<false, true, 0>"] = m["density_encode_fwd_kernel<false, false, 0>"]
     m["dynhash_fwd_lds_kernel"] = dict(bound="lds", bytes=lds_alg * P, hbm=(2 * L * 16 + 2 * 2 * L) * P,
                                        note="xz / yz HashGridT stacks from LDS-resident slice tables; one streaming pass of xt / flow per (plane, level)")
-    m["hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="l2", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, gathers=Lf * 8 * P, note="flow grid + interpT")
+    m["hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="fabric", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, gathers=Lf * 8 * P, note="flow grid + interpT")
     fl = lambda pad, nh: 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
     it_s, nf = in_pad // 16, model.flow_net.n_hidden
     # sigma network: x + y + saved activations; backward also writes dx
@@ -346,6 +363,7 @@ def compact_line(detail, args):
     line["value"], line["ms_per_step"] = _r(line["value"], 1), _r(line["ms_per_step"], 4)
     line["config"] = {"workload": c["workload"][:160], "rays_per_gpu_per_step": c["rays_per_gpu_per_step"], "samples_per_ray": c["samples_per_ray"],
                       "global_rays_per_step": c["global_rays_per_step"], "parallelism": c["parallelism"].split(",")[0],
+                      "rccl_ranks_seen": c.get("rccl_ranks_seen"), "distinct_gpus_seen": c.get("distinct_gpus_seen"),
                       "skipped_steps_in_timed_region": c["skipped_steps_in_timed_region"], "skipped_steps_in_warmup": c["skipped_steps_in_warmup"],
                       "settling_steps": c["scaler_settling_steps_before_warmup"], "loss_scale": c["loss_scale_after_timed_region"],
                       "step_mode": c["step_mode"][:60]}
@@ -353,8 +371,11 @@ def compact_line(detail, args):
     if rf:
         tr = rf.get("traffic") or {}
         req, miss = tr.get("l2_requests"), tr.get("l2_misses")
+        alg = rf.get("algorithmic") or {}
         line["roofline"] = {"bound": rf["bound"], "kernel": rf["kernel"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
+                            "achieved_from": str(rf.get("achieved_from"))[:60],
                             "traffic": tr.get("bytes_per_launch"), "frac_hbm_counter": rf.get("frac_hbm_counter"),
+                            "algorithmic_GBps": alg.get("GBps"), "algorithmic_frac_of_l2_peak": alg.get("frac_of_l2_peak"),
                             "l2_miss_rate": _r(miss / req) if req and miss is not None else None,
                             "bytes_per_launch": rf["bytes_per_launch"], "avg_launch_ms": rf["avg_launch_ms"], "samples_per_launch": rf["samples_per_launch"],
                             "hash_gathers_G_per_s": rf.get("hash_gathers_G_per_s"), "gather_peak_G_per_s": GATHER_PEAK_G if rf.get("hash_gathers_G_per_s") else None,
@@ -375,6 +396,11 @@ def compact_line(detail, args):
     v = detail.get("variants")
     if v:
         line["variants"] = {k: {"ms_per_step": _r(d["ms_per_step"], 3), "rays_per_s": _r(d["rays_per_s"], 0)} for k, d in v.items()}
+        ts = v.get("trained_state")
+        if ts:  # both operating points next to each other: the headline is the random-init state
+            line["config"]["state"] = "random init (mask fraction ~1)"
+            line["config"]["trained_state"] = {"ms_per_step": _r(ts["ms_per_step"], 3), "rays_per_s": _r(ts["rays_per_s"], 0),
+                                               "mask_fraction": ts.get("mask_fraction"), "after_steps": ts.get("after_steps")}
     if "eval" in detail:
         line["eval"] = {"chamfer_f_score": detail["eval"]["chamfer_distance_m2, f_score@0.05"], "frames": detail["eval"]["frames"]}
     cb = detail.get("cpu_baseline")
@@ -444,6 +470,7 @@ def _run_plumbing(args, rank, world):
     for _ in range(args.warmup):
         step()
     dt = timed(step, args.steps, barrier)
+    ranks_seen = dist.get_world_size() if world > 1 else 1
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -454,7 +481,8 @@ def _run_plumbing(args, rank, world):
     return {"metric": "training rays/sec (64x1024 LiDAR panorama)", "value": n_rays * world * args.steps / dt, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "none", "data": "synthetic",
-            "config": {"workload": "PLUMBING TEST (L4D_BENCH_PLUMBING=1): stand-in step on the CPU over gloo, not a measurement", "parallelism": f"dp{world}"}}
+            "config": {"workload": "PLUMBING TEST (L4D_BENCH_PLUMBING=1): stand-in step on the CPU over gloo, not a measurement", "parallelism": f"dp{world}",
+                       "rccl_ranks_seen": ranks_seen, "distinct_gpus_seen": None}}
 
 
 def _run(args):
@@ -597,6 +625,17 @@ def _run(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     scale_after = trainer.scaler.get_scale() if (not inference and trainer.scaler is not None) else None
+    # what the process group really spans: ranks of the RCCL communicator, and how many DISTINCT devices they sit on
+    # (all-gathered device UUIDs; two ranks on one GPU would show up here)
+    ranks_seen, gpus_seen = (dist.get_world_size() if dist.is_initialized() else 1), 1
+    if dist.is_initialized():
+        uuid = str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")) or f"{socket.gethostname()}:{local_rank}"
+        mine = torch.zeros(64, dtype=torch.uint8, device=dev)
+        raw = uuid.encode()[:64]
+        mine[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+        every = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(every, mine)
+        gpus_seen = len({bytes(e.cpu().tolist()) for e in every})
 
     # ---- per-kernel timing pass (HIP events around every kernel launch, on the launch stream), outside the timed region ----
     roofline, roofline_kernels, mfma, per_step = None, None, None, {}
@@ -623,7 +662,7 @@ def _run(args):
             b = data.batch_for(25) if not inference else None
             M = P if inference else int(model.render(b["rays_o_lidar"], b["rays_d_lidar"], b["time"], staged=False, perturb=True, num_steps=768)["mask_count"])
         models = kernel_models(model, P, M)
-        peaks = {"hbm": HBM_PEAK_GBS, "l2": L2_PEAK_GBS, "lds": LDS_PEAK_GBS}
+        peaks = {"hbm": HBM_PEAK_GBS, "fabric": L2_PEAK_GBS, "lds": LDS_PEAK_GBS}  # ("fabric" rows: the algorithmic bytes against the L2 peak; the headline is the counter view below)
         # counter files of a committed rocprofv3 --pmc pass (tools/gpu_profile_round.sh): only attached when they were measured on
         # THIS build of the library (they carry its sha256) -- numbers of an older build would be constants, not measurements
         import hashlib
@@ -707,7 +746,7 @@ def _run(args):
             low = []
             for r in modelled:
                 if r.get("traffic"):
-                    must = r["bytes_per_launch"] if r["bound"] == "hbm" else models[r["kernel"]].get("hbm", 0)
+                    must = r["bytes_per_launch"] if r["bound"] == "hbm" else models[r["kernel"]].get("hbm", 0)  # (gather kernels: their compulsory streams)
                     ratio = r.get("counter_bytes", r["traffic"]["bytes_per_launch"]) / max(must, 1)
                     r["counter_over_compulsory"] = round(ratio, 3)
                     if ratio < 0.95 and not models[r["kernel"]].get("upper_bound"):
@@ -716,17 +755,30 @@ def _run(args):
                          "clean": not missing and not low}
         if modelled:
             d = modelled[0]  # the dominant modelled kernel
-            roofline = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": d["peak"], "unit": "GB/s",
-                        "frac": d["frac"], "traffic": d["traffic"], "frac_hbm_counter": d.get("frac_hbm_counter"), "traffic_source": traffic_src,
+            fabric = d["bound"] == "fabric"
+            # gather kernels: the headline is the fabric view -- counter bytes of THIS build / duration / 8 TB/s; without a
+            # counter file of this build the compulsory HBM bytes stand in (a lower bound) and ``achieved_from`` says so
+            if fabric and d.get("frac_hbm_counter") is not None:
+                ach, src = d["counter_bytes"] / (d["modelled_launch_ms"] * 1e-3) / 1e9, "counter bytes (TCC_EA0 read requests by size + write requests) of this build / duration"
+            elif fabric:
+                ach, src = d.get("compulsory_hbm_GBps"), "compulsory HBM bytes / duration (no counter file of this build in profiles/: a lower bound of the fabric traffic)"
+            else:
+                ach, src = d["achieved"], {"hbm": "compulsory HBM bytes / duration", "lds": "table-entry bytes served from LDS / duration"}[d["bound"]]
+            peak = HBM_PEAK_GBS if fabric else d["peak"]
+            roofline = {"bound": d["bound"], "kernel": d["kernel"], "achieved": None if ach is None else round(ach, 1), "peak": peak, "unit": "GB/s",
+                        "frac": None if ach is None else round(ach / peak, 4), "achieved_from": src,
+                        "traffic": d["traffic"], "frac_hbm_counter": d.get("frac_hbm_counter"), "traffic_source": traffic_src,
                         "library_sha256": lib_sha, "bytes_per_launch": d["bytes_per_launch"],
                         "avg_launch_ms": d["modelled_launch_ms"], "launches_per_step": d["modelled_launches_per_step"],
-                        "bytes_are": {"hbm": "compulsory HBM bytes", "l2": "table-entry bytes gathered through L1/L2 (tables are cache resident)",
+                        "bytes_are": {"hbm": "compulsory HBM bytes", "fabric": "table-entry bytes gathered through L1/L2 (SURVEY 8d; tables are cache resident)",
                                       "lds": "table-entry bytes served from LDS"}[d["bound"]],
+                        "algorithmic": {"bytes_per_launch": d["bytes_per_launch"], "GBps": d["achieved"], "frac_of_l2_peak": d["frac"], "l2_peak": L2_PEAK_GBS} if fabric else None,
                         "compulsory_hbm_GBps": d.get("compulsory_hbm_GBps"), "compulsory_hbm_frac": d.get("compulsory_hbm_frac"),
                         "hash_gathers_G_per_s": d.get("hash_gathers_G_per_s"),
                         "frac_of_measured_random_gather_rate": d.get("frac_of_measured_random_gather_rate"),
-                        "gather_rate_note": "the vector-memory path retires a 64-lane gather of 64 distinct L2-resident lines at 292 G lane-loads/s chip-wide "
-                                            "(64 G/s on L2 misses), measured with tools/ubench/gather.hip: that rate, not a byte rate, is what binds this kernel",
+                        "gather_rate_note": "a gather costs one 128-byte line at the boundary it crosses: 264-292 G lane-loads/s chip-wide when the line is L2-resident "
+                                            "(= the L2's 34 TB/s), 65 G/s when it comes over the fabric (= 8.3 TB/s), for 4 / 8 / 16 B per lane and every cache "
+                                            "policy alike (tools/ubench/gather_policy.hip, profiles/r05_ubench_gather_policy.txt)",
                         "samples_per_launch": P, "attribute_rows": M, "pmc_check": pmc_check}
         mfma = {"kernels": mf, "peak_tflops": MFMA_F16_PEAK_TFLOPS,
                 "pmc_source": (mfma_src + " (rocprofv3 --pmc pass of this command on this build: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))") if mfma_pmc else mfma_src,
@@ -745,28 +797,31 @@ def _run(args):
         _, xt = ops.sample_rays_xt(b["rays_o_lidar"].view(-1, 3).contiguous(), b["rays_d_lidar"].view(-1, 3).contiguous(), lin, noise,
                                    b["time"].view(-1), float(np.float32(model.near_lidar)), float(np.float32(model.far_lidar)), model.bound)
         hash_enc = {"what": "static 3-D hash grid forward alone (l4d_hashgrid_fwd / l4d_hashgrid_fwd_ws), ray-ordered samples of one batch, F = 4, 2^19-entry tables, fp16; "
-                            "rows_kernel: one thread per point, all levels; xcd_pinned: level l on XCD l % 8 (table L2-resident), level-major scratch, row assembly (both kernels timed)",
+                            "rows_kernel: one thread per point, all levels; level_major: one level at a time chip-wide (every L2 holds that level's table), "
+                            "x-neighbour pairs in one 16-byte load where aligned, level-major scratch, row assembly (both kernels timed)",
                     "samples": xt.shape[0], "peak": HBM_PEAK_GBS, "unit": "GB/s", "target_frac": 0.40,
-                    # every table entry is one 8-byte lane of a gather instruction, and the vector-memory path retires at most
-                    # GATHER_PEAK_G lane-loads/s when every line hits L2 (tools/ubench/gather.hip): 292 G/s x 8 B = 2.34 TB/s
-                    "ceiling_frac": round(GATHER_PEAK_G * 8.0 / HBM_PEAK_GBS, 4),
-                    "ceiling_note": "8-byte entry gathers are bound by the gather ISSUE rate (292 G lane-loads/s all-hit, 64 G/s on L2 misses; "
-                                    "profiles/r02_ubench_gather.txt, r03_ubench_l2_window.txt), not by bytes: 0.40 of the HBM byte rate would need 400 G gathers/s"}
+                    # every gather occupies the address path for ~2.1 clocks per distinct address of the instruction: 292 G lane-loads/s when
+                    # every line is L2-resident (tools/ubench/gather.hip); with pair loads a level's 8 entries cost 6 address slots
+                    "ceiling_frac": round(GATHER_PEAK_G * 8.0 * (8.0 / 6.0) / HBM_PEAK_GBS, 4),
+                    "ceiling_note": "8-byte entry gathers are bound by the address path (292 G distinct-address slots/s all-hit, 65 G/s over the fabric; "
+                                    "profiles/r02_ubench_gather.txt, r05_ubench_gather_policy.txt), not by bytes; a level's 8 corners take 6 slots with "
+                                    "x-neighbour pair loads: ceiling 292 G/s x 8 B x 8/6 = 3.1 TB/s = 0.39 of the HBM peak if every lane's line were L2-resident "
+                                    "and the coarse levels cost what the fine ones do"}
         for Lh in (8, 16):
             meta = GridMeta(3, Lh, 4, 19, 512, np.exp2(np.log2(32768 / 512) / (Lh - 1)))
             table = ((torch.rand(meta.n_params, device=dev) - 0.5)).half()
             entry = {"algorithmic_bytes_per_sample": Lh * 64}
-            for tag, pinned in (("rows_kernel", False), ("xcd_pinned", True)):
-                out = ops.hashgrid_fwd(meta, xt, (0, 1, 2), table, xcd_pinned=pinned)
+            for tag, lm in (("rows_kernel", False), ("level_major", True)):
+                out = ops.hashgrid_fwd(meta, xt, (0, 1, 2), table, level_major=lm)
                 torch.cuda.synchronize()
                 _lib.profile_start()
                 for _ in range(5):
-                    ops.hashgrid_fwd(meta, xt, (0, 1, 2), table, out=out, xcd_pinned=pinned)
+                    ops.hashgrid_fwd(meta, xt, (0, 1, 2), table, out=out, level_major=lm)
                 ms = sum(v for _, v in _lib.profile_stop()) / 5
                 gbs = Lh * 64 * xt.shape[0] / (ms * 1e-3) / 1e9
                 entry[tag] = {"ms": round(ms, 4), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
                 del out
-            best = max(("rows_kernel", "xcd_pinned"), key=lambda t: entry[t]["frac"])
+            best = max(("rows_kernel", "level_major"), key=lambda t: entry[t]["frac"])
             entry.update(ms=entry[best]["ms"], achieved=entry[best]["achieved"], frac=entry[best]["frac"], variant=best)
             hash_enc[f"L{Lh}"] = entry
             del table
@@ -786,7 +841,8 @@ def _run(args):
             with torch.no_grad():
                 bb = data.batch_for(25)
                 frac = float(model.render(bb["rays_o_lidar"], bb["rays_d_lidar"], bb["time"], staged=False, perturb=True, num_steps=768)["mask_count"]) / (n_rays * 768)
-            variants["trained_state"] = {"what": f"the headline step after {args.warmup + args.steps + args.profile_steps + args.trained_steps + 2 * args.variant_steps} training "
+            variants["trained_state"] = {"after_steps": args.warmup + args.steps + args.profile_steps + args.trained_steps + 2 * args.variant_steps,
+                                         "what": f"the headline step after {args.warmup + args.steps + args.profile_steps + args.trained_steps + 2 * args.variant_steps} training "
                                                  "steps on the synthetic scene: fewer samples pass the weights > 1e-4 mask (attribute networks run on those only), flow gradients are no longer tiny",
                                          "steps": args.variant_steps, "ms_per_step": dtv / args.variant_steps * 1e3, "rays_per_s": n_rays * args.variant_steps / dtv,
                                          "mask_fraction": round(frac, 4), "loss_scale": trainer.scaler.get_scale() if trainer.scaler is not None else None}
@@ -819,7 +875,8 @@ def _run(args):
                        "state": "random init (tiny-cuda-nn default U(-1e-4, 1e-4) tables): every sample passes the weights > 1e-4 mask, the attribute networks run on all of them",
                        "loss_scale_after_timed_region": scale_after, "skipped_steps_in_timed_region": skipped,
                        "skipped_steps_in_warmup": skipped_warmup, "scaler_settling_steps_before_warmup": settle_steps, "step_mode": step_mode,
-                       "side_streams_mask": ops.streams_mask()},
+                       "side_streams_mask": ops.streams_mask(),
+                       "rccl_ranks_seen": ranks_seen, "distinct_gpus_seen": gpus_seen},
             "roofline": roofline,
             "roofline_kernels": roofline_kernels,
             "mfma": mfma,

@@ -103,6 +103,13 @@ int l4d_hashgrid_bwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t
 int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
                        const int32_t* cols /*host*/, const void* const* tables /*host*/, int32_t n_slices,
                        const float* t, void* out, int32_t out_stride, int32_t out_is_half, void* stream);
+/* The same with l4d_hashgrid_t_fwd_workspace() bytes of device scratch: the levels are evaluated one after the other over the whole
+ * chip (every L2 then holds ONE level's table), level-major into the scratch, and a streaming kernel writes the rows.  Used for the
+ * flow field's grid (3-D, F = 8, fp16 rows) from 2^18 points on; every other shape takes l4d_hashgrid_t_fwd. */
+int64_t l4d_hashgrid_t_fwd_workspace(const l4d_grid_desc* desc /*host*/, int64_t P);
+int l4d_hashgrid_t_fwd_ws(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
+                          const int32_t* cols /*host*/, const void* const* tables /*host*/, int32_t n_slices,
+                          const float* t, void* out, int32_t out_stride, int32_t out_is_half, void* workspace, void* stream);
 /* dout [P, dout_stride] fp32 or fp16, multiplied by grad_scale; grad_tables host array of n_slices device
  * pointers to fp32 tables (accumulated into).  Only the slices selected by *t are touched.
  * scratch: n_entries * F/4 floats of device memory (the per-entry scalar accumulators; zeroed here).

@@ -65,6 +65,8 @@ SIGNATURES = {
     "l4d_hashgrid_fwd_ws": [GD, P, I64, I32, PI32, P, P, I32, P, P],
     "l4d_hashgrid_bwd": [GD, P, I64, I32, PI32, P, I32, I32, F32, P, P],
     "l4d_hashgrid_t_fwd": [GD, P, I64, I32, PI32, PP, I32, P, P, I32, I32, P],
+    "l4d_hashgrid_t_fwd_workspace": [GD, I64],
+    "l4d_hashgrid_t_fwd_ws": [GD, P, I64, I32, PI32, PP, I32, P, P, I32, I32, P, P],
     "l4d_hashgrid_t_bwd": [GD, P, I64, I32, PI32, I32, P, P, I32, I32, F32, PP, P, P, P],
     "l4d_hashgrid_t_bwd_workspace": [GD, I64],
     "l4d_planes_relayout": [PP, PI32, I32, I32, P, PI64, I32, P],

@@ -65,6 +65,9 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 // fp16) instead of being gathered here: 8 bytes per level and sample, dense, and the kernel's own gathers (xy stack, planes) no
 // longer share the L2s with 33 MB of static tables.  HSMODE 2: gathered here, x-neighbour pairs in one 16-byte load where they
 // share an aligned pair (hashgrid_dev.h PAIRLD).  HSMODE 0: gathered here, one 8-byte load per corner (rounds 1-4).
+// (Measured and removed: the xy stack through a level-major pre-pass of its own as well -- its tables are 512 KB per level, so the
+// pre-pass hit L2 always, but took 2.18 ms where the same lookups cost this kernel 1.34: here their address-path time hides behind
+// the plane arithmetic; step 31.65 -> 32.58 ms, profiles/r05_experiment_runs.txt session s5.)
 template <bool USE_HDT, bool ROWS, int PART = 0, int HSMODE = 0>
 __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,

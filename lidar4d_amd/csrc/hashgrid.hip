@@ -7,6 +7,7 @@
 // consecutive samples of a ray (consecutive threads) share cells on the coarse levels.
 // Corner entries are fetched as one 4/8/16-byte vector (F = 2/4/8 fp16 features).
 #include "common.h"
+#include <type_traits>
 
 #include "hashgrid_dev.h"
 #include "wave_dev.h"
@@ -292,6 +293,50 @@ __global__ void __launch_bounds__(256) hashgrid_t_fwd_kernel(GridDesc desc, cons
   }
 }
 
+// The same, level-major into a scratch array lvlT[level][P][F / 4] fp16 (rows are assembled by hashgrid_rows_from_levels_kernel):
+// one table at a time chip-wide, the coordinate stream and the results non-temporal -- as hashgrid_fwd_levels_kernel, and for the
+// same reason: a gather that misses L2 costs the fabric a 128-byte line ON TOP of its slot in the address path, and written as 4
+// bytes per (sample, level) into 32-byte rows the output of the row kernel above is eight partial passes over every line.
+template <int D, int F>
+__global__ void __launch_bounds__(256) hashgrid_t_fwd_levels_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride, Cols cols,
+                                                                   SliceTables tabs, int n_slices, const float* __restrict__ t_ptr,
+                                                                   int64_t n_tiles, half_t* __restrict__ lvlT) {
+  constexpr int FO = F / 4;
+  const int lvl = (int)(blockIdx.x / n_tiles);
+  const int64_t tile = blockIdx.x - (int64_t)lvl * n_tiles;
+  const int64_t p = tile * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float t = *t_ptr;
+  const SlicePair sp = slice_pair(t, n_slices);
+  float basis[4];
+  lagrange4(t, basis);
+  float xin[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = __builtin_nontemporal_load(x + p * x_stride + cols.c[d]);
+  const size_t off = (size_t)desc.offset[lvl] * F;
+  const bool hashed = (desc.hashed_mask >> lvl) & 1u;
+  float a[F], b[F];
+  level_lookup<D, F>(tabs.t[sp.i1] + off, desc.scale[lvl], desc.res[lvl], desc.size[lvl], hashed, xin, a);
+  if (sp.i1 != sp.i2) {
+    level_lookup<D, F>(tabs.t[sp.i2] + off, desc.scale[lvl], desc.res[lvl], desc.size[lvl], hashed, xin, b);
+#pragma unroll
+    for (int f = 0; f < F; ++f) a[f] = sp.w1 * h2f(f2h(a[f])) + sp.w2 * h2f(f2h(b[f]));
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) a[f] = h2f(f2h(a[f]));
+  }
+  half_t h[FO];
+#pragma unroll
+  for (int j = 0; j < FO; ++j) {
+    float r = 0.0f;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) r += basis[bb] * a[bb * FO + j];
+    h[j] = f2h(r);
+  }
+  typedef typename std::conditional<FO == 2, uint32_t, unsigned short>::type V;
+  __builtin_nontemporal_store(*reinterpret_cast<V*>(h), reinterpret_cast<V*>(lvlT + ((int64_t)lvl * P + p) * FO));
+}
+
 // Adjoint of the fused time blend + interpT.  Every feature of an entry receives basis[f / FO] * w_slice * Hs[f % FO]
 // where Hs[j] = sum_p go[p][j] * w_corner: only the FO scalars per entry are scattered (4 x fewer atomics at F = 8,
 // 8 x fewer for the two-slice F = 4 case), run-length pre-reduced along the ray, then expanded by a second kernel.
@@ -488,6 +533,35 @@ extern "C" int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc, const float* x, int
   DISPATCH_T(desc->n_dims, desc->n_features, out_is_half, CALL)
 #undef CALL
   L4D_LAUNCH_CHECK("l4d_hashgrid_t_fwd");
+  return 0;
+}
+
+// level-major form (default from 2^18 points on; L4D_FLOW_LEVELS=0: the row kernel, A/B)
+extern "C" int64_t l4d_hashgrid_t_fwd_workspace(const l4d_grid_desc* desc, int64_t P) {
+  return (int64_t)desc->n_levels * P * (desc->n_features / 4) * 2;
+}
+
+extern "C" int l4d_hashgrid_t_fwd_ws(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride,
+                                     const int32_t* cols, const void* const* tables, int32_t n_slices, const float* t,
+                                     void* out, int32_t out_stride, int32_t out_is_half, void* workspace, void* stream) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("L4D_FLOW_LEVELS"); enabled = (e && e[0] == '0') ? 0 : 1; }
+  const int FO = desc->n_features / 4, width = desc->n_levels * FO;
+  const int64_t n_tiles = ceil_div64(P, 256);
+  if (!workspace || !enabled || !out_is_half || P < (1 << 18) || desc->n_features != 8 || desc->n_dims != 3 || width % 8 || out_stride % 8 ||
+      ((uintptr_t)out & 15) || n_tiles * desc->n_levels > 0x7fffffffLL)
+    return l4d_hashgrid_t_fwd(desc, x, P, x_stride, cols, tables, n_slices, t, out, out_stride, out_is_half, stream);
+  if (check_t(desc, n_slices)) return 1;
+  GridDesc g = make_grid_desc(desc);
+  Cols c = make_cols(cols, desc->n_dims);
+  SliceTables tabs;
+  for (int i = 0; i < L4D_MAX_SLICES; ++i) tabs.t[i] = i < n_slices ? (const half_t*)tables[i] : nullptr;
+  L4D_LAUNCH((hashgrid_t_fwd_levels_kernel<3, 8>), dim3((unsigned)(n_tiles * desc->n_levels)), dim3(256), 0, (hipStream_t)stream, g, x, P, x_stride,
+             c, tabs, n_slices, t, n_tiles, (half_t*)workspace);
+  const int lds = HG_ROWS_THREADS * (width + 8) * 2;
+  L4D_LAUNCH((hashgrid_rows_from_levels_kernel<2>), dim3((unsigned)ceil_div64(P, HG_ROWS_THREADS)), dim3(HG_ROWS_THREADS), lds, (hipStream_t)stream,
+             desc->n_levels, P, (const half_t*)workspace, (half_t*)out, out_stride);
+  L4D_LAUNCH_CHECK("l4d_hashgrid_t_fwd_ws");
   return 0;
 }
 

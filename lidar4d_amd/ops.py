@@ -15,10 +15,11 @@ def call(name, *args):
     _lib.call(name, *args)
 
 
-XCD_PINNED_MIN_POINTS = 1 << 20           # stand-alone hash-grid forward: level <-> XCD pinning from here on
+LEVEL_MAJOR_MIN_POINTS = 1 << 20          # stand-alone hash-grid forward: level-major through scratch from here on
 PLANE_ROWS_MIN_POINTS = 1 << 12           # below this the row build (a launch) costs more than the saved taps
 LDS_DYNHASH_MIN_POINTS = 1 << 15          # below this the per-sample direct-gather path wins (table fills dominate)
 BINNED_SCATTER_MIN_RECORDS = 1 << 16  # below this the global-atomic path is cheaper than two extra launches
+FLOW_LEVELS_MIN_POINTS = 1 << 18          # the flow grid level-major through scratch (l4d_hashgrid_t_fwd_ws) from here on
 
 
 def _stream():
@@ -55,7 +56,7 @@ def _ptrs(tensors):
 
 
 # ---- hash grid -----------------------------------------------------------------------------------
-def hashgrid_fwd(meta, x, cols, table16, out=None, out_col=0, xcd_pinned=None):
+def hashgrid_fwd(meta, x, cols, table16, out=None, out_col=0, level_major=None):
     """x [P, S] fp32 (grid coords = columns ``cols``), table16 fp16 flat -> out [P, >= L*F] fp16."""
     _chk(x, torch.float32, "x"), _chk(table16, torch.float16, "table")
     P = x.shape[0]
@@ -63,9 +64,9 @@ def hashgrid_fwd(meta, x, cols, table16, out=None, out_col=0, xcd_pinned=None):
         out = torch.empty(P, meta.n_output_dims, dtype=torch.float16, device=x.device)
     _chk(out, torch.float16, "out")
     d = meta.desc()
-    if xcd_pinned is None:
-        xcd_pinned = P >= XCD_PINNED_MIN_POINTS and max(meta.size) * meta.n_features * 2 >= (2 << 20)
-    if xcd_pinned:  # one level per XCD at a time (its table stays in that XCD's L2), level-major scratch, then rows
+    if level_major is None:
+        level_major = P >= LEVEL_MAJOR_MIN_POINTS and max(meta.size) * meta.n_features * 2 >= (2 << 20)
+    if level_major:  # one level at a time over the whole chip (every L2 holds that level's table), level-major scratch, then rows
         ws = torch.empty(_lib.lib().l4d_hashgrid_fwd_workspace(C.byref(d), P), dtype=torch.uint8, device=x.device)
         call("l4d_hashgrid_fwd_ws", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _p(table16),
              C.c_void_p(out.data_ptr() + 2 * out_col), out.stride(0), _p(ws), _stream())
@@ -97,6 +98,12 @@ def hashgrid_t_fwd(meta, x, cols, tables16, t_dev, out=None, out_col=0, half_out
         out = torch.empty(P, width, dtype=torch.float16 if half_out else torch.float32, device=x.device)
     _chk(out, None, "out")
     d = meta.desc()
+    if P >= FLOW_LEVELS_MIN_POINTS and meta.n_dims == 3 and meta.n_features == 8 and out.dtype == torch.float16:
+        # the flow field's grid on a render batch: level-major through a scratch array (csrc/hashgrid.hip hashgrid_t_fwd_levels_kernel)
+        ws = torch.empty(_lib.lib().l4d_hashgrid_t_fwd_workspace(C.byref(d), P), dtype=torch.uint8, device=x.device)
+        call("l4d_hashgrid_t_fwd_ws", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _ptrs(tables16), len(tables16),
+             _p(t_dev), C.c_void_p(out.data_ptr() + out.element_size() * out_col), out.stride(0), 1, _p(ws), _stream())
+        return out
     call("l4d_hashgrid_t_fwd", C.byref(d), _p(x), P, x.stride(0), _i32s(list(cols)), _ptrs(tables16), len(tables16),
          _p(t_dev), C.c_void_p(out.data_ptr() + out.element_size() * out_col), out.stride(0),
          int(out.dtype == torch.float16), _stream())

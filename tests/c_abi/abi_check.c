@@ -52,6 +52,8 @@ int main(void) {
       (fn_t)&l4d_hashgrid_t_bwd,
       (fn_t)&l4d_hashgrid_t_bwd_workspace,
       (fn_t)&l4d_hashgrid_t_fwd,
+      (fn_t)&l4d_hashgrid_t_fwd_workspace,
+      (fn_t)&l4d_hashgrid_t_fwd_ws,
       (fn_t)&l4d_last_error,
       (fn_t)&l4d_lidar_to_pano,
       (fn_t)&l4d_lidar_to_pano_workspace,

@@ -138,6 +138,7 @@ def test_bench_multi_rank_launch_plumbing(tmp_path):
     assert len(lines[0]) < 4096  # what the driver can parse
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["rccl_ranks_seen"] == 2  # the size of the process group the ranks really formed, next to the requested n_gpus
     # more ranks than devices: refused loudly, nothing that looks like a result on stdout
     env["L4D_BENCH_FAKE_GPUS"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
