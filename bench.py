@@ -108,6 +108,7 @@ def kernel_models(model, P, M):
     lds_alg = 2 * 3 * (2 * L * 4 * 8)                                            # xz, yz stacks x 3 frames
     X = 2 * in_pad
     m = {}
+    fl = lambda pad, nh: 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
     # gathers always issued: static grid 8 corners + current-frame xy stack 4 corners per level; the two warped frames' 4 + 4 are
     # issued only where the warped point leaves the current point's cell (all reused while the flow is zero, as at initialisation)
     enc = dict(bound="fabric", bytes=enc_alg * P, hbm=(16 + 32 + X + 2 * 2 * L) * P, gathers=(L * 8 + L * 4) * P,
@@ -120,6 +121,10 @@ def kernel_models(model, P, M):
     # the xy stack and takes the static grid's columns from the pre-pass
     m["density_encode_fwd_kernel<true, true, 0, 1>"] = dict(bound="fabric", bytes=(enc_alg - L * 8 * 8) * P, hbm=(16 + 32 + X + 2 * 2 * L + 8 * L) * P, gathers=L * 4 * P,
                                                            note="planes + xy dynamic hash gathers; static-grid columns read from the level-major pre-pass (8 B per level); row staged in LDS, written once")
+    m["density_encode_fwd_kernel<true, true, 0, 1, true>"] = dict(
+        bound="fabric", bytes=(enc_alg - L * 8 * 8) * P, hbm=(16 + 32 + X + 2 * 2 * L + 8 * L + 32 + 4) * P, gathers=L * 4 * P, flops=fl(in_pad, nh_s) * P,
+        note="planes + xy dynamic hash gathers, static-grid columns from the level-major pre-pass, row staged in LDS and written once, AND the density "
+             "network's forward pass on the staged rows as epilogue (y + sigma out; the hidden activations are recomputed by the backward)")
     hs_lv = dict(bound="fabric", bytes=L * 8 * 8 * P, hbm=(L * 12 + L * 8) * P, gathers=L * 8 * P,
                  note="static 3-D grid, one level at a time chip-wide (every L2 holds that level's 4 MB table): 8 corners x 8 B per level; "
                       "x-neighbour pairs in one 16-byte load where aligned (6 address slots per level instead of 8)")
@@ -132,12 +137,13 @@ def kernel_models(model, P, M):
     m["dynhash_fwd_lds_kernel"] = dict(bound="lds", bytes=lds_alg * P, hbm=(2 * L * 16 + 2 * 2 * L) * P,
                                        note="xz / yz HashGridT stacks from LDS-resident slice tables; one streaming pass of xt / flow per (plane, level)")
     m["hashgrid_t_fwd_kernel<3, 8, true>"] = dict(bound="fabric", bytes=Lf * 8 * 16 * P, hbm=(Lf * 16 + 2 * Lf * 2) * P, gathers=Lf * 8 * P, note="flow grid + interpT")
-    fl = lambda pad, nh: 2 * (pad * 64 + (nh - 1) * 64 * 64 + 64 * 16)
     it_s, nf = in_pad // 16, model.flow_net.n_hidden
     # sigma network: x + y + saved activations; backward also writes dx
     m[f"mlp_fwd_kernel<{it_s}, {nh_s}>"] = dict(bound="hbm", bytes=(X + 32 + 4 + nh_s * 128) * P, flops=fl(in_pad, nh_s) * P, note="x + y + sigma (exp epilogue) + saved activations")
     m[f"mlp_bwd_kernel<{it_s}, {nh_s}, 0, {it_s}, true>"] = dict(bound="hbm", bytes=(X + nh_s * 128 + 32 + X) * P, flops=2 * fl(in_pad, nh_s) * P,
                                                                note="x + activations + dy read, dx written (algorithmic flops: dX + dW)")
+    m[f"mlp_bwd_kernel<{it_s}, {nh_s}, 0, {it_s}, true, true>"] = dict(bound="hbm", bytes=(X + 32 + X) * P, flops=3 * fl(in_pad, nh_s) * P,
+                                                                     note="x + dy read, dx written; hidden activations recomputed (algorithmic flops: fwd + dX + dW)")
     # flow network: activations are recomputed in the backward, not stored
     m[f"mlp_fwd_kernel<1, {nf}>"] = dict(bound="hbm", bytes=(32 + 32) * P, flops=fl(16, nf) * P, note="x in, y out (no activations stored)")
     m[f"mlp_bwd_kernel<1, {nf}, 0, 1, true, true>"] = dict(bound="hbm", bytes=(32 + 32 + 32) * P, flops=3 * fl(16, nf) * P,

@@ -305,6 +305,14 @@ int64_t l4d_density_encode_fwd_workspace(const l4d_field_desc* f /*host*/, int64
 int l4d_density_encode_fwd(const l4d_field_desc* f /*host*/, const float* xt, const void* flow16,
                            const float* tinfo, int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows,
                            void* stream);
+/* l4d_density_encode_fwd followed by the density network's forward pass l4d_mlp_fwd_sigma(X, ...) (model/lidar4d.py:181-186) as ONE
+ * call: sigma_weights = the network's fp16 weights (W1 [64, in_pad] | hidden [64, 64] x (n_hidden - 1) | Wo [16, 64]), y [P, 16] fp16,
+ * act [n_hidden, P, 64] fp16 or null, sigma [P] fp32 = exp(y[:, 0]).  For the default shape (in_pad 128, one hidden layer) behind the
+ * level-major encode the network runs as the encode kernel's epilogue on the rows it holds in LDS (bit-identical outputs; X is still
+ * written); every other shape runs the two launches. */
+int l4d_density_encode_sigma_fwd(const l4d_field_desc* f /*host*/, const float* xt, const void* flow16, const float* tinfo,
+                                 int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows,
+                                 const void* sigma_weights, int32_t n_hidden, void* y, void* act, float* sigma, void* stream);
 /* Adjoint.  dX [P,in_pad] fp16 (loss-scaled); parameter gradients are accumulated multiplied by param_scale
  * (= 1/loss_scale); dflow16 [P,16] fp16 stays in dX's scaled domain.  plane_abs_max: device fp32 = max |plane
  * parameter| (bounds the fixed-point LDS accumulators); samples_per_ray: T when the P rows are rays x T samples in

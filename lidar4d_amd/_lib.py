@@ -93,6 +93,7 @@ SIGNATURES = {
     "l4d_sigma_bwd_rows": [P, P, I64, F32, P, P],
     "l4d_time_setup": [P, I32, P, P],
     "l4d_density_encode_fwd": [FD, P, P, P, I64, P, I32, P, P, P],
+    "l4d_density_encode_sigma_fwd": [FD, P, P, P, I64, P, I32, P, P, P, I32, P, P, P, P],
     "l4d_plane_rows_workspace": [FD],
     "l4d_density_encode_fwd_workspace": [FD, I64],
     "l4d_density_encode_bwd": [FD, FG, P, P, P, I64, P, I32, F32, P, I32, P, P, P, P, I32, P],

@@ -7,6 +7,7 @@
 //
 // This is the direct-gather formulation (every table entry is fetched through L1/L2).
 #include "field_dev.h"
+#include "mlp_dev.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -68,22 +69,57 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 // (Measured and removed: the xy stack through a level-major pre-pass of its own as well -- its tables are 512 KB per level, so the
 // pre-pass hit L2 always, but took 2.18 ms where the same lookups cost this kernel 1.34: here their address-path time hides behind
 // the plane arithmetic; step 31.65 -> 32.58 ms, profiles/r05_experiment_runs.txt session s5.)
-template <bool USE_HDT, bool ROWS, int PART = 0, int HSMODE = 0>
-__global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
+// SIGMA (round 5): the density network's forward pass (tcnn FullyFusedMLP 128 -> 64 -> 16, lidar4d.py:83-93,181; trunc_exp on column 0)
+// runs as this kernel's epilogue on the rows it has just staged in LDS -- the operand layout, the fragment order and the order of
+// the accumulation are mlp_fwd_kernel<8, 1>'s, so y / act / sigma are bit-identical to the two-kernel path -- instead of a separate
+// launch that reads the 3.2 GB row matrix back (1.05 ms at 12.6 M samples).  X is still written: the backward pass reads it.
+// The whole 128-column row is staged at once (272-byte pitch) next to the 18 weight fragments (18 KB, shared by the workgroup): eight
+// wavefronts per workgroup, one workgroup per CU (154 KB of LDS) = the two wavefronts per SIMD the registers allow anyway; the
+// wavefronts only ever touch their own rows, so staging and copy-out synchronise per wavefront, not per workgroup.
+#define ENC_SIGMA_THREADS 512
+#define ENC_SIGMA_FRAGS 18
+struct SigmaOut {
+  const half_t* w;  // W1 [64, 128] | Wo [16, 64] fp16
+  half_t* y;        // [P, 16]
+  half_t* act;      // [P, 64] or null
+  float* sigma;     // [P]
+};
+template <bool USE_HDT, bool ROWS, int PART = 0, int HSMODE = 0, bool SIGMA = false>
+__global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
                                                                         const float* __restrict__ tinfo, int64_t P,
                                                                         const half_t* __restrict__ hdT,
                                                                         half_t* __restrict__ X, int in_pad, PlaneRows prows,
-                                                                        const half_t* __restrict__ hsT) {
+                                                                        const half_t* __restrict__ hsT, SigmaOut so) {
   constexpr int C = 8;
+  static_assert(!SIGMA || PART == 0, "the network epilogue needs the whole row");
   // the row is staged and written out in two parts (planes | everything else) so that the staging buffer is half as
-  // large: LDS is what limits this kernel's occupancy (gather latency needs waves in flight)
-  extern __shared__ __attribute__((aligned(16))) half_t stage[];  // [ENC_THREADS][max(part) + 8]
+  // large: LDS is what limits this kernel's occupancy (gather latency needs waves in flight).  (SIGMA: the whole row at once.)
+  extern __shared__ __attribute__((aligned(16))) half_t stage_all[];  // (SIGMA: 18 weight fragments, then) [threads][pitch]
+  half_t* stage = stage_all + (SIGMA ? ENC_SIGMA_FRAGS * 64 * 8 : 0);
   const int colsA = 2 * fd.planes.n_scales * C;
-  const int ENC_PITCH = max(colsA, in_pad - colsA) + 8;  // halfs per staged row: 16-byte aligned, spreads rows over the banks
+  const int ENC_PITCH = (SIGMA ? in_pad : max(colsA, in_pad - colsA)) + 8;  // halfs per staged row: 16-byte aligned, spreads rows over the banks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t blk_p0 = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x;
   if (blk_p0 >= P) return;  // idle tile of the rounded-up grid (block-uniform)
+  if (SIGMA) {  // weight fragments of mlp_fwd_kernel<8, 1>: 16 of the hidden layer (4 neuron tiles x 4 k-steps), 2 of the output layer
+    const int i = lane & 15, g = lane >> 4;
+    for (int f = wave; f < ENC_SIGMA_FRAGS; f += ENC_SIGMA_THREADS / 64) {
+      const h8 v = f < 16 ? build_frag(so.w, HID, 128, 0, perm_row(f >> 2, i), 32 * (f & 3) + 8 * g)
+                          : build_frag(so.w + HID * 128, 16, HID, 0, i, 32 * (f - 16) + 8 * g);
+      reinterpret_cast<uint4*>(stage_all)[f * 64 + lane] = *reinterpret_cast<const uint4*>(&v);
+    }
+    __syncthreads();
+  }
+  // a wavefront reads back only rows its own lanes staged: (SIGMA) wait for the wavefront's LDS writes instead of a workgroup barrier
+  auto stage_sync = [&]() {
+    if (SIGMA) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      __syncthreads();
+    }
+  };
   const int64_t wave_p0 = blk_p0 + wave * 64;
   const int64_t pr = wave_p0 + lane;
   const int64_t p = pr < P ? pr : P - 1;
@@ -131,13 +167,13 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
       if (grow < P) *reinterpret_cast<uint4*>(X + grow * in_pad + c0 + c * 8) = *reinterpret_cast<const uint4*>(wstage + r * ENC_PITCH + c * 8);
     }
   };
-  if (PART != 2) {
+  if (PART != 2 && !SIGMA) {
     __syncthreads();
     copy_out(0, colsA);
     if (PART == 1) return;
     __syncthreads();
   }
-  row -= colsA;  // the second part is staged from column 0 again
+  if (!SIGMA) row -= colsA;  // the second part is staged from column 0 again
   int col = colsA;
 
   // ---- static 3-D hash grid (hash_field.py:141-144) ----
@@ -216,8 +252,46 @@ __global__ void __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_waves_per_e
   }
   for (; col < in_pad; ++col) row[col] = (half_t)1.0f;  // tcnn pads the network input with ones
 
-  __syncthreads();  // rows complete (and visible) before the cooperative copy-out
-  copy_out(colsA, in_pad - colsA);
+  stage_sync();  // rows complete (and visible) before the cooperative copy-out
+  if (!SIGMA) {
+    copy_out(colsA, in_pad - colsA);
+    return;
+  }
+  copy_out(0, in_pad);
+  // ---- density network on the staged rows: mlp_fwd_kernel<8, 1>'s chain, four tiles of 16 rows per wavefront ----
+  const int i = lane & 15, g = lane >> 4;
+  auto FR = [&](int f) -> h8 { const uint4 u = reinterpret_cast<const uint4*>(stage_all)[f * 64 + lane]; return *reinterpret_cast<const h8*>(&u); };
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    const half_t* xr = wstage + (16 * t + i) * ENC_PITCH + 8 * g;
+    h8 xb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xb[ks] = *reinterpret_cast<const h8*>(xr + 32 * ks);
+    f4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      acc[mt] = f4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc[mt] = MFMA(FR(mt * 4 + ks), xb[ks], acc[mt]);
+    }
+    const h8 hb0 = relu_pack(acc[0], acc[1]), hb1 = relu_pack(acc[2], acc[3]);
+    const int64_t orow = wave_p0 + 16 * t + i;
+    const bool ok = orow < P;
+    if (so.act && ok) {
+      *reinterpret_cast<h8*>(so.act + orow * HID + 8 * g) = hb0;
+      *reinterpret_cast<h8*>(so.act + orow * HID + 32 + 8 * g) = hb1;
+    }
+    f4 o = f4{0, 0, 0, 0};
+    o = MFMA(FR(16), hb0, o);
+    o = MFMA(FR(17), hb1, o);
+    if (ok) {
+      h4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = f2h(clamp_h(o[r]));
+      *reinterpret_cast<h4*>(so.y + orow * 16 + 4 * g) = ov;
+      if (g == 0) so.sigma[orow] = expf(h2f(ov[0]));
+    }
+  }
 }
 
 // ---- dynamic hash, forward, with LDS-resident slice tables ---------------------------------------------------
@@ -459,8 +533,18 @@ extern "C" int64_t l4d_plane_rows_workspace(const l4d_field_desc* f) {
   return n * (int64_t)sizeof(float);
 }
 
-extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, const void* flow16, const float* tinfo,
-                                      int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows, void* stream) {
+extern "C" int l4d_mlp_fwd_sigma(const void* x, int64_t P, int32_t in_pad, int32_t n_hidden, const void* weights, void* y, void* act,
+                                 float* sigma, void* stream);
+// density network inside the encode kernel (default; L4D_ENC_SIGMA=0: a launch of its own behind it, A/B)
+static int enc_sigma_fused() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("L4D_ENC_SIGMA"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+// so: null, or where the density network's forward pass (n_hidden hidden layers) puts its outputs
+static int encode_fwd_impl(const l4d_field_desc* f, const float* xt, const void* flow16, const float* tinfo,
+                           int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows, void* stream,
+                           const SigmaOut* so, int n_hidden) {
   if (P == 0) return 0;
   FieldDesc d;
   if (make_field(f, d)) return 1;
@@ -511,13 +595,21 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
   const int enc_lds = ENC_THREADS * (std::max(colsA, in_pad - colsA) + 8) * 2;
 #define ENC_LAUNCH(HDT, ROWS, PART)                                                                                         \
   L4D_LAUNCH((density_encode_fwd_kernel<HDT, ROWS, PART>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,                \
-             (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr)
-  if (hs_pre) {
+             (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr, no_sigma)
+  const SigmaOut no_sigma{nullptr, nullptr, nullptr, nullptr};
+  // the density network as the kernel's epilogue: the default network shape behind the level-major form of the encode
+  const bool sigma_fused = so && hs_pre && in_pad == 128 && n_hidden == 1 && enc_sigma_fused();
+  if (sigma_fused) {
+    const int lds = ENC_SIGMA_FRAGS * 1024 + ENC_SIGMA_THREADS * (in_pad + 8) * 2;
+    (void)hipFuncSetAttribute((const void*)density_encode_fwd_kernel<true, true, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 1, true>), dim3((unsigned)xcd_grid(ceil_div64(P, ENC_SIGMA_THREADS))), dim3(ENC_SIGMA_THREADS), lds,
+               main_s, d, xt, (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT, *so);
+  } else if (hs_pre) {
     L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 1>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
-               (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT);
+               (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT, no_sigma);
   } else if (!split && hd_scratch && plane_rows && l4d_hs_pairld()) {
     L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 2>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
-               (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr);
+               (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr, no_sigma);
   } else if (split) {  // plane columns while the side stream evaluates the xz / yz stacks, then the hash columns
     if (plane_rows) ENC_LAUNCH(true, true, 1);
     else ENC_LAUNCH(true, false, 1);
@@ -530,5 +622,22 @@ extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, 
   else ENC_LAUNCH(false, false, 0);
 #undef ENC_LAUNCH
   L4D_LAUNCH_CHECK("l4d_density_encode_fwd");
+  if (so && !sigma_fused)  // other shapes / paths: the network as a launch of its own on the rows just written
+    return l4d_mlp_fwd_sigma(X, P, in_pad, n_hidden, so->w, so->y, so->act, so->sigma, stream);
   return 0;
+}
+
+extern "C" int l4d_density_encode_fwd(const l4d_field_desc* f, const float* xt, const void* flow16, const float* tinfo,
+                                      int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows, void* stream) {
+  return encode_fwd_impl(f, xt, flow16, tinfo, P, X, in_pad, hd_scratch, plane_rows, stream, nullptr, 0);
+}
+
+// l4d_density_encode_fwd + l4d_mlp_fwd_sigma (the density network, lidar4d.py:181-186) in one call: for the default network shape
+// (128 -> 64 -> 16) behind the level-major encode the network runs as the encode kernel's epilogue on the rows in LDS
+extern "C" int l4d_density_encode_sigma_fwd(const l4d_field_desc* f, const float* xt, const void* flow16, const float* tinfo,
+                                            int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows,
+                                            const void* sigma_weights, int32_t n_hidden, void* y, void* act, float* sigma, void* stream) {
+  if (!sigma_weights || !y || !sigma) { l4d_set_error(1, "l4d_density_encode_sigma_fwd: weights / y / sigma is null"); return 1; }
+  const SigmaOut so{(const half_t*)sigma_weights, (half_t*)y, (half_t*)act, sigma};
+  return encode_fwd_impl(f, xt, flow16, tinfo, P, X, in_pad, hd_scratch, plane_rows, stream, &so, n_hidden);
 }

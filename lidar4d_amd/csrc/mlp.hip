@@ -27,74 +27,7 @@
 #include "common.h"
 #include "wave_dev.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-#define HID 64
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ int perm_row(int mt, int i) { return 32 * (mt >> 1) + 8 * (i >> 2) + 4 * (mt & 1) + (i & 3); }
-
-// ---- fragment construction (once per block, into LDS) -----------------------------------------
-// value(row, k) of an A/B fragment: lane (i, g), element e -> k = 32*ks + 8g + e
-// kind 0: W[row_of(i)][k]          (forward A: rows = neurons of this layer, k = its inputs)
-// kind 1: W[k][row_of(i)]          (W^T: rows = inputs of the layer, k = its neurons)
-// cperm >= 0 (the attribute networks fed from AttrSrc): the kernel's PHYSICAL input column order differs from the weight
-// matrix' logical one so that the geo features can be taken from the sigma network's output row [h0, g0 .. g14] with two
-// aligned 16-byte loads: physical column cperm carries the constant 1.0 (logical column cperm + 15, the first padding
-// column), physical cperm + 1 .. cperm + 15 carry g0 .. g14 (logical cperm .. cperm + 14); all other columns coincide.
-__device__ __forceinline__ int col_map(int c, int cperm) {
-  if (cperm < 0 || c < cperm || c >= cperm + 16) return c;
-  return c == cperm ? cperm + 15 : c - 1;
-}
-__device__ __forceinline__ h8 build_frag(const half_t* __restrict__ W, int R, int Cw, int kind, int row, int kbase, int cperm = -1) {
-  h8 v;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = kbase + e;
-    float x = 0.0f;
-    if (kind == 0) {
-      if (row < R && k < Cw) x = h2f(W[row * Cw + col_map(k, cperm)]);
-    } else {
-      if (k < R && row < Cw) x = h2f(W[k * Cw + col_map(row, cperm)]);
-    }
-    v[e] = f2h(x);
-  }
-  return v;
-}
-
-__device__ __forceinline__ h8 ident_frag(int lane, int half_sel) {
-  const int j = lane & 15, g = lane >> 4;
-  h8 v;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (8 * g + e == 16 * half_sel + j) ? (half_t)1.0f : (half_t)0.0f;
-  return v;
-}
-
-__device__ __forceinline__ h8 relu_pack(const f4& lo, const f4& hi) {
-  h8 v;
-  // Convert first, then ONE packed fp16 maximum per pair (v_cvt_pk_f16_f32 + v_pk_max_f16: half the instructions of eight
-  // v_max_f32 + four conversions; same values: rounding is monotone and keeps zero).  Measured over the step's MLP kernels:
-  // -0.30 ms (gpurun_out/r4j).  The integer form (max of the bit patterns as int16) made the compiler split the conversions
-  // again and lost most of that (r4k).  A result of -0 (from a tiny negative input) is possible here; every consumer compares
-  // "> 0" as a float, for which it is a zero.
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 z = {(half_t)0.0f, (half_t)0.0f};
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    h2 a = {f2h(lo[2 * q]), f2h(lo[2 * q + 1])}, b = {f2h(hi[2 * q]), f2h(hi[2 * q + 1])};
-    a = __builtin_elementwise_max(a, z);
-    b = __builtin_elementwise_max(b, z);
-    v[2 * q] = a[0]; v[2 * q + 1] = a[1];
-    v[4 + 2 * q] = b[0]; v[4 + 2 * q + 1] = b[1];
-  }
-  return v;
-}
-
-// (ReLU masks of the backward as bit-pattern operations on the packed halfs: measured mixed -- attribute backward 2.82 -> 2.71 ms, flow
-// backward 1.26 -> 1.30 -- because the compiler turns them back into compares; removed in round 5.)
-__device__ __forceinline__ float clamp_h(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
+#include "mlp_dev.h"
 
 // Input rows of the attribute networks assembled on the fly (model/lidar4d.py:196-213: row j of the work list =
 // [frequency encoding of the ray direction (n_enc) | geo_feat of sample idx[j] = h[:, 1 : 1 + n_geo] | ones]) instead of
@@ -950,10 +883,10 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
                (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1}, no_epi, dstat);    \
     done = true;                                                                                                     \
   }
-  X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3)  // <8, 1>: measured neutral; <6, 2> and wider / deeper spill registers
+  X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3) X(8, 1)  // <8, 1> (the density network): measured neutral in round 2, again in round 5 (L4D_MLP_RECOMP_SIGMA=1); <6, 2> and wider / deeper spill registers
 #undef X
   if (!done && !act) {
-    l4d_set_error(1, "l4d_mlp_bwd: act == null (recompute the activations) is only built for in_pad <= 32");
+    l4d_set_error(1, "l4d_mlp_bwd: act == null (recompute the activations) is only built for in_pad <= 32 and for the 128 -> 64 -> 16 shape");
     return 1;
   }
 #define X(IT, NHH)                                                                                                   \

@@ -117,10 +117,11 @@ class RenderFn(torch.autograd.Function):
 
         # density (lidar4d.py:139-188)
         fd = _field_desc(model)
-        X = ops.density_encode_fwd(fd, xt, flow16, tinfo, model.sigma_net.in_pad)
-        # density network with its activation (trunc_exp, activation.py:6-20) as epilogue
-        h, act_s, sigma = ops.mlp_fwd_sigma(X, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,
-                                            save_act=train and not ops.mlp_recompute_supported(X.shape[1], model.sigma_net.n_hidden_layers))
+        # ... and the density network with its activation (trunc_exp, activation.py:6-20) in the same call: for the default shape it
+        # runs as the encode kernel's epilogue on the rows in LDS (csrc/fused.hip SIGMA)
+        sn = model.sigma_net
+        X, h, act_s, sigma = ops.density_encode_fwd(fd, xt, flow16, tinfo, sn.in_pad, sigma_weights16=store.half(sn.params), n_hidden=sn.n_hidden_layers,
+                                                    save_act=train and not ops.mlp_recompute_supported(sn.in_pad, sn.n_hidden_layers))
 
         # compositing + mask compaction (renderer.py:98-110)
         weights, wsum, depth, _, idx, count = ops.composite_fwd(sigma, z_vals, sample_dist, model.density_scale,

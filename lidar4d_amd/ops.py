@@ -202,10 +202,16 @@ def mlp_fwd(x16, weights16, n_hidden, save_act=True, n_rows=None, y=None, act=No
 def mlp_recompute_supported(in_pad, n_hidden):
     """Shapes for which l4d_mlp_bwd recomputes the hidden activations itself (act = None), so that the forward does not store
     them: narrow inputs (the flow network: 32-byte rows against 256 B of activations; measured forward 1.11 -> 0.33 ms,
-    backward 1.64 -> 1.41 ms at 12.6 M rows).  For the 128-wide sigma network the same trade was measured neutral (forward
-    0.91 -> 0.67 ms, backward 1.93 -> 2.13 ms) and wider / deeper shapes spill registers, so those keep their activations."""
+    backward 1.64 -> 1.41 ms at 12.6 M rows) and, since round 5, the 128 -> 64 -> 16 density network (round 2 had measured that
+    trade neutral, forward 0.91 -> 0.67 ms, backward 1.93 -> 2.13 ms; with today's kernels it is -0.17 ms per step).  Wider / deeper
+    shapes spill registers and keep their activations."""
     if os.environ.get("L4D_MLP_STORE_ACT") == "1":  # tuning: store the activations after all
         return False
+    if in_pad == 128 and n_hidden == 1:
+        # the density network (round 5): its forward runs as the encode kernel's epilogue and stores 128 B less per sample, the backward
+        # reads 128 B less and recomputes the hidden layer from the row it reads anyway: 32.08 -> 31.91 ms per step (gpurun_out/s6;
+        # L4D_MLP_RECOMP_SIGMA=0: store them, A/B)
+        return os.environ.get("L4D_MLP_RECOMP_SIGMA") != "0"
     return in_pad <= 32 and 1 <= n_hidden <= 3
 
 
@@ -404,7 +410,10 @@ def time_setup(t_dev, num_frames, tinfo=None):
     return tinfo
 
 
-def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
+def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None, sigma_weights16=None, n_hidden=0, save_act=True):
+    """-> X [P, in_pad] fp16.  With ``sigma_weights16`` (the density network's fp16 weights): -> (X, y [P,16] fp16, act or None,
+    sigma [P] fp32) = the rows AND ``mlp_fwd_sigma`` of them in one call (l4d_density_encode_sigma_fwd: for the default network
+    shape the network runs inside the encode kernel)."""
     _chk(xt, torch.float32, "xt"), _chk(flow16, torch.float16, "flow16"), _chk(tinfo, torch.float32, "tinfo")
     P = xt.shape[0]
     if X is None:
@@ -416,6 +425,14 @@ def density_encode_fwd(field_desc, xt, flow16, tinfo, in_pad, X=None):
     rows = None
     if P >= PLANE_ROWS_MIN_POINTS:  # time planes through per-call 1-D rows (two taps instead of four)
         rows = torch.empty(_lib.lib().l4d_plane_rows_workspace(C.byref(field_desc)) // 4, dtype=torch.float32, device=xt.device)
+    if sigma_weights16 is not None:
+        _chk(sigma_weights16, torch.float16, "sigma weights")
+        y = torch.empty(P, 16, dtype=torch.float16, device=xt.device)
+        act = torch.empty(n_hidden, P, 64, dtype=torch.float16, device=xt.device) if save_act else None
+        sigma = torch.empty(P, dtype=torch.float32, device=xt.device)
+        call("l4d_density_encode_sigma_fwd", C.byref(field_desc), _p(xt), _p(flow16), _p(tinfo), P, _p(X), in_pad, _p(scratch), _p(rows),
+             _p(sigma_weights16), int(n_hidden), _p(y), _p(act), _p(sigma), _stream())
+        return X, y, act, sigma
     call("l4d_density_encode_fwd", C.byref(field_desc), _p(xt), _p(flow16), _p(tinfo), P, _p(X), in_pad, _p(scratch), _p(rows), _stream())
     return X
 

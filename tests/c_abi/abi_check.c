@@ -39,6 +39,7 @@ int main(void) {
       (fn_t)&l4d_density_encode_bwd,
       (fn_t)&l4d_density_encode_bwd_workspace,
       (fn_t)&l4d_density_encode_fwd,
+      (fn_t)&l4d_density_encode_sigma_fwd,
       (fn_t)&l4d_density_encode_fwd_workspace,
       (fn_t)&l4d_dyn_pairs_build,
       (fn_t)&l4d_field_width,

@@ -202,3 +202,51 @@ def test_c5_full_frame_inference(big):
         np.testing.assert_allclose(got.cpu().numpy(), brute.cpu().numpy(), rtol=1e-4, atol=1e-7)
     finally:
         model.train(was_training)
+
+
+def test_encode_with_network_epilogue_equals_two_launches(big):
+    """csrc/fused.hip SIGMA: the density network run as the encode kernel's epilogue (rows in LDS, l4d_density_encode_sigma_fwd) gives
+    the same X, y, hidden activations and sigma -- bit for bit -- as l4d_density_encode_fwd followed by l4d_mlp_fwd_sigma on the
+    rows read back (same fragments, same accumulation order), at a size where the level-major form of the encode runs, with a
+    ragged last workgroup (P not a multiple of 512), for a frame with both neighbours and for the first frame."""
+    from lidar4d_amd import ops
+    from lidar4d_amd.fused import _field_desc
+    model, data = big
+    store, sn = model._store, model.sigma_net
+    fd = _field_desc(model)
+    w16 = store.half(sn.params)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    P = 700 * T + 77
+    xt = torch.rand(P, 4, device=DEV, generator=g)
+    flow16 = ((torch.rand(P, 16, device=DEV, generator=g) - 0.5) * 0.01).half()
+    for frame in (20, 0):
+        t_dev = torch.tensor([frame / 50.0], device=DEV)
+        xt[:, 3] = t_dev
+        tinfo = ops.time_setup(t_dev, model.num_frames)
+        X1 = ops.density_encode_fwd(fd, xt, flow16, tinfo, sn.in_pad)
+        y1, a1, s1 = ops.mlp_fwd_sigma(X1, w16, sn.n_hidden_layers, save_act=True)
+        X2, y2, a2, s2 = ops.density_encode_fwd(fd, xt, flow16, tinfo, sn.in_pad, sigma_weights16=w16, n_hidden=sn.n_hidden_layers, save_act=True)
+        assert torch.equal(X1, X2) and torch.equal(y1, y2) and torch.equal(a1, a2) and torch.equal(s1, s2)
+        assert bool(torch.isfinite(s2).all()) and float(y2.float().abs().sum()) > 0
+        X3, y3, a3, s3 = ops.density_encode_fwd(fd, xt, flow16, tinfo, sn.in_pad, sigma_weights16=w16, n_hidden=sn.n_hidden_layers, save_act=False)
+        assert a3 is None and torch.equal(y1, y3) and torch.equal(s1, s3)
+
+
+def test_level_major_flow_grid_equals_row_kernel(big):
+    """l4d_hashgrid_t_fwd_ws (the flow field's grid, one level at a time over the whole chip through a level-major scratch array)
+    == l4d_hashgrid_t_fwd (one thread per (point, level) writing into the rows), bit for bit, at a ragged size."""
+    from lidar4d_amd import _lib, ops
+    import ctypes as C
+    model, _ = big
+    fn, store = model.flow_net, model._store
+    g = torch.Generator(device=DEV).manual_seed(5)
+    P = (1 << 18) + 333
+    xt = torch.rand(P, 4, device=DEV, generator=g)
+    t_dev = torch.tensor([0.37], device=DEV)
+    grid16 = store.half(fn.grid_enc.params)
+    a = ops.hashgrid_t_fwd(fn.grid_enc.meta, xt, (0, 1, 2), [grid16], t_dev, half_out=True)        # P >= 2^18: level-major
+    b = torch.empty_like(a)
+    d = fn.grid_enc.meta.desc()
+    ops.call("l4d_hashgrid_t_fwd", C.byref(d), ops._p(xt), P, xt.stride(0), ops._i32s([0, 1, 2]), ops._ptrs([grid16]), 1, ops._p(t_dev),
+             ops._p(b), b.stride(0), 1, ops._stream())
+    assert torch.equal(a, b) and float(a.float().abs().sum()) > 0
