@@ -83,6 +83,7 @@ struct SigmaOut {
   half_t* y;        // [P, 16]
   half_t* act;      // [P, 64] or null
   float* sigma;     // [P]
+  int persistent;   // 1: gridDim.x workgroups (one per CU) whose wavefronts each walk many 64-sample groups (see the kernel)
 };
 template <bool USE_HDT, bool ROWS, int PART = 0, int HSMODE = 0, bool SIGMA = false>
 __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
   const int ENC_PITCH = (SIGMA ? in_pad : max(colsA, in_pad - colsA)) + 8;  // halfs per staged row: 16-byte aligned, spreads rows over the banks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t blk_p0 = xcd_tile(blockIdx.x, gridDim.x) * blockDim.x;
-  if (blk_p0 >= P) return;  // idle tile of the rounded-up grid (block-uniform)
+  if (!(SIGMA && so.persistent) && blk_p0 >= P) return;  // idle tile of the rounded-up grid (block-uniform)
   if (SIGMA) {  // weight fragments of mlp_fwd_kernel<8, 1>: 16 of the hidden layer (4 neuron tiles x 4 k-steps), 2 of the output layer
     const int i = lane & 15, g = lane >> 4;
     for (int f = wave; f < ENC_SIGMA_FRAGS; f += ENC_SIGMA_THREADS / 64) {
@@ -120,7 +121,23 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
       __syncthreads();
     }
   };
-  const int64_t wave_p0 = blk_p0 + wave * 64;
+  // PERSISTENT (SIGMA): the eight wavefronts of a workgroup start together behind the fragment barrier; with one 64-sample group per
+  // wavefront they ran their gather phase and their network / store phase in step, and the launch took as long as encode and network
+  // one after the other (4.98 ms against 3.94 + 1.05).  Here a wavefront walks its own sequence of groups -- XCD x keeps the x-th
+  // contiguous eighth of the samples, as xcd_tile gives it to the one-group form -- with nothing but its own LDS traffic to wait
+  // for, so the wavefronts of a CU drift apart and one's stores overlap another's gathers.
+  const int64_t n_groups = (P + 63) >> 6, gpx = (n_groups + 7) >> 3;  // groups per XCD
+  const int64_t g_step = (int64_t)(gridDim.x >> 3) * (ENC_SIGMA_THREADS / 64);
+  int64_t g_in_xcd = (int64_t)(blockIdx.x >> 3) * (ENC_SIGMA_THREADS / 64) + wave;
+  const bool persistent = SIGMA && so.persistent;
+  for (;; g_in_xcd += g_step) {
+  int64_t wave_p0_ = blk_p0 + wave * 64;
+  if (persistent) {
+    const int64_t grp = (int64_t)(blockIdx.x & 7) * gpx + g_in_xcd;
+    if (g_in_xcd >= gpx || grp >= n_groups) break;  // wave-uniform
+    wave_p0_ = grp << 6;
+  }
+  const int64_t wave_p0 = wave_p0_;
   const int64_t pr = wave_p0 + lane;
   const int64_t p = pr < P ? pr : P - 1;
   const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
@@ -292,6 +309,9 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
       if (g == 0) so.sigma[orow] = expf(h2f(ov[0]));
     }
   }
+  if (!persistent) break;
+  stage_sync();  // this group's reads of the staged rows are done before the next group's rows overwrite them
+  }  // groups of this wavefront
 }
 
 // ---- dynamic hash, forward, with LDS-resident slice tables ---------------------------------------------------
@@ -596,14 +616,24 @@ static int encode_fwd_impl(const l4d_field_desc* f, const float* xt, const void*
 #define ENC_LAUNCH(HDT, ROWS, PART)                                                                                         \
   L4D_LAUNCH((density_encode_fwd_kernel<HDT, ROWS, PART>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,                \
              (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr, no_sigma)
-  const SigmaOut no_sigma{nullptr, nullptr, nullptr, nullptr};
+  const SigmaOut no_sigma{nullptr, nullptr, nullptr, nullptr, 0};
   // the density network as the kernel's epilogue: the default network shape behind the level-major form of the encode
   const bool sigma_fused = so && hs_pre && in_pad == 128 && n_hidden == 1 && enc_sigma_fused();
   if (sigma_fused) {
     const int lds = ENC_SIGMA_FRAGS * 1024 + ENC_SIGMA_THREADS * (in_pad + 8) * 2;
     (void)hipFuncSetAttribute((const void*)density_encode_fwd_kernel<true, true, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 1, true>), dim3((unsigned)xcd_grid(ceil_div64(P, ENC_SIGMA_THREADS))), dim3(ENC_SIGMA_THREADS), lds,
-               main_s, d, xt, (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT, *so);
+    static int persistent = -1, n_cu = 0;
+    if (persistent < 0) {
+      const char* e = getenv("L4D_ENC_PERSISTENT");
+      persistent = (e && e[0] == '0') ? 0 : 1;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
+    }
+    SigmaOut so_l = *so;
+    so_l.persistent = persistent;
+    const unsigned grid = persistent ? (unsigned)(n_cu / 8 * 8) : (unsigned)xcd_grid(ceil_div64(P, ENC_SIGMA_THREADS));  // one workgroup per CU (LDS)
+    L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 1, true>), dim3(grid), dim3(ENC_SIGMA_THREADS), lds,
+               main_s, d, xt, (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT, so_l);
   } else if (hs_pre) {
     L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 1>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
                (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT, no_sigma);
@@ -638,6 +668,6 @@ extern "C" int l4d_density_encode_sigma_fwd(const l4d_field_desc* f, const float
                                             int64_t P, void* X, int32_t in_pad, void* hd_scratch, float* plane_rows,
                                             const void* sigma_weights, int32_t n_hidden, void* y, void* act, float* sigma, void* stream) {
   if (!sigma_weights || !y || !sigma) { l4d_set_error(1, "l4d_density_encode_sigma_fwd: weights / y / sigma is null"); return 1; }
-  const SigmaOut so{(const half_t*)sigma_weights, (half_t*)y, (half_t*)act, sigma};
+  const SigmaOut so{(const half_t*)sigma_weights, (half_t*)y, (half_t*)act, sigma, 0};
   return encode_fwd_impl(f, xt, flow16, tinfo, P, X, in_pad, hd_scratch, plane_rows, stream, &so, n_hidden);
 }
