@@ -125,7 +125,7 @@ def kernel_models(model, P, M):
         bound="fabric", bytes=(enc_alg - L * 8 * 8) * P, hbm=(16 + 32 + X + 2 * 2 * L + 8 * L + 32 + 4) * P, gathers=L * 4 * P, flops=fl(in_pad, nh_s) * P,
         note="planes + xy dynamic hash gathers, static-grid columns from the level-major pre-pass, row staged in LDS and written once, AND the density "
              "network's forward pass on the staged rows as epilogue (y + sigma out; the hidden activations are recomputed by the backward)")
-    hs_lv = dict(bound="fabric", bytes=L * 8 * 8 * P, hbm=(L * 12 + L * 8) * P, gathers=L * 8 * P,
+    hs_lv = dict(bound="fabric", bytes=L * 8 * 8 * P, hbm=(L * 12 + L * 8) * P, gathers=L * 6 * P,  # (address slots: 4 pair loads + a neighbour load on half the lanes)
                  note="static 3-D grid, one level at a time chip-wide (every L2 holds that level's 4 MB table): 8 corners x 8 B per level; "
                       "x-neighbour pairs in one 16-byte load where aligned (6 address slots per level instead of 8)")
     m["hashgrid_fwd_levels_kernel<3, 4, true>"] = m["hashgrid_fwd_levels_kernel<3, 4>"] = hs_lv

@@ -13,7 +13,8 @@ Roofs (all measured on this chip):
           runs beside the VALU -> max of the two.
   hbm     compulsory bytes of the byte model (bench.py kernel_models) / 6.3 TB/s achievable.
   miss    gather kernels: lines that miss an XCD's L2 arrive at 64 G lines/s (TCC_MISS of the traffic file).
-  gather  gather kernels: 292 G lane-loads/s when every line hits.
+  gather  gather kernels: 292 G distinct-address slots/s when every line hits (table-entry gathers only: plane taps not counted).
+  gather+miss  the sum of the two (round 5: they add).
 floor = max of the applicable ones; gap = time - floor.  The sum of the floors is what THIS design (this instruction stream, this
 traffic) could reach if every kernel sat on its roof -- not a lower bound for the problem.
 """
@@ -66,10 +67,14 @@ def main():
         elif "compulsory_hbm_GBps" in r:
             floors["hbm"] = r["compulsory_hbm_GBps"] * 1e9 * r["modelled_launch_ms"] * 1e-3 / HBM * 1e3 * r.get("modelled_launches_per_step", n)
         tv = traf(name)
-        if tv and r.get("bound") == "l2" and tv.get("l2_misses"):
+        if tv and r.get("bound") in ("l2", "fabric") and tv.get("l2_misses"):
             floors["miss"] = tv["l2_misses"] / MISS_LINES * 1e3 * r.get("modelled_launches_per_step", n)
         if "hash_gathers_G_per_s" in r:
             floors["gather"] = r["hash_gathers_G_per_s"] * 1e9 * r["modelled_launch_ms"] * 1e-3 / GATHER * 1e3 * r.get("modelled_launches_per_step", n)
+        if "miss" in floors and "gather" in floors:
+            # round 5: the two ADD -- a line that misses L2 costs the fabric its 128 bytes on top of the gather's slot in the address path
+            # (level-major kernels: time = slots / 292 G/s + misses / 64 G/s to within 10 %, profiles/r05_experiment_runs.txt)
+            floors["gather+miss"] = floors["gather"] + floors["miss"]
         floor = max(floors.values()) if floors else None
         which = max(floors, key=floors.get) if floors else "-"
         rows.append((name, t, floor, which, floors, valu))
