@@ -69,11 +69,19 @@ __device__ __forceinline__ void write_seg_bounds(float* __restrict__ segb, int64
   // lanes of a wave hold consecutive samples starting at a multiple of 64 (callers whose chunks are not whole segments pass
   // segb = nullptr, and a wave that does not start on a segment writes nothing); lanes past P carry the last valid sample
   if (!segb || (lane != 0 && lane != 63) || pr - lane >= P || ((pr - lane) & 63) != 0) return;
-  const int64_t n_seg = (P + 63) >> 6;
-  int64_t seg = pr >> 6;
-  asm volatile("" : "+v"(seg));  // (opaque per call: hoisted out of the caller's sample loop, the three 64-bit addresses cost a scratch slot there)
+  const uint32_t n_seg = (uint32_t)((P + 63) >> 6);  // (3 x n_seg x 8 bytes < 2^32: 3 x 2^26 segments = 1.3e10 samples)
+  // scalar base + a 32-bit byte offset per lane (round 5): as three 64-bit per-lane addresses the loop-invariant part was hoisted out
+  // of the caller's sample loop into register pairs that did not fit -- one of them lived in scratch and came back behind an
+  // s_waitcnt vmcnt(0) inside the loop (12 bytes of scratch in planes_dyn_lds_kernel<true, true>, the only default-path kernel with any)
+  typedef __attribute__((address_space(1))) char GlobalByte;
+  typedef __attribute__((address_space(1))) float GlobalF32;
+  const uint64_t b = reinterpret_cast<uint64_t>(segb);
+  GlobalByte* base = (GlobalByte*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b));
+  uint32_t off = ((uint32_t)(pr >> 6) * 2u + (lane == 63 ? 1u : 0u)) * 4u;
+  asm volatile("" : "+v"(off));  // (opaque per call)
 #pragma unroll
-  for (int a = 0; a < 3; ++a) segb[((int64_t)a * n_seg + seg) * 2 + (lane == 63 ? 1 : 0)] = c4[a];
+  for (int a = 0; a < 3; ++a) *(GlobalF32*)(base + (off + (uint32_t)a * n_seg * 8u)) = c4[a];
 }
 
 #define PREP_THREADS 128
@@ -260,6 +268,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
   half2_t dyn_max = {(half_t)0.0f, (half_t)0.0f};  // PREP: running max |gdynT| over ALL columns (this lane's samples)
   uint32_t dyn_bad = 0u;   // PREP: sticky "saw inf / nan in a dynamic-hash column"
 
+  typedef uint32_t U4 __attribute__((ext_vector_type(4)));
   for (int64_t it = 0; it < n_iter; ++it) {
     const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
     const bool active = pr < hi_p;
@@ -274,7 +283,9 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
     }
     const half_t* row = dX + p * in_pad;
     // pieces 0 .. nS-1: the static planes' gradient columns, nS .. 2 nS - 1: the time planes' (contiguous in the row)
-    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    // (Plain loads on purpose: the row's 16-byte pieces are fetched one per scale and count on the line staying in L1 / L2 in
+    // between; marked non-temporal -- tried in round 5 together with the kernel's other streams -- every piece came over the fabric
+    // again: 3.61 -> 4.37 ms, gpurun_out/s8.)
     U4 piece_next;
     __builtin_memcpy(&piece_next, row + (PREP ? 0 : nS * C), 16);
     auto next_piece = [&](int k) -> U4 {  // hands out piece k (requested one scale ago) and requests piece k + 1

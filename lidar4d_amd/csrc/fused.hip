@@ -140,12 +140,16 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
   const int64_t wave_p0 = wave_p0_;
   const int64_t pr = wave_p0 + lane;
   const int64_t p = pr < P ? pr : P - 1;
-  const float4_t c4 = *reinterpret_cast<const float4_t*>(xt + p * 4);
+  // (round 5) everything this kernel streams -- coordinates, flow, the pre-passes' columns in; the row, the network's outputs out --
+  // is marked non-temporal: 3.8 GB per launch through L2s whose 4 MB the xy stack's slice-pair tables (4 MB) need for themselves
+  typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2_nt __attribute__((ext_vector_type(2)));
+  const float4_t c4 = __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(xt + p * 4));
   const float t0 = tinfo[0], t1 = tinfo[1], t2 = tinfo[2];
   const bool has_fwd = tinfo[3] != 0.0f, has_bwd = tinfo[4] != 0.0f;
   float fl[8];
   {
-    uint4 u = *reinterpret_cast<const uint4*>(flow16 + p * 16);
+    const u32x4_nt u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(flow16 + p * 16));
     const half_t* h = reinterpret_cast<const half_t*>(&u);
 #pragma unroll
     for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
@@ -181,7 +185,8 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     for (int idx = lane; idx < 64 * chunks; idx += 64) {
       const int r = idx / chunks, c = idx - r * chunks;
       const int64_t grow = wave_p0 + r;
-      if (grow < P) *reinterpret_cast<uint4*>(X + grow * in_pad + c0 + c * 8) = *reinterpret_cast<const uint4*>(wstage + r * ENC_PITCH + c * 8);
+      if (grow < P)
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4_nt*>(wstage + r * ENC_PITCH + c * 8), reinterpret_cast<u32x4_nt*>(X + grow * in_pad + c0 + c * 8));
     }
   };
   if (PART != 2 && !SIGMA) {
@@ -221,7 +226,8 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     for (int plane = 0; plane < 3; ++plane) {
       const int L = fd.hd[plane].n_levels;
       if (USE_HDT && plane > 0) {  // xz / yz: evaluated by dynhash_fwd_lds_kernel from LDS-resident slice tables
-        for (int lvl = 0; lvl < L; ++lvl) row[col + lvl] = hdT[(int64_t)(col - col_dyn0 + lvl) * P + p];
+        for (int lvl = 0; lvl < L; ++lvl)
+          row[col + lvl] = __builtin_bit_cast(half_t, __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(hdT) + (int64_t)(col - col_dyn0 + lvl) * P + p));
         col += L;
         continue;
       }
@@ -295,8 +301,8 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     const int64_t orow = wave_p0 + 16 * t + i;
     const bool ok = orow < P;
     if (so.act && ok) {
-      *reinterpret_cast<h8*>(so.act + orow * HID + 8 * g) = hb0;
-      *reinterpret_cast<h8*>(so.act + orow * HID + 32 + 8 * g) = hb1;
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, hb0), reinterpret_cast<u32x4_nt*>(so.act + orow * HID + 8 * g));
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, hb1), reinterpret_cast<u32x4_nt*>(so.act + orow * HID + 32 + 8 * g));
     }
     f4 o = f4{0, 0, 0, 0};
     o = MFMA(FR(16), hb0, o);
@@ -305,8 +311,8 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
       h4 ov;
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov[r] = f2h(clamp_h(o[r]));
-      *reinterpret_cast<h4*>(so.y + orow * 16 + 4 * g) = ov;
-      if (g == 0) so.sigma[orow] = expf(h2f(ov[0]));
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x2_nt, ov), reinterpret_cast<u32x2_nt*>(so.y + orow * 16 + 4 * g));
+      if (g == 0) __builtin_nontemporal_store(expf(h2f(ov[0])), so.sigma + orow);
     }
   }
   if (!persistent) break;
