@@ -643,7 +643,7 @@ static int encode_fwd_impl(const l4d_field_desc* f, const float* xt, const void*
   } else if (hs_pre) {
     L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 1>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
                (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT, no_sigma);
-  } else if (!split && hd_scratch && plane_rows && l4d_hs_pairld()) {
+  } else if (!split && hd_scratch && plane_rows && l4d_hs_pairld() && (reinterpret_cast<uintptr_t>(d.hs_table) & 15) == 0) {
     L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 2>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
                (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr, no_sigma);
   } else if (split) {  // plane columns while the side stream evaluates the xz / yz stacks, then the hash columns

@@ -86,6 +86,20 @@ template <> struct NtVec<2> { typedef uint32_t type; };
 template <> struct NtVec<4> { typedef u32x2_t type; };
 template <> struct NtVec<8> { typedef u32x4_t type; };
 
+// coordinates of point p for the level-major kernels, non-temporal.  The render path's points are rows [x, y, z, t] of four floats:
+// one 16-byte load instead of three 4-byte loads into the same 16 bytes (block-uniform test)
+template <int D>
+__device__ __forceinline__ void load_coords_nt(const float* __restrict__ x, int64_t p, int x_stride, const Cols& cols, float xin[D]) {
+  if (D == 3 && x_stride == 4 && cols.c[0] == 0 && cols.c[1] == 1 && cols.c[2] == 2 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const float4_t v = __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(x) + p);
+#pragma unroll
+    for (int d = 0; d < D; ++d) xin[d] = v[d];
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) xin[d] = __builtin_nontemporal_load(x + p * x_stride + cols.c[d]);
+}
+
 // Level-major evaluation into a scratch array lvlT[level][P][F]; a second, streaming kernel (or the fused encode kernel)
 // assembles rows from it.  A level's table (4 MB at 2^19 entries x 8 B) is as large as one XCD's L2, and a gather costs one
 // 128-byte LINE at whichever boundary it crosses: 264 G lane-loads/s chip-wide = the L2's 34 TB/s when the line is L2-resident,
@@ -119,8 +133,7 @@ __global__ void __launch_bounds__(256) hashgrid_fwd_levels_kernel(GridDesc desc,
   const int64_t p = tile * blockDim.x + threadIdx.x;
   if (p >= P) return;
   float xin[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) xin[d] = __builtin_nontemporal_load(x + p * x_stride + cols.c[d]);
+  load_coords_nt<D>(x, p, x_stride, cols, xin);
   float acc[F];
   level_lookup<D, F, PAIRLD>(table + (size_t)desc.offset[lvl] * F, desc.scale[lvl], desc.res[lvl], desc.size[lvl],
                              (desc.hashed_mask >> lvl) & 1u, xin, acc);
@@ -158,7 +171,9 @@ L4D_INTERNAL int l4d_hashgrid_levels_launch(const GridDesc* g, int n_dims, int n
 #define CALL(D, F)                                                                                                             \
   L4D_LAUNCH((hashgrid_fwd_levels_kernel<D, F>), grid, block, 0, (hipStream_t)stream, *g, x, P, x_stride, c, (const half_t*)table, \
              n_tiles, (half_t*)lvlT, order);
-  if (n_features == 4 && l4d_hs_pairld()) {
+  bool pair_ok = n_features == 4 && l4d_hs_pairld() && (reinterpret_cast<uintptr_t>(table) & 15) == 0;  // 16-byte pairs need a 16-byte aligned table
+  for (int l = 0; l < g->n_levels; ++l) pair_ok = pair_ok && (g->offset[l] & 1u) == 0;                   // ... and levels that start on an even entry
+  if (pair_ok) {
     if (n_dims == 2)
       L4D_LAUNCH((hashgrid_fwd_levels_kernel<2, 4, true>), grid, block, 0, (hipStream_t)stream, *g, x, P, x_stride, c, (const half_t*)table, n_tiles, (half_t*)lvlT, order);
     else
@@ -311,8 +326,7 @@ __global__ void __launch_bounds__(256) hashgrid_t_fwd_levels_kernel(GridDesc des
   float basis[4];
   lagrange4(t, basis);
   float xin[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) xin[d] = __builtin_nontemporal_load(x + p * x_stride + cols.c[d]);
+  load_coords_nt<D>(x, p, x_stride, cols, xin);
   const size_t off = (size_t)desc.offset[lvl] * F;
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   float a[F], b[F];
