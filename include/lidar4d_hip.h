@@ -59,7 +59,8 @@ int l4d_profile_get(int32_t i, const char** name /*host out*/, float* ms /*host 
  * library-owned side streams of the launch stream and join them back before they return (event record + wait only: no host
  * synchronisation, capturable into a hipGraph).  No reference counterpart (PyTorch runs the path on one stream).
  *   l4d_streams_config(mask)  bit 0: forward encode (the xz / yz LDS evaluation next to the plane columns), bit 1: field
- *                             adjoint (sorted scatter | time planes | static planes + dynamic hash).  Default 0 = everything
+ *                             adjoint (sorted scatter | time planes | static planes + dynamic hash), bit 2: the static grid's
+ *                             level-major pre-pass next to the LDS evaluation of the xz / yz stacks.  Default 0 = everything
  *                             on the launch stream (environment L4D_STREAMS overrides): measured on MI355X the overlap buys
  *                             0 +- 0.4 ms of a 40 ms step -- these kernels share their bottlenecks.
  *   l4d_streams_mask()        current setting
@@ -80,9 +81,10 @@ int l4d_side_join(void* into, int32_t i);
 int l4d_hashgrid_fwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
                      const int32_t* cols /*host*/, const void* table, void* out, int32_t out_stride,
                      void* stream);
-/* The same with l4d_hashgrid_fwd_workspace() bytes of device scratch: level l is evaluated by the workgroups that land on XCD
- * l % 8 (each XCD's L2 then holds one level's table instead of all of them), level-major into the scratch, and a second
- * streaming kernel writes the rows.  Worthwhile from ~1e6 points with tables that exceed an L2 (4 MB). */
+/* The same with l4d_hashgrid_fwd_workspace() bytes of device scratch: the levels are evaluated one after the other over the whole
+ * chip (every XCD's L2 then holds the ONE table in use instead of all of them), x-neighbour entry pairs in one 16-byte load where
+ * they share an aligned pair (F = 4, 16-byte aligned table), level-major into the scratch, and a second streaming kernel writes
+ * the rows.  Worthwhile from ~1e6 points with tables that exceed an L2 (4 MB). */
 int64_t l4d_hashgrid_fwd_workspace(const l4d_grid_desc* desc /*host*/, int64_t P);
 int l4d_hashgrid_fwd_ws(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
                         const int32_t* cols /*host*/, const void* table, void* out, int32_t out_stride, void* workspace,
@@ -296,7 +298,9 @@ int l4d_sample_rays_xt(const float* rays_o, const float* rays_d, const float* li
                        float* xt, void* stream);
 /* flow16 [P,16] fp16: flow network output (cols 0-2 forward, 3-5 backward); X [P,in_pad] fp16.
  * hd_scratch: null, or l4d_density_encode_fwd_workspace() bytes of device scratch -> the xz / yz 2-D x time hash stacks are
- * evaluated by a separate kernel from LDS-resident slice tables (faster from ~1e5 samples).
+ * evaluated by a separate kernel from LDS-resident slice tables (faster from ~1e5 samples), and -- from 2^18 samples on, with
+ * plane_rows given as well -- the static 3-D grid by a level-major pre-pass into the same scratch (one level's table at a time
+ * over the whole chip), whose columns the encode kernel then reads instead of gathering.
  * plane_rows: null, or l4d_plane_rows_workspace() bytes of device scratch -> the time planes are first reduced to the
  * 1-D rows of the call's three frame times (their time coordinate is the same for every sample) and sampled with two
  * taps instead of four. */

@@ -250,3 +250,29 @@ def test_level_major_flow_grid_equals_row_kernel(big):
     ops.call("l4d_hashgrid_t_fwd", C.byref(d), ops._p(xt), P, xt.stride(0), ops._i32s([0, 1, 2]), ops._ptrs([grid16]), 1, ops._p(t_dev),
              ops._p(b), b.stride(0), 1, ops._stream())
     assert torch.equal(a, b) and float(a.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("L,F", [(8, 4), (16, 4), (8, 2)])
+def test_level_major_static_grid_equals_row_kernel(L, F):
+    """l4d_hashgrid_fwd_ws (levels one after the other chip-wide through a level-major scratch array, x-neighbour pair loads for
+    F = 4, the last level's launch assembling the rows) == l4d_hashgrid_fwd (one thread per point, all levels), bit for bit, at a
+    ragged size, also into a wider output matrix at a column offset."""
+    from lidar4d_amd import ops
+    from lidar4d_amd.gridmeta import GridMeta
+    meta = GridMeta(3, L, F, 19, 512, np.exp2(np.log2(32768 / 512) / (L - 1)))
+    g = torch.Generator(device=DEV).manual_seed(L * 10 + F)
+    table = (torch.rand(meta.n_params, device=DEV, generator=g) - 0.5).half()
+    P = (1 << 18) + 1234 + 77
+    x = torch.rand(P, 4, device=DEV, generator=g)
+    a = ops.hashgrid_fwd(meta, x, (0, 1, 2), table, level_major=True)
+    b = ops.hashgrid_fwd(meta, x, (0, 1, 2), table, level_major=False)
+    assert torch.equal(a, b) and float(a.float().abs().sum()) > 0
+    if (L * F) % 8 == 0:
+        wide = torch.zeros(P, L * F + 16, dtype=torch.float16, device=DEV)
+        ops.hashgrid_fwd(meta, x, (0, 1, 2), table, out=wide, out_col=8, level_major=True)
+        assert torch.equal(wide[:, 8:8 + L * F], b) and float(wide[:, :8].abs().sum()) == 0 and float(wide[:, 8 + L * F:].abs().sum()) == 0
+    # coordinates from other columns of a wider row (no 16-byte row load)
+    x5 = torch.rand(P, 5, device=DEV, generator=g)
+    a5 = ops.hashgrid_fwd(meta, x5, (1, 2, 4), table, level_major=True)
+    b5 = ops.hashgrid_fwd(meta, x5, (1, 2, 4), table, level_major=False)
+    assert torch.equal(a5, b5)
