@@ -603,3 +603,28 @@ def test_flat_adam_device_schedule_follows_loaded_state():
     opt.step_count = 500
     opt.sync_device_schedule()
     assert float(opt.sched[0]) == 500.0
+
+
+def test_resolve_knobs_tool(tmp_path):
+    """tools/resolve_knobs.py (the unifdef that fixed round 4's compile-time knobs at their measured values): resolved branches are
+    replaced by the selected side, default blocks of resolved macros disappear, --plain macros lose their guard, unknown conditions
+    pass through untouched."""
+    import subprocess
+    import sys
+    src = tmp_path / "k.hip"
+    src.write_text("\n".join([
+        "#ifndef A", "#define A 1  // on", "#endif",
+        "#ifndef B", "#define B 0", "#endif",
+        "#ifndef KEEP", "#define KEEP 64  // tile", "#endif",
+        "#if A", "int a_on;", "#else", "int a_off;", "#endif",
+        "#if !B", "int b_off;", "#endif",
+        "#if B", "int b_on;", "#if A", "int nested;", "#endif", "#endif",
+        "#ifdef __HIPCC__", "int dev;", "#endif",
+        "#ifdef GONE", "int gone;", "#else", "int not_gone;", "#endif",
+        "#if A >= 2", "int a2;", "#endif", "int tail;"]))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "resolve_knobs.py"), str(src), "A=1", "B=0", "GONE=", "--plain", "KEEP"], check=True)
+    out = src.read_text()
+    assert "int a_on;" in out and "a_off" not in out and "int b_off;" in out and "b_on" not in out and "nested" not in out
+    assert "#define KEEP 64  // tile" in out and "#ifndef KEEP" not in out and "#define A" not in out and "#define B" not in out
+    assert "#ifdef __HIPCC__" in out and "int dev;" in out and "not_gone" in out and "int gone;" not in out and "a2" not in out and out.rstrip().endswith("int tail;")
+    assert out.count("#endif") == 1 and out.count("#if") == 1
