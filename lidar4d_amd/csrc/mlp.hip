@@ -253,7 +253,8 @@ struct BwdFrags {
 // MLP_BWD_NARROW_WAVES: waves per SIMD the 16-wide (flow) network's backward is compiled for.  Its accumulators are small, but
 // the compiler keeps the LDS weight fragments in registers across the tile loop as long as it has any (446 of 512).
 #define MLP_BWD_PIN 1  // backward kernels: wait for the prefetched next tile in front of the current tile's dX stores (see there)
-#define MLP_BWD_NARROW_WAVES 1
+#define MLP_BWD_NARROW_WAVES 2  // round 5: 248 registers without the next-tile prefetch, two workgroups per CU: 1.03 -> 0.93 ms (gpurun_out/s13; with one
+                                // workgroup per CU and no prefetch: 1.28; round 2's two-wave attempt kept the prefetch and spilled 80 bytes)
 // ATTR_EPI (attribute networks, with GATHER): the two streaming steps around the network live in the kernel --
 //   in:  dy[row][0] = d_attr[sample][ch] * s (1 - s) * loss_scale with s = attr_compact[row][ch] (adjoint of the sigmoid +
 //        scatter, lidar4d.py:210-219), other columns 0, instead of a [rows, 16] matrix that is 15/16 zeros;
@@ -275,7 +276,7 @@ struct DxStat {
 };
 template <int IN_TILES, int NH, int COL_LO, int COL_HI, bool REST, bool RECOMP = false, bool GATHER = false, int DX_LO = COL_LO,
           bool ATTR_EPI = false>
-__global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1)) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
+__global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARROW_WAVES : 1)) mlp_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ act,
                                                      const half_t* __restrict__ dy, int64_t cap,
                                                      const int32_t* __restrict__ n_rows,
                                                      const half_t* __restrict__ weights, half_t* __restrict__ dx,
@@ -354,7 +355,9 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 ? MLP_BWD_NARROW_WAVES : 1
   // are fetched ONE TILE AHEAD: with the single wavefront per SIMD this kernel's accumulators leave room for, nothing else
   // hides the HBM latency of a tile's loads (measured: 12,000 clocks per tile for 5,000 clocks of MFMA + VALU work).
   constexpr int NACT = RECOMP ? 0 : NH;
-  constexpr bool PREFETCH = !(NH >= 3 && COL_HI - COL_LO >= 8);  // the widest 3-hidden-layer variant has no register left for it
+  // (the widest 3-hidden-layer variant has no register left for it; the 16-wide network at two wavefronts per SIMD hides a tile's
+  // loads behind its partner wavefront instead: with the prefetch it does not fit 256 registers)
+  constexpr bool PREFETCH = !(NH >= 3 && COL_HI - COL_LO >= 8) && !(IN_TILES == 1 && NH <= 2 && MLP_BWD_NARROW_WAVES >= 2);
   struct TileIn {
     uint4 x[2][KS_IN];
     uint4 dy[2];
@@ -808,6 +811,7 @@ static int bwd_grid_cap(int in_pad, int n_hidden) {
       narrow = (e && atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0;
     }
     if (narrow) return narrow * n_cu;
+    if (in_pad <= 16 && n_hidden <= 2) return 2 * n_cu;  // compiled for two wavefronts per SIMD (MLP_BWD_NARROW_WAVES): two workgroups per CU
   }
   return (n_hidden >= 2 || in_pad >= 64) ? n_cu : 2 * n_cu;
 }
