@@ -31,8 +31,10 @@ def test_library_exports_declared_abi():
     import subprocess
     if shutil.which("nm"):
         out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
-        exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("l4d_")}
-        assert exported == declared, (exported - declared, declared - exported)
+        exported = {l.split()[-1] for l in out.splitlines() if l.split()}
+        # (round 5: linked with csrc/exports.map -- kernel stubs, kernel handles and host-side C++ helpers are no longer in the
+        # dynamic symbol table either)
+        assert exported == declared, (sorted(exported - declared)[:8], declared - exported)
 
 
 def test_ctypes_structs_match_header_layout():
