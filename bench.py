@@ -208,26 +208,58 @@ from oracle import fields_ref, tcnn_ref
 from oracle.detparams import det_uniform, fill_model
 from oracle.make_golden import test_rays
 tcnn_ref.set_precision("tcnn")
-cores = min(os.cpu_count() or 1, 32)          # oversubscribing a big host with tiny torch ops only thrashes
+host_cores = os.cpu_count() or 1
+cores = min(host_cores, 32)                    # threads actually used (oversubscribing a big host with tiny torch ops only thrashes)
 torch.set_num_threads(cores)
 scale, num_frames, budget, out_path = {scale!r}, {num_frames!r}, {budget!r}, {out_path!r}
-m = fields_ref.LiDAR4D(near_lidar=1.0 * scale, far_lidar=81.0 * scale, num_frames=num_frames)
 g = torch.Generator().manual_seed(0)
 rd = torch.nn.functional.normalize(torch.randn(1, 1024, 3, generator=g), dim=-1)
 ro = torch.zeros(1, 1024, 3)
 t = torch.tensor([[0.5]])
-def step(n):
+def median3(fn, n):                            # BASELINE.md section 3: 1 warm-up + 3 timed repetitions, median
+    fn(n)
+    return sorted(fn(n) for _ in range(3))[1]
+def fit(fn, share):                            # t(n) = a + b n from two sizes: 8 rays and as many as warm-up + 3 repetitions fit into `share` seconds
+    fn(4)                                      # (allocator, thread pool)
+    t8, t24 = fn(8), fn(24)
+    b = max((t24 - t8) / 16, 1e-6)
+    a = max(t8 - 8 * b, 0.0)
+    n = int(max(32, min(1024, (share / 4 - a) / b)))
+    tn = median3(fn, n)
+    b = max((tn - t8) / (n - 8), 1e-9)
+    return n, tn, max(t8 - 8 * b, 0.0), b
+# (b) training step of the default 4D model (C3 / C4's per-GPU work): forward + backward + Adam, the three primary losses' shape
+m = fields_ref.LiDAR4D(near_lidar=1.0 * scale, far_lidar=81.0 * scale, num_frames=num_frames)
+opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+def step(n):                                   # forward + backward of n rays (linear in n)
     t0 = time.time()
+    opt.zero_grad(set_to_none=True)
     out = m.render(ro[:, :n], rd[:, :n], t, num_steps=768, perturb=True)
     (out["depth_lidar"].sum() + out["image_lidar"].sum()).backward()
     return time.time() - t0
-step(4)                                        # warm-up (allocator, thread pool)
-probe = step(8)
-n = int(max(8, min(1024, budget / max(probe / 8, 1e-6))))
-dt = step(n)
-res = dict(value=n / dt, unit="rays/s", cores=cores, kind="port",
-      sample="oracle port (torch CPU, tcnn rounding points): render() fwd+bwd, %d rays x 768 samples, default 4D config, "
-             "no optimizer; %.1f s on %d threads" % (n, dt, cores))
+def adam(_):                                   # the optimiser step over all 46.5 M parameters (constant per step)
+    t0 = time.time()
+    opt.step()
+    return time.time() - t0
+n, dt, a_fb, b_fb = fit(step, 0.6 * budget)
+dt_adam = median3(adam, 0)
+step_1024 = a_fb + 1024 * b_fb + dt_adam            # the reference's own batch (num_rays_lidar = 1024): what BASELINE.md section 3 (b) asks for
+# (a) BASELINE configs[0] (C1): L = 4 hash grid + 2-layer-64 sigma network, forward only, render(staged=True) on a slice of the
+# 64 x 1024 frame, extrapolated linearly to its 65,536 rays (reference path renderer.py:142-186)
+m1 = fields_ref.LiDAR4D(near_lidar=1.0 * scale, far_lidar=81.0 * scale, num_frames=num_frames, n_levels_hash=4, num_layers_sigma=2)
+def fwd(n1):
+    t0 = time.time()
+    with torch.no_grad():
+        m1.render(ro[:, :n1], rd[:, :n1], t, staged=True, num_steps=768, perturb=False)
+    return time.time() - t0
+n1, dt1, a_f, b_f = fit(fwd, 0.4 * budget)
+res = dict(value=1024 / step_1024, unit="rays/s", cores=cores, host_cores=host_cores, kind="port",
+      sample="oracle port (torch CPU, tcnn rounding points): training step fwd + bwd + Adam at 1,024 rays x 768 samples, default 4D config, = "
+             "a + 1024 b + Adam, with fwd + bwd time a + b n fitted to 8 rays and a %d-ray sample (%.2f s; a = %.2f s, b = %.4f s/ray) and Adam over all "
+             "parameters %.2f s; each 1 warm-up + 3 repetitions, median; %d threads of %d host cores" % (n, dt, a_fb, b_fb, dt_adam, cores, host_cores),
+      c1_forward=dict(value=65536 / (a_f + 65536 * b_f), unit="rays/s", frame_s=a_f + 65536 * b_f,
+                      sample="C1: L=4 hash + 2-layer sigma net, forward only, render(staged=True), %d-ray slice of the 64x1024 frame, "
+                             "median of 3: %.2f s; frame_s = a + 65,536 b with a = %.2f s, b = %.5f s/ray fitted to 8 and %d rays" % (n1, dt1, a_f, b_f, n1)))
 # parity reference (checker role): the default model with deterministic, visible parameters, 64 rays x 768 samples, frame 25
 m.density_scale = 30.0
 fill_model(m, seed=3)
@@ -241,7 +273,7 @@ print(json.dumps(res))
 """
 
 
-def cpu_baseline(num_frames, scale, out_path, budget_s=20.0, timeout_s=300):
+def cpu_baseline(num_frames, scale, out_path, budget_s=16.0, timeout_s=300):
     """Oracle (CPU restatement = a port of the reference path) fwd+bwd on the host cores, in a subprocess with a hard
     timeout so the bench line is always produced; the same subprocess writes the parity reference outputs."""
     code = CPU_BASELINE_CODE.format(root=ROOT, scale=scale, num_frames=num_frames, budget=budget_s, out_path=out_path)
@@ -373,6 +405,10 @@ def compact_line(detail, args):
                       "skipped_steps_in_timed_region": c["skipped_steps_in_timed_region"], "skipped_steps_in_warmup": c["skipped_steps_in_warmup"],
                       "settling_steps": c["scaler_settling_steps_before_warmup"], "loss_scale": c["loss_scale_after_timed_region"],
                       "step_mode": c["step_mode"][:60]}
+    ar = c.get("allreduce")
+    if ar:  # multi-rank runs: bytes on the wire per phase and the part of the collective the step waited for (GradReducer.finish)
+        line["config"]["allreduce"] = {"MB_early": _r(ar["bytes_early_phase"] / 1e6, 1), "MB_late": _r(ar["bytes_late_phase"] / 1e6, 1),
+                                       "transport": ar["transport"], "exposed_wait_ms": _r(ar.get("exposed_wait_ms_per_step"), 3)}
     rf = detail.get("roofline")
     if rf:
         tr = rf.get("traffic") or {}
@@ -406,12 +442,17 @@ def compact_line(detail, args):
         if ts:  # both operating points next to each other: the headline is the random-init state
             line["config"]["state"] = "random init (mask fraction ~1)"
             line["config"]["trained_state"] = {"ms_per_step": _r(ts["ms_per_step"], 3), "rays_per_s": _r(ts["rays_per_s"], 0),
-                                               "mask_fraction": ts.get("mask_fraction"), "after_steps": ts.get("after_steps")}
+                                               "mask_fraction": ts.get("mask_fraction"), "after_steps": ts.get("after_steps"),
+                                               "zero_grad_row_fraction": ts.get("zero_grad_row_fraction"),
+                                               "zero_grad_wave_fraction": ts.get("zero_grad_wave_fraction")}
     if "eval" in detail:
         line["eval"] = {"chamfer_f_score": detail["eval"]["chamfer_distance_m2, f_score@0.05"], "frames": detail["eval"]["frames"]}
     cb = detail.get("cpu_baseline")
     if cb:
-        line["cpu_baseline"] = {"value": _r(cb.get("value"), 2), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": str(cb.get("sample"))[:200]}
+        c1 = cb.get("c1_forward") or {}
+        line["cpu_baseline"] = {"value": _r(cb.get("value"), 2), "unit": cb.get("unit"), "cores": cb.get("cores"), "host_cores": cb.get("host_cores"),
+                                "kind": cb.get("kind"), "sample": str(cb.get("sample"))[:240],
+                                "c1_forward": {"value": _r(c1.get("value"), 1), "unit": c1.get("unit"), "frame_s": _r(c1.get("frame_s"), 1)} if c1 else None}
     pr = detail.get("parity")
     if pr:
         line["parity"] = {k: (pr[k] if not isinstance(pr[k], float) else float("%.3g" % pr[k])) for k in pr if k not in ("vs",)}
@@ -622,7 +663,15 @@ def _run(args):
     for _ in range(args.warmup):
         step()
     steps_mid = int(trainer.opt.steps.max()) if not inference else 0
+    reducer = getattr(trainer, "reducer", None)
+    if reducer is not None:
+        reducer.record_timing = True  # two events per step around GradReducer.finish: how much of the all-reduce was NOT hidden
     dt = timed(step, args.steps, barrier)
+    allreduce = None
+    if reducer is not None:
+        reducer.record_timing = False
+        allreduce = {"bytes_early_phase": reducer.bytes_early, "bytes_late_phase": reducer.bytes_late, "transport": reducer.transport,
+                     "exposed_wait_ms_per_step": reducer.exposed_wait_ms()}
     # GradScaler: steps the device skipped (non-finite gradients while the scale backs off) are cheaper than real ones
     skipped = (args.steps - (int(trainer.opt.steps.max()) - steps_mid)) if not inference else None
     skipped_warmup = (args.warmup - (steps_mid - steps_before)) if not inference else None
@@ -849,7 +898,23 @@ def _run(args):
             with torch.no_grad():
                 bb = data.batch_for(25)
                 frac = float(model.render(bb["rays_o_lidar"], bb["rays_d_lidar"], bb["time"], staged=False, perturb=True, num_steps=768)["mask_count"]) / (n_rays * 768)
-            variants["trained_state"] = {"after_steps": args.warmup + args.steps + args.profile_steps + args.trained_steps + 2 * args.variant_steps,
+            # exact zeros of the adjoint: rows of dh = d loss / d (sigma-network output) that are all-zero fp16 after the
+            # compositing and attribute backward produce no gradient anywhere downstream; measured on one extra step, per row, per
+            # 64-row wavefront segment and per 512-row tile (what a wave- / workgroup-uniform skip would save)
+            zero_rows = {}
+
+            def _probe(dh):
+                z = (dh == 0).all(dim=1)
+                zero_rows.update(rows=float(z.float().mean()), waves=float(z.view(-1, 64).all(dim=1).float().mean()),
+                                 tiles=float(z.view(-1, 512).all(dim=1).float().mean()))
+            model._bwd_probe = _probe
+            trainer.train_step()
+            torch.cuda.synchronize()
+            model._bwd_probe = None
+            variants["trained_state"] = {"zero_grad_row_fraction": round(zero_rows.get("rows", -1.0), 4),
+                                         "zero_grad_wave_fraction": round(zero_rows.get("waves", -1.0), 4),
+                                         "zero_grad_tile_fraction": round(zero_rows.get("tiles", -1.0), 4),
+                                         "after_steps": args.warmup + args.steps + args.profile_steps + args.trained_steps + 2 * args.variant_steps,
                                          "what": f"the headline step after {args.warmup + args.steps + args.profile_steps + args.trained_steps + 2 * args.variant_steps} training "
                                                  "steps on the synthetic scene: fewer samples pass the weights > 1e-4 mask (attribute networks run on those only), flow gradients are no longer tiny",
                                          "steps": args.variant_steps, "ms_per_step": dtv / args.variant_steps * 1e3, "rays_per_s": n_rays * args.variant_steps / dtv,
@@ -884,7 +949,7 @@ def _run(args):
                        "loss_scale_after_timed_region": scale_after, "skipped_steps_in_timed_region": skipped,
                        "skipped_steps_in_warmup": skipped_warmup, "scaler_settling_steps_before_warmup": settle_steps, "step_mode": step_mode,
                        "side_streams_mask": ops.streams_mask(),
-                       "rccl_ranks_seen": ranks_seen, "distinct_gpus_seen": gpus_seen},
+                       "rccl_ranks_seen": ranks_seen, "distinct_gpus_seen": gpus_seen, "allreduce": allreduce},
             "roofline": roofline,
             "roofline_kernels": roofline_kernels,
             "mfma": mfma,

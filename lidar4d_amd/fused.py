@@ -214,6 +214,9 @@ class RenderFn(torch.autograd.Function):
                 ops.attr_gather_bwd(idx, count, P, dxaR, dxaI, an.in_pad, n_enc, model.geo_feat_dim, dh)
         if not sigma_done:
             ops.sigma_bwd(h, d_sigma.view(-1), ls, dh)
+        probe = getattr(model, "_bwd_probe", None)  # measurement hook (bench.py: fraction of all-zero adjoint rows); never set in training
+        if probe is not None:
+            probe(dh)
         # sigma network
         # (the backward reports max |dX| of the time-plane columns as it stores them: the field adjoint's fixed-point scale)
         pe = model.planes_encoder

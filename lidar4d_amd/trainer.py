@@ -624,6 +624,23 @@ class GradReducer:
         assert self.flow_lo == st.group_ranges[1][0] and all(self.flow_lo <= off < self.flow_hi for off, _ in flow)
         self.works = []
         self._pending16 = None
+        # what a scaling record needs to show how much of the collective was hidden (bench.py): bytes on the wire per phase, and -- when
+        # ``record_timing`` is set -- the time the launch stream spent inside finish() (HIP events, read back after the timed region)
+        wire = 2 if self.transport == "bf16" else 4
+        self.bytes_early = self.flow_lo * wire + (st.grad_numel - self.flow_hi) * 4  # encoders (+ networks and gates: always fp32)
+        self.bytes_late = (self.flow_hi - self.flow_lo) * 4                          # the flow field's range
+        self.record_timing = False
+        self._timing = []
+
+    def exposed_wait_ms(self):
+        """Mean time per step the launch stream was held in finish() -- the flow range's all-reduce plus whatever of the early phase
+        had not completed under the flow field's adjoint -- over the steps recorded since ``record_timing`` was set."""
+        if not self._timing:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._timing]
+        self._timing = []
+        return sum(ms) / len(ms)
 
     # -- bf16 transport of one range -----------------------------------------------------------------------------------
     def _start16(self, lo, hi):
@@ -656,6 +673,16 @@ class GradReducer:
                       for a, b in ((0, self.flow_lo), (self.flow_hi, self.store.grad_numel)) if b > a]  # incl. the gates
 
     def finish(self):
+        if self.record_timing and self.store.flat_grad.is_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._finish()
+            b.record()
+            self._timing.append((a, b))
+        else:
+            self._finish()
+
+    def _finish(self):
         g = self.store.flat_grad
         if not self.works:
             if self.transport == "bf16":

@@ -139,6 +139,15 @@ def test_bench_multi_rank_launch_plumbing(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["rccl_ranks_seen"] == 2  # the size of the process group the ranks really formed, next to the requested n_gpus
+    # the driver's largest launch: 8 ranks (rendezvous, port, MAX-over-ranks reduction and the single line must survive it)
+    env["L4D_BENCH_FAKE_GPUS"] = "8"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["rccl_ranks_seen"] == 8 and d["value"] > 0
     # more ranks than devices: refused loudly, nothing that looks like a result on stdout
     env["L4D_BENCH_FAKE_GPUS"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
