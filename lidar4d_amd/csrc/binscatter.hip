@@ -5,14 +5,25 @@
 // not fit LDS, so contributions are first *binned* by table segment and then reduced segment by segment in LDS:
 //
 //   pass 1  (one thread per (sample, level)): the 2^D corner contributions {entry, w * g[0..NV)} (fp16 payload) are
-//           partitioned inside the workgroup by bin = entry >> shift (LDS histogram + ranks) and written, sorted by
-//           bin, into the workgroup's own fixed slot of the record buffer together with its bin offsets -- no global
-//           atomics, no overflow, deterministic layout.  Coarse levels first merge runs of samples in one cell along the
-//           ray (DPP row scan, wave_dev.h).  Blocks are ordered level-fast and XCD-aware so that the levels of a tile
-//           share the gradient rows in one L2.
-//   pass 2  (one workgroup per (level, bin)): walks every pass-1 workgroup's run for its bin (16 lanes per run),
+//           partitioned inside the workgroup by bin = entry >> shift (LDS histogram + ranks), staged sorted by bin in LDS,
+//           and appended to the BIN-MAJOR record lists in HBM: one returning global atomic per (workgroup, level, bin)
+//           reserves the run's place in list [level][bin][XCD of the workgroup] (round 6; rounds 1-5 kept every workgroup's
+//           records in its own slot, sorted by bin, plus a table of bin offsets -- pass 2 then read ~100-byte runs at 4-byte
+//           alignment out of 24,576 slots: 9.15 GB of 128-byte line fills for 4.8 GB of records at an L2 hit rate of 17 %).
+//           Coarse levels first merge runs of samples in one cell along the ray (DPP row scan, wave_dev.h).
+//   pass 2  (one workgroup per (level, bin)): STREAMS its bin's eight lists -- contiguous, every line read once, whole --
 //           accumulates in LDS as int64 fixed point (ds_add_u64: 2.9 T lane-ops/s, exact and order independent), and
 //           adds the segment to the fp32 gradient table with plain stores -- each segment has exactly one owner.
+//
+// LISTS AND OVERFLOW.  A list holds `cap` records = 1.25 x its expected share (samples x 2^(D-1) pair records / (bins x 8)) +
+// 8 sigma + 64: a hashed table spreads the records evenly, so this is never reached by data that looks like a scene.  It is
+// still only a capacity: records that do not fit (clustered or repeated points, pairs that all straddle bins) go, tagged with
+// their bin, to the level's OVERFLOW list, which has room for every record the level can produce (samples x 2^D); the owner
+// of a bin that overflowed (a per-bin counter says so) scans that list after its own.  Where a record lands depends on the
+// arrival of atomics; WHAT is summed does not, and the sums are integers: results stay bit-reproducible in every case
+// (tests/test_gpu_properties.py: random points, and all points in one cell).  Lists are per XCD (workgroup b runs on XCD
+// b % 8: speed only) so that the tail line of a list is completed inside one L2 before it is written back, and so that
+// eight counters, not one, take a bin's reservations.
 //
 // Non-hashed (dense, coarse) levels fall back to run-reduced global atomics.
 //
@@ -40,13 +51,17 @@
 
 #define BS_THREADS 512
 #define BS_MAX_BINS 256
-#define BS_GROUP 8
-#define BS_XCD_BINS 1
-#define BS_UNROLL 4
 #define BS_MIN_WAVES 4  // pass 1: wavefronts per SIMD the register allocation must leave room for (128 registers)
 
+// key + packed halfs.  Records are stored whole (8 or 12 bytes).  ``split`` stores 12-byte records as a dword key stream + an 8-byte
+// payload stream per level, same record index in both (naturally aligned stores and loads); measured slower than whole records at
+// 12-byte alignment (pass 1 2.04 -> 2.16 ms, session s5 of round 6: two store instructions per record cost more than their alignment
+// saves), kept as a compile-time option of the layout.
 template <int NV>
-struct RecWords { static constexpr int n = 1 + (NV + 1) / 2; };  // key + packed halfs
+struct RecWords {
+  static constexpr int n = 1 + (NV + 1) / 2;
+  static constexpr bool split = false;
+};
 
 template <int NV>
 __device__ __forceinline__ void pack_payload(const float v[NV], uint32_t out[(NV + 1) / 2]) {
@@ -60,8 +75,9 @@ __device__ __forceinline__ void pack_payload(const float v[NV], uint32_t out[(NV
 template <int D, int NV>
 __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
                                                               BsCols cols, const half_t* __restrict__ g, int g_stride, int g_col,
-                                                              float pre_scale, int shift, int64_t n_wg,
-                                                              uint16_t* __restrict__ offs, uint32_t* __restrict__ bins,
+                                                              float pre_scale, int shift, int64_t n_wg, BsLayout lay,
+                                                              uint32_t* __restrict__ cur, uint32_t* __restrict__ ovf_cur, uint32_t* __restrict__ ovf_cnt,
+                                                              uint32_t* __restrict__ lists, uint32_t* __restrict__ ovf,
                                                               float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NC = 1 << D;
   constexpr int NW = RecWords<NV>::n;
@@ -75,7 +91,13 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // typically NC / 2 records per lane: NC / 2 pair records, or NC single records per run with <= 32 runs per wave
   constexpr uint32_t CAP = BS_THREADS * NC;  // records per (workgroup, level) slot: every pair of every lane may have to be split
   __shared__ __attribute__((aligned(16))) uint32_t stage[CAP * NW];
-  __shared__ uint32_t total_s;
+  __shared__ uint8_t rbin[CAP];  // bin of every staged record (the copy-out's destination depends on it)
+  // what the copy-out of a level needs, double-buffered by the parity of the binned level (the copy-out runs under the NEXT level's
+  // bin scan, which produces that level's values): per bin ONE 16-byte entry {i0, lim, -, odel} -- record r of the stage (bin b) is
+  // record i0 + r of the level's lists if r < lim, else record r + odel of the level's overflow list; the number of records staged;
+  // and whether any list of the level was full (then, and only then, the copy-out runs its second loop)
+  __shared__ __attribute__((aligned(16))) uint4 bdst[2][BS_MAX_BINS];
+  __shared__ uint32_t total_s[2], ovf_flag[2];
   // per-level maximum |g| of this workgroup (bit patterns of non-negative floats: ordered like unsigned integers).  Updating the
   // global lvl_max[] per wavefront and level meant a load of the current maximum and a wait for it -- one exposed L2 round trip
   // per level in every wavefront of the workgroup at the same moment, with nothing else to run (two workgroups per CU).
@@ -99,24 +121,24 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // halfs): read level by level -- 2 to 8 bytes out of a 256-byte-strided row per level phase -- every level pulled its own
   // 64-byte sector across the fabric (PMC: 5.4 GB fetched for 0.8 GB of values).  The level loop is not unrolled, so the
   // level's dwords are picked by a uniform index into a register VECTOR (an indexed array would live in scratch).
-  // Held 8 dwords (32 bytes of the row) at a time: the next 32 bytes are fetched while the last level of the current ones is
-  // ranked.  (All 64 bytes up front cost 8 more registers for the whole kernel, which now sits at the 128-register limit of its
-  // four wavefronts per SIMD.)
-  constexpr int GW = 8;
+  // Held 4 dwords (16 bytes of the row) at a time: the next 16 bytes are fetched while the last level of the current ones is
+  // ranked.  (The kernel sits at the 128-register limit of its four wavefronts per SIMD: 8 dwords at a time -- rounds 4-5 -- left
+  // no room for the four list reservations that wavefront 0 now carries from one level into the next.)
+  constexpr int GW = 4;
   const bool g_in_regs = n_lv * NV <= 32 && (g_stride * 2) % 16 == 0 && (g_col * 2) % 16 == 0;  // block-uniform
   typedef uint32_t GwVec __attribute__((ext_vector_type(GW)));  // a vector, so that a uniform index becomes relative VGPR addressing
   GwVec gw;
   // (g_in_regs only.  The loads are unconditional -- a piece behind the last level re-reads piece 0 and is never picked: a load
   // under a condition merges with its default value in register copies, and the copies wait for the load where it is issued)
-  auto gw_load = [&](int chunk) {  // dwords 8 chunk .. 8 chunk + 7 of the row's gradient columns
+  auto gw_load = [&](int chunk) {  // dwords GW chunk .. GW chunk + GW - 1 of the row's gradient columns
 #pragma unroll
     for (int q = 0; q < GW / 4; ++q) {
-      const int piece = (chunk * 2 + q) * 8 < n_lv * NV ? chunk * 2 + q : 0;  // block-uniform
+      const int piece = (chunk * (GW / 4) + q) * 8 < n_lv * NV ? chunk * (GW / 4) + q : 0;  // block-uniform
       const uint4 u = *reinterpret_cast<const uint4*>(grow + piece * 8);
       gw[4 * q + 0] = u.x; gw[4 * q + 1] = u.y; gw[4 * q + 2] = u.z; gw[4 * q + 3] = u.w;
     }
   };
-  gw = GwVec{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  gw = GwVec{0u, 0u, 0u, 0u};
   if (g_in_regs) gw_load(0);
   auto gw_pick = [&](int k) -> uint32_t { return gw[k & (GW - 1)]; };
   half_t gnext[NV];
@@ -126,21 +148,96 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // The level loop exists twice (a generic lambda over GREG = "gradient dwords in the register window"): the loads of the other
   // shapes' path, in ONE loop with the common path, made the compiler wait for every outstanding memory operation at the join --
   // the gradient dwords just requested and the previous level's copy-out stores included -- on the common path as well.
-  // COPY-OUT, ONE LEVEL LATE.  A level's staged records (sorted by bin; LDS -> the workgroup's slot, 16 bytes per lane: the slot is
-  // 16-byte aligned and large enough for the rounded-up tail) are stored at the HEAD of the next level, behind the pick of that
-  // level's gradient dwords.  The pick waits for the dwords requested a level earlier, and the compiler's wait there is for every
-  // outstanding memory operation: with the stores issued at a level's end it drained them at the head of the next one, eight
-  // times per workgroup, with nothing else to run at two workgroups per CU.  Issued behind the pick they have a whole level
-  // (three barriers) to complete before the next wait.  Nothing touches `stage` or total_s before the next level's first
-  // barrier, which every wavefront reaches only behind its share of the copy.
-  int copy_lvl = -1;  // block-uniform
-  auto copy_out = [&]() {
-    if (copy_lvl < 0) return;
-    const uint32_t total = total_s;
-    uint32_t* dst = bins + ((uint64_t)copy_lvl * n_wg + tile) * (uint64_t)(CAP * NW);
-    const uint32_t n16 = (total * NW + 3) >> 2;
-    for (uint32_t q = threadIdx.x; q < n16; q += blockDim.x) reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(stage)[q];
-    copy_lvl = -1;
+  // COPY-OUT, UNDER THE NEXT LEVEL'S BIN SCAN.  A level's staged records (sorted by bin) leave LDS between the first and the second
+  // barrier of the next binned level -- while wavefront 0 scans that level's bin totals the other seven copy -- or behind the loop.
+  // Consecutive records of a run are consecutive in their list, so a wavefront's store covers ~8 runs = 8-16 lines.  The reservation
+  // behind bdst is a returning global atomic that the bin's thread issues behind the level's own scan and consumes one ranking phase
+  // later (finish_reserve): its round trip never stands in anybody's way.  Nothing touches `stage`, rbin or this parity's bdst /
+  // total_s before the next level's second barrier, which every wavefront reaches only behind its share of the copy.
+  // The loop is software-pipelined by hand: a record's bin (one byte) is read an iteration ahead, so that an iteration waits once --
+  // for its bdst entry and its record, requested together -- not twice in a row.
+  const int list_k = (int)(blockIdx.x & (BS_LISTS - 1));  // workgroup b runs on XCD b % 8 (observed; speed only)
+  int copy_lvl = -1, nb = 0;  // block-uniform: level whose records are staged; binned levels seen so far (parity = nb & 1)
+  auto copy_out = [&](int first, int step) {
+    const int par = (nb - 1) & 1;
+    const uint32_t total = total_s[par];
+    // the level's record region (split records: key stream, then payload stream; RecWords)
+    typedef __attribute__((address_space(1))) uint32_t GlobalU32;
+    typedef __attribute__((address_space(1))) char GlobalByte;
+    const uint64_t key_base = reinterpret_cast<uint64_t>(lists + lay.list_base[copy_lvl] * NW);
+    const uint64_t lvl_recs = (uint64_t)(desc.size[copy_lvl] >> shift) * BS_LISTS * lay.cap[copy_lvl];
+    const uint64_t pay_base = key_base + lvl_recs * 4u;
+    const bool near = lvl_recs * (NW * 4u) < (1ull << 32);  // block-uniform: 32-bit byte offsets from a scalar base reach every record
+    // HOT LOOP: records that fit their list (all of them, unless ovf_flag says otherwise); one multiply for the address
+    {
+      uint32_t r = (uint32_t)first;
+      uint32_t b_next = rbin[r < CAP ? r : 0u];
+      while (r < total) {
+        const uint32_t b = b_next;
+        const uint32_t rn = r + (uint32_t)step;
+        b_next = rbin[rn < CAP ? rn : 0u];
+        uint2 e = *reinterpret_cast<const uint2*>(&bdst[par][b]);  // {i0, lim}
+        uint32_t w[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) w[q] = stage[r * NW + q];
+        // (the entry and the record requested together, ONE wait)
+        if (NW == 3) asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(w[0]), "+v"(w[1]), "+v"(w[NW - 1]));
+        else asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(w[0]), "+v"(w[NW - 1]));
+        if (r < e.y) {
+          const uint32_t rec = e.x + r;  // record index inside the level's region (mod 2^32: e.x is relative to stage record 0)
+          if (RecWords<NV>::split) {
+            *(GlobalU32*)(key_base + (uint64_t)rec * 4u) = w[0];
+            __builtin_memcpy((GlobalU32*)(pay_base + (uint64_t)rec * ((NW - 1) * 4u)), w + 1, (NW - 1) * sizeof(uint32_t));
+          } else {  // ONE store of the whole record (a vector type of 4-byte alignment: global_store_dwordx2 / x3)
+            typedef uint32_t RecVecA __attribute__((ext_vector_type(NW), aligned(4)));
+            typedef __attribute__((address_space(1))) RecVecA GlobalRec;
+            RecVecA rv;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) rv[q] = w[q];
+            if (near) *(GlobalRec*)((GlobalByte*)key_base + rec * (uint32_t)(NW * 4u)) = rv;
+            else *(GlobalRec*)(key_base + (uint64_t)rec * (NW * 4u)) = rv;
+          }
+        }
+        r = rn;
+      }
+    }
+    if (ovf_flag[par]) {  // (block-uniform, rare) records of lists that are full: LISTS AND OVERFLOW
+      const uint32_t ovf_cap = lay.ovf_cap[copy_lvl];
+      uint32_t* ov = ovf + lay.ovf_base[copy_lvl] * (NW + 1);
+      for (uint32_t r = (uint32_t)first; r < total; r += (uint32_t)step) {
+        const uint32_t b = rbin[r];
+        const uint4 e = bdst[par][b];
+        const uint32_t op = r + e.w;
+        if (r >= e.y && op < ovf_cap) {
+          uint32_t* d = ov + (uint64_t)op * (NW + 1);
+          d[0] = b;
+#pragma unroll
+          for (int q = 0; q < NW; ++q) d[1 + q] = stage[r * NW + q];
+        }
+      }
+    }
+  };
+  // threads 0 .. 255 own one bin each: the reservation of the staged level's run for that bin has returned by now; turn it into the
+  // bin's bdst entry
+  constexpr int BPL = BS_MAX_BINS / 64;
+  uint32_t resv = 0u;
+  auto finish_reserve = [&]() {
+    const int par = (nb - 1) & 1;
+    const uint32_t cap = lay.cap[copy_lvl];
+    uint32_t b = threadIdx.x;
+    asm volatile("" : "+v"(b));  // (opaque per level: hoisted out of the level loop, the LDS and cursor addresses of every use of b cost a register each -- spilled)
+    const uint32_t o0 = boff[b], cnt = boff[b + 1] - o0;
+    const uint32_t fit = resv >= cap ? 0u : min(cnt, cap - resv);  // records of the run that fit the list
+    uint32_t odel = 0u;
+    if (fit < cnt) {  // (never with data that looks like a scene)
+      const uint32_t n_ovf = cnt - fit;
+      const uint32_t op = atomicAdd(ovf_cur + copy_lvl, n_ovf);
+      atomicAdd(ovf_cnt + copy_lvl * BS_MAX_BINS + b, n_ovf);
+      odel = op - (o0 + fit);
+      ovf_flag[par] = 1u;
+    }
+    // {record index of stage record 0 if the run started there (mod 2^32), first stage index that does not fit, -, overflow delta}
+    bdst[par][b] = uint4{(b * BS_LISTS + (uint32_t)list_k) * cap + resv - o0, o0 + fit, 0u, odel};
   };
   auto levels = [&](auto greg_tag) {
   constexpr bool GREG = decltype(greg_tag)::value;
@@ -152,56 +249,57 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // atomic path below -- so that their index is the plain xor-and-mask of hashgrid_dev.h grid_index_fast)
   const bool binned = hashed && is_pow2(size) && nbins <= BS_MAX_BINS && nbins > 1;
 
-  if (!GREG) {  // (shapes outside the register window: this level's values, loaded where they are used)
-#pragma unroll
-    for (int j = 0; j < NV; ++j) gnext[j] = grow[lvl * NV + j];
-  }
-  if (GREG) {  // this level's NV halfs out of the preloaded dwords
-    uint32_t w[(NV + 1) / 2];
-#pragma unroll
-    for (int q = 0; q < (NV + 1) / 2; ++q) w[q] = gw_pick(NV == 1 ? lvl >> 1 : lvl * (NV / 2) + q);
-    // (picked before the next dwords are requested INTO the same registers: loads scheduled in front of the pick need a second
-    // register set and a copy behind them -- which waits for them on the spot)
-#pragma unroll
-    for (int q = 0; q < (NV + 1) / 2; ++q) asm volatile("" : "+v"(w[q]) : : "memory");
-    if (NV == 1 && (lvl & 1)) w[0] >>= 16;
-    const half_t* hw = reinterpret_cast<const half_t*>(w);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) gnext[j] = hw[j];
-    // first dword of the next level (NV = 1: two levels per dword); at a 32-byte boundary the held dwords are all consumed
-    const int k_next = NV == 1 ? (lvl + 1) >> 1 : (lvl + 1) * (NV / 2);
-    if (lvl + 1 < n_lv && k_next % GW == 0 && (NV > 1 || ((lvl + 1) & 1) == 0)) gw_load(k_next / GW);
-  }
-  copy_out();  // the previous level's records (see above)
+  // THE LEVEL'S GRADIENT VALUES ARE TAKEN LATE: behind the cell location, the corner hashes and the weights, none of which needs
+  // them.  Taking them is where the compiler waits for EVERY outstanding memory operation of the wavefront (its counter wait in a
+  // loop is vmcnt(0)) -- the previous level's copy-out stores and, in the first four wavefronts, the returning atomic that reserved
+  // the previous level's runs (issued two barriers back).  At the head of the level that wait stood ~2 us of atomic round trip in
+  // front of everything (session s4 of round 6: 0.28 ms of pass 1); here the hashing has covered it.
   float gv[NV];
   bool any = false;
   float amax = 0.0f;
+  auto take_gradient = [&]() {
+    if (!GREG) {  // (shapes outside the register window: this level's values, loaded where they are used)
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    gv[j] = valid ? h2f(gnext[j]) * pre_scale : 0.0f;
-    any |= gv[j] != 0.0f;
-    amax = amax_nf(amax, gv[j]);
-  }
+      for (int j = 0; j < NV; ++j) gnext[j] = grow[lvl * NV + j];
+    }
+    if (GREG) {  // this level's NV halfs out of the preloaded dwords
+      uint32_t w[(NV + 1) / 2];
+#pragma unroll
+      for (int q = 0; q < (NV + 1) / 2; ++q) w[q] = gw_pick(NV == 1 ? lvl >> 1 : lvl * (NV / 2) + q);
+      // (picked before the next dwords are requested INTO the same registers: loads scheduled in front of the pick need a second
+      // register set and a copy behind them -- which waits for them on the spot)
+#pragma unroll
+      for (int q = 0; q < (NV + 1) / 2; ++q) asm volatile("" : "+v"(w[q]) : : "memory");
+      if (NV == 1 && (lvl & 1)) w[0] >>= 16;
+      const half_t* hw = reinterpret_cast<const half_t*>(w);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) gnext[j] = hw[j];
+      // first dword of the next level (NV = 1: two levels per dword); at a 16-byte boundary the held dwords are all consumed
+      const int k_next = NV == 1 ? (lvl + 1) >> 1 : (lvl + 1) * (NV / 2);
+      if (lvl + 1 < n_lv && k_next % GW == 0 && (NV > 1 || ((lvl + 1) & 1) == 0)) gw_load(k_next / GW);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      gv[j] = valid ? h2f(gnext[j]) * pre_scale : 0.0f;
+      any |= gv[j] != 0.0f;
+      amax = amax_nf(amax, gv[j]);
+    }
+  };
   // (No barrier here: the histogram was left zeroed by the scan of the previous binned level, and this level's staging writes and
-  // bin offsets come two barriers down, behind every wavefront's copy-out of the previous level -- three barriers per level, not five.)
+  // bin offsets come behind the barriers below, which every wavefront reaches only behind its share of the previous level's copy-out.)
 
   Cell<D> c = locate<D>(xin, desc.scale[lvl]);
   uint32_t keys[NC];
   float vals[NC][NV];
   bool emit[NC];
   uint32_t pos[NC];
-  const bool wave_any = __any(any);
   // Consecutive lanes are consecutive samples of a ray: on coarse levels several of them sit in one cell and hit the same
   // 2^D entries.  Binned levels merge such runs inside 16-lane rows with the DPP scan (one record per run and corner);
   // the dense fallback keeps the wave-wide shuffle reduction (global atomics are the expensive resource there).
   int n_heads = 64;
   RowRuns runs;
   bool use_scan = false;
-  // (fine levels: the 64 consecutive samples of a wavefront cross far more than 32 cells, no two of them share one -- the run
-  // detection below (three DPP compares, a ballot, the run bookkeeping: ~45 instructions) is skipped when the first and the last
-  // lane are more than 48 cells apart along some axis; a heuristic about WORK only, the pair path is always correct)
-  bool try_merge = binned && wave_any;
-  if (try_merge) {
+  if (binned) {
     bool same = true;  // same cell as the previous lane (the first lane of a row never is: old = ~cell, bound_ctrl off)
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -215,49 +313,61 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   }
   const bool pairs = binned && !use_scan;  // wave-uniform
   uint32_t fxq = 0u;  // keys[] carry the record's tz code in bits 24..27 from here on (entries per level <= 2^24: checked by the host side)
+  bool wave_any;
   if (pairs) {
     // one record per x-neighbour pair (corners 2q, 2q + 1): slots 0 .. NC/2 - 1 are used, the rest stay silent
     fxq = (uint32_t)fx_round(c.frac[0] * BS_FX_ONE);
     const float fx = (float)fxq * (1.0f / BS_FX_ONE);
+    float wyz[NC / 2];  // weight without the x factor
+    bool paired[NC / 2];
 #pragma unroll
     for (int q = 0; q < NC / 2; ++q) {
       uint32_t g0[D], g1[D];
-      const float w0 = corner<D>(c, 2 * q, g0);
+      (void)corner<D>(c, 2 * q, g0);
       (void)corner<D>(c, 2 * q + 1, g1);
-      float wyz = 1.0f;  // weight without the x factor
+      wyz[q] = 1.0f;
 #pragma unroll
-      for (int d = 1; d < D; ++d) wyz *= ((2 * q) >> d) & 1 ? c.frac[d] : 1.0f - c.frac[d];
-      (void)w0;
+      for (int d = 1; d < D; ++d) wyz[q] *= ((2 * q) >> d) & 1 ? c.frac[d] : 1.0f - c.frac[d];
       const uint32_t k0 = grid_index_fast<D>(g0, size - 1u), k1 = grid_index_fast<D>(g1, size - 1u);
       const uint32_t m = k0 ^ k1;
-      const bool paired = (m & (m + 1u)) == 0u && m != 0u && (m >> shift) == 0u && __popc(m) <= (int)BS_CODE_SINGLE;
-      keys[q] = k0 | ((uint32_t)(__popc(m) - 1) << 24);
+      paired[q] = (m & (m + 1u)) == 0u && m != 0u && (m >> shift) == 0u && __popc(m) <= (int)BS_CODE_SINGLE;
+      keys[q] = k0 | ((paired[q] ? (uint32_t)(__popc(m) - 1) : BS_CODE_SINGLE) << 24);
+      keys[q + NC / 2] = k1 | (BS_CODE_SINGLE << 24);
+    }
+    take_gradient();
+    wave_any = __any(any);
+#pragma unroll
+    for (int q = 0; q < NC / 2; ++q) {
       float* v = vals[q];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) v[j] = wyz * gv[j];
+      for (int j = 0; j < NV; ++j) v[j] = wyz[q] * gv[j];
       bool nz = false;
 #pragma unroll
       for (int j = 0; j < NV; ++j) nz |= v[j] != 0.0f;
       emit[q] = any && nz;
       // straddles two bins (2^-shift of the pairs): two single records, the neighbour's in the otherwise unused slot q + NC/2
-      const bool split = emit[q] && !paired;
+      const bool split = emit[q] && !paired[q];
       emit[q + NC / 2] = split;
-      keys[q + NC / 2] = k1 | (BS_CODE_SINGLE << 24);
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         vals[q + NC / 2][j] = v[j] * fx;
         if (split) v[j] *= 1.0f - fx;
       }
-      if (split) keys[q] = k0 | (BS_CODE_SINGLE << 24);
     }
   } else {
+    float wk[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      uint32_t gg[D];
+      wk[k] = corner<D>(c, k, gg);
+      keys[k] = binned ? grid_index_fast<D>(gg, size - 1u) : grid_index<D>(gg, desc.res[lvl], size, hashed);
+    }
+    take_gradient();
+    wave_any = __any(any);
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
-    uint32_t gg[D];
-    const float w = corner<D>(c, k, gg);
-    keys[k] = binned ? grid_index_fast<D>(gg, size - 1u) : grid_index<D>(gg, desc.res[lvl], size, hashed);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) vals[k][j] = w * gv[j];
+    for (int j = 0; j < NV; ++j) vals[k][j] = wk[k] * gv[j];
     if (binned) {
       emit[k] = any;
       if (use_scan) {
@@ -300,10 +410,11 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
 #pragma unroll
     for (int k = NC / 2; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   }
+  // (the reservations of the level that is still staged have had this level's head and ranking phase to return)
+  if (threadIdx.x < BS_MAX_BINS && copy_lvl >= 0) finish_reserve();
   __syncthreads();
-  const bool scan_io = true;
+  const int par = nb & 1;
   if (threadIdx.x < 64) {  // exclusive scan of the bin totals by one wave: BPL consecutive bins per lane
-    constexpr int BPL = BS_MAX_BINS / 64;
     uint32_t c[BPL], sum = 0;
 #pragma unroll
     for (int q = 0; q < BPL; ++q) {
@@ -323,41 +434,36 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     L4D_ADD_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
     L4D_ADD_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
 #undef L4D_ADD_DPP
-    // Bin offsets are stored TRANSPOSED, offs[level][bin][workgroup]: pass 2 walks one bin over all workgroups, and read from
-    // a [workgroup][bin] table every run cost it a 64-byte sector for two 2-byte numbers -- as many fabric requests as the run's
-    // records themselves.  The 2-byte stores below land in lines that the neighbouring tiles (same XCD, dispatched together:
-    // xcd_tile) complete within the same L2.
-    const uint32_t nwg32 = (uint32_t)n_wg;  // (levels x bins x workgroups < 2^32: checked by the host side)
-    // scalar base + 32-bit byte offset per lane: as 64-bit per-lane addresses the level-invariant part was hoisted out of the level
-    // loop into two register pairs that did not fit and were reloaded from scratch here -- in the one wavefront that the other
-    // fifteen of the workgroup wait for
-    const uint64_t ob = reinterpret_cast<uint64_t>(offs + (uint64_t)lvl * (BS_MAX_BINS + 1) * n_wg + tile);
-    typedef __attribute__((address_space(1))) char GlobalByte;  // (an integer cast to a plain pointer is a FLAT address)
-    typedef __attribute__((address_space(1))) uint16_t GlobalU16;
-    GlobalByte* o = (GlobalByte*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ob >> 32)) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob));
     uint32_t excl = inc - sum;
-    uint32_t lane_off = (uint32_t)(lane * BPL) * nwg32 * 2u;
-    asm volatile("" : "+v"(lane_off));  // (opaque per level: hoisted out of the level loop the offsets become 64-bit register pairs again)
 #pragma unroll
     for (int q = 0; q < BPL; ++q) {
       const int b = lane * BPL + q;
       boff[b] = excl;
-      if (scan_io && b <= nbins) *(GlobalU16*)(o + (lane_off + (uint32_t)q * nwg32 * 2u)) = (uint16_t)excl;
       excl += c[q];
     }
-    if (scan_io && lane == 63) {
-      total_s = inc;
+    if (lane == 63) {
+      total_s[par] = inc;
+      ovf_flag[par] = 0u;
       boff[BS_MAX_BINS] = inc;
-      if (nbins == BS_MAX_BINS) *(GlobalU16*)(o + (uint32_t)BS_MAX_BINS * nwg32 * 2u) = (uint16_t)inc;
     }
+  } else if (copy_lvl >= 0) {
+    copy_out((int)threadIdx.x - 64, BS_THREADS - 64);  // the previous binned level's records, under the scan
   }
   __syncthreads();
+  // this level's reservations: ONE returning atomic per bin on the list cursor [level][list][bin], issued by the bin's thread (the
+  // first four wavefronts; 64 lanes = 64 consecutive counters = two lines).  Unconditional (a bin without records adds 0): a
+  // conditional one is waited for where it is issued.  Consumed by finish_reserve() in front of the NEXT level's first barrier.
+  if (threadIdx.x < BS_MAX_BINS) {
+    uint32_t b = threadIdx.x;
+    asm volatile("" : "+v"(b));  // (as above: scalar base + 32-bit lane offset, formed here)
+    resv = atomicAdd(cur + ((uint32_t)lvl * BS_LISTS + (uint32_t)list_k) * BS_MAX_BINS + b, boff[b + 1] - boff[b]);
+  }
   auto stage_slot = [&](int k) {
     if (emit[k]) {
       const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
       const uint32_t r = boff[b] + pos[k];
       const uint32_t code = keys[k] >> 24;
+      rbin[r] = (uint8_t)b;
       stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));
       uint32_t pay[NW - 1];
       pack_payload<NV>(vals[k], pay);
@@ -371,13 +477,17 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
 #pragma unroll
     for (int k = NC / 2; k < NC; ++k) stage_slot(k);
   }
-  __syncthreads();
-  copy_lvl = lvl;  // the staged records leave at the head of the next level (or behind the loop)
+  copy_lvl = lvl;  // the staged records leave under the next binned level's scan (or behind the loop)
+  ++nb;
   }  // levels
   };
   if (g_in_regs) levels(std::true_type{});
   else levels(std::false_type{});
-  copy_out();
+  if (copy_lvl >= 0) {  // the last binned level's records
+    if (threadIdx.x < BS_MAX_BINS) finish_reserve();
+    __syncthreads();
+    copy_out((int)threadIdx.x, BS_THREADS);
+  }
   __syncthreads();
   if ((int)threadIdx.x < n_lv) {
     const uint32_t m = lmax_s[threadIdx.x];
@@ -385,23 +495,23 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   }
 }
 
-// CSHIFT > 0: the bin size is a compile-time constant, so the [value][entry] accumulator addresses are ONE register (entry * 8) plus
-// immediate offsets (j * 2^CSHIFT * 8 <= 48 KB fits the DS offset field) -- the kernel issues ~100 VALU instructions per record on 8
-// wavefronts per SIMD and is bound by exactly those (SQ_ACTIVE_INST_VALU: 11 % of every wave's cycles x 8 waves).  CSHIFT = 0: run-time.
+// ---- pass 2 -----------------------------------------------------------------------------------------------------------------
+// One workgroup per (level, bin).  Its records are eight contiguous lists (one per XCD, pass 1 above): every wavefront takes 64
+// consecutive records of a list at a time -- one 8- or 12-byte load per lane, whole lines, each read once -- and adds them to the
+// bin's [value][entry] int64 accumulators in LDS; the records of a window are requested before the previous window is accumulated.
+// (Rounds 3-5 walked every pass-1 workgroup's run for the bin instead: a table of bin offsets, and per 64 records a prefix scan
+// over 64 run lengths, owner stamps in LDS, a max scan and a ds_bpermute to find out whose record a lane holds.)
+// CSHIFT > 0: the bin size is a compile-time constant, so the accumulator addresses are ONE register (entry * 8) plus immediate
+// offsets (j * 2^CSHIFT * 8 <= 48 KB fits the DS offset field).  CSHIFT = 0: run-time.
 template <int D, int NV, int CSHIFT = 0>
-__global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shift_rt, int n_wg, int64_t P,
-                                                       const uint16_t* __restrict__ offs, const uint32_t* __restrict__ bins,
-                                                       const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
-  constexpr int NC = 1 << D;
+__global__ void __launch_bounds__(1024) bin_reduce_kernel(GridDesc desc, int shift_rt, BsLayout lay, const uint32_t* __restrict__ cur,
+                                                        const uint32_t* __restrict__ ovf_cur, const uint32_t* __restrict__ ovf_cnt,
+                                                        const uint32_t* __restrict__ lists, const uint32_t* __restrict__ ovf,
+                                                        const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
   constexpr int NW = RecWords<NV>::n;
   extern __shared__ long long acc[];
   const int shift = CSHIFT > 0 ? CSHIFT : shift_rt;
-  // XCD-aware bin order: workgroup x runs on XCD x % 8, so bin = (x % 8) * (n / 8) + x / 8 gives every XCD a contiguous eighth of a
-  // level's bins, and the workgroups it holds at any time own ADJACENT bins.  They walk the pass-1 workgroups in the same order at
-  // about the same pace, and a pass-1 slot is sorted by bin: what one of them misses in L2, its neighbours hit (the lines at the run
-  // boundaries, the other half of every 128-byte request).  With bin = x those neighbours sat in eight different L2s.
-  const int lvl = blockIdx.y;
-  const int b = (BS_XCD_BINS && gridDim.x % 8 == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int lvl = blockIdx.y, b = blockIdx.x;
   const uint32_t size = desc.size[lvl];
   const bool hashed = (desc.hashed_mask >> lvl) & 1u;
   const int nbins = (int)((size + (1u << shift) - 1) >> shift);
@@ -416,20 +526,33 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   const int seg = CSHIFT > 0 ? (1 << CSHIFT) : (1 << shift);  // entries per bin = stride of the [value][entry] accumulator layout
   const int n_ent = (int)min(1u << shift, size - lo);
   const int n_el = n_ent * NV;
+  // the eight list lengths (block-uniform: scalar loads) and their 64-aligned prefix: window w of the concatenation lies in ONE list
+  const uint32_t cap = lay.cap[lvl];
+  // (eight named scalars each, not arrays: the compiler turns a select chain over array elements into an indexed load from scratch)
+  static_assert(BS_LISTS == 8, "the list walk below is written out for eight lists");
+#define BS_LEN(k) const uint32_t n##k = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(cur[((uint32_t)lvl * BS_LISTS + k) * BS_MAX_BINS + b], cap));
+  BS_LEN(0) BS_LEN(1) BS_LEN(2) BS_LEN(3) BS_LEN(4) BS_LEN(5) BS_LEN(6) BS_LEN(7)
+#undef BS_LEN
+#define BS_R64(n) (((n) + 63u) & ~63u)
+  const uint32_t o1 = BS_R64(n0), o2 = o1 + BS_R64(n1), o3 = o2 + BS_R64(n2), o4 = o3 + BS_R64(n3), o5 = o4 + BS_R64(n4), o6 = o5 + BS_R64(n5),
+                 o7 = o6 + BS_R64(n6), v_end = o7 + BS_R64(n7);
+#undef BS_R64
+  const uint32_t n_ovf_mine = ovf_cnt[lvl * BS_MAX_BINS + b];
   for (int i = threadIdx.x; i < seg * NV; i += blockDim.x) acc[i] = 0;
   __syncthreads();
   // Fixed point: every contribution is |v| <= gmax, scaled to 30 bits and converted with ONE v_cvt_i32_f32 (a float -> int64
-  // conversion is a dozen instructions on this ISA, eight of them per record: pass 2 was bound by exactly that), then
-  // sign-extended into the 64-bit accumulator -- 2^33 contributions per entry before it could overflow, quantisation 2^-26 of
-  // the level's largest gradient (the payload itself carries 11 bits).
-  // (a merged run of a coarse level sums up to 16 lanes of one DPP row: 16 gmax bounds every record)
+  // conversion is a dozen instructions on this ISA, eight of them per record), then sign-extended into the 64-bit accumulator --
+  // 2^33 contributions per entry before it could overflow, quantisation 2^-26 of the level's largest gradient (the payload itself
+  // carries 11 bits).  (a merged run of a coarse level sums up to 16 lanes of one DPP row: 16 gmax bounds every record)
   const float fxs = fx_scale(gmax * 16.5f, 30);
-  // groups of BS_GROUP lanes, one pass-1 workgroup's run each.  Every run costs a dependent pair of loads (its offsets,
-  // then its records): small groups = many independent chains in flight, which is what hides that latency
-  constexpr int NGRP = 1024 / BS_GROUP;
-  const int grp = threadIdx.x / BS_GROUP, l16 = threadIdx.x % BS_GROUP;
-  auto add = [&](uint32_t w0, const uint32_t* wd) {  // w0: record key word (see PAIR RECORDS above)
-    const half_t* hv = reinterpret_cast<const half_t*>(wd);
+  // one record = NW words, kept as ONE register tuple from its load to its use (separate scalars made the register allocator copy
+  // the words out of the load's destination right behind the load, i.e. wait for it there)
+  typedef uint32_t RecVec __attribute__((ext_vector_type(NW)));
+  auto add = [&](const RecVec rv) {  // rv[0]: record key word (see PAIR RECORDS above)
+    const uint32_t w0 = rv[0];
+    // (the halfs are taken out of the payload WORDS here, with shifts: read through a half_t pointer the words were split into
+    // 16-bit pieces where they are loaded)
+    auto hv_at = [&](int j) -> half_t { return __builtin_bit_cast(half_t, (unsigned short)(rv[1 + (j >> 1)] >> (16 * (j & 1)))); };
     const uint32_t local = w0 & ((1u << BS_KEY_BITS) - 1u), code = (w0 >> BS_KEY_BITS) & 15u;
     const bool single = code == BS_CODE_SINGLE;
     const float f1 = single ? 0.0f : (float)(w0 >> (BS_KEY_BITS + 4)) * (1.0f / BS_FX_ONE);
@@ -441,62 +564,76 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
     unsigned long long* a1 = reinterpret_cast<unsigned long long*>(acc) + other;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const float v = h2f(hv[j]);
+      const float v = h2f(hv_at(j));
       if (v != 0.0f) {  // (many payloads ARE zero: w * g below the smallest fp16 -- dropping this test cost 8 % / 35 % at NV = 4 / 2)
-        atomicAdd(a0 + j * seg, (unsigned long long)(long long)fx_round(v * s0));
-        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)fx_round(v * s1));
+        const float2_t p = float2_t{s0, s1} * v;  // one v_pk_mul_f32
+        atomicAdd(a0 + j * seg, (unsigned long long)(long long)fx_round(p[0]));
+        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)fx_round(p[1]));
       }
     }
   };
-  // The runs of this bin, one per pass-1 workgroup, consecutive groups take consecutive workgroups: their offsets
-  // offs[level][bin][w], offs[level][bin + 1][w] are two dense arrays (fetched one iteration ahead), so the only scattered
-  // accesses left are the records themselves.
-  const uint16_t* o0 = offs + ((uint64_t)lvl * (BS_MAX_BINS + 1) + b) * n_wg;
-  const uint16_t* o1 = o0 + n_wg;
-  constexpr uint64_t SLOT = (uint64_t)(BS_THREADS * NC) * NW;
-  const uint32_t* lvl_bins = bins + (uint64_t)lvl * n_wg * SLOT;
-  // BS_UNROLL runs per group and iteration: their first records are all in flight before any is consumed (each group otherwise has
-  // ONE load outstanding -- a dependent chain of ~1.5 us round trips that left the kernel at ~2.8 TB/s of line traffic), and the next
-  // iteration's offsets are fetched while this one is processed.
-  uint32_t s0n[BS_UNROLL], s1n[BS_UNROLL];
+  // this bin's eight lists inside the level's region (split records: key stream, then payload stream; RecWords)
+  const uint32_t* lvl_keys = lists + lay.list_base[lvl] * NW;
+  const uint32_t* lvl_pays = lvl_keys + (uint64_t)nbins * BS_LISTS * cap;
+  const uint64_t bin_first = (uint64_t)b * BS_LISTS * cap;
+  // fetch: ISSUES the loads of the window that starts at virtual position vw (a multiple of 64, wave-uniform: kept in scalar
+  // registers, so that picking the window's list is SALU work) -- nothing here waits for them.  Lanes behind a list's last record read
+  // the bin's first record and ignore it (an unconditional load: one under `if (ok)` is waited for at the end of that block -- the
+  // merge with the default value is a copy).
+  const uint32_t lane = threadIdx.x & 63u;
+  auto fetch = [&](uint32_t vw, RecVec& rv, bool& ok) {
+    uint32_t base_k = 0u, off_k = 0u, len_k = n0;
+#define BS_PICK(k) if (vw >= o##k) { base_k = k##u * cap; off_k = o##k; len_k = n##k; }
+    BS_PICK(1) BS_PICK(2) BS_PICK(3) BS_PICK(4) BS_PICK(5) BS_PICK(6) BS_PICK(7)
+#undef BS_PICK
+    const uint32_t r = vw - off_k + lane;
+    ok = r < len_k;
+    const uint64_t rec = bin_first + (ok ? base_k + r : 0u);
+    if (RecWords<NV>::split) {  // one global_load_dword + one global_load_dwordx2
+      uint32_t pay[NW - 1];
+      const uint32_t key = lvl_keys[rec];
+      __builtin_memcpy(pay, lvl_pays + rec * (NW - 1), (NW - 1) * sizeof(uint32_t));
+      rv[0] = key;
 #pragma unroll
-  for (int u = 0; u < BS_UNROLL; ++u) {
-    const int w = grp + u * NGRP;
-    s0n[u] = s1n[u] = 0u;
-    if (w < n_wg) { s0n[u] = o0[w]; s1n[u] = o1[w]; }
+      for (int q = 1; q < NW; ++q) rv[q] = pay[q - 1];
+    } else {
+      __builtin_memcpy(&rv, lvl_keys + rec * NW, NW * sizeof(uint32_t));  // one global_load_dwordx2
+    }
+  };
+  // Two windows in flight: the records of window n + 1 are requested before window n is accumulated, two register sets in turn so that
+  // no copy waits for a load.  The empty asm is where a window's records are waited for: BEFORE the next window is requested, so that
+  // exactly one request is outstanding at every wait.
+  RecVec rec_a = {}, rec_b = {};
+  bool ok_a = false, ok_b = false;
+  uint32_t vw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  const uint32_t vstep = blockDim.x;
+  if (vw < v_end) {
+    fetch(vw, rec_a, ok_a);
+    for (;;) {
+      asm volatile("" : "+v"(rec_a));
+      vw += vstep;
+      const bool more_b = vw < v_end;
+      if (more_b) fetch(vw, rec_b, ok_b);
+      if (ok_a) add(rec_a);
+      if (!more_b) break;
+      asm volatile("" : "+v"(rec_b));
+      vw += vstep;
+      const bool more_a = vw < v_end;
+      if (more_a) fetch(vw, rec_a, ok_a);
+      if (ok_b) add(rec_b);
+      if (!more_a) break;
+    }
   }
-  for (int w0 = grp; w0 < n_wg; w0 += NGRP * BS_UNROLL) {
-    uint32_t s0[BS_UNROLL], s1[BS_UNROLL], key0[BS_UNROLL], wd0[BS_UNROLL][NW - 1];
-    const uint32_t* rec[BS_UNROLL];
+  if (n_ovf_mine != 0u) {  // records of this bin that did not fit their list (LISTS AND OVERFLOW): tagged with the bin in the level's overflow list
+    const uint32_t n = min(ovf_cur[lvl], lay.ovf_cap[lvl]);
+    const uint32_t* ov = ovf + lay.ovf_base[lvl] * (NW + 1);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint32_t* rec = ov + (uint64_t)i * (NW + 1);
+      if (rec[0] == (uint32_t)b) {
+        RecVec rv;
 #pragma unroll
-    for (int u = 0; u < BS_UNROLL; ++u) {
-      s0[u] = s0n[u];
-      s1[u] = s1n[u];
-      rec[u] = lvl_bins + (uint64_t)min(w0 + u * NGRP, n_wg - 1) * SLOT;
-      const uint32_t r = s0[u] + l16;
-      key0[u] = BS_CODE_SINGLE << BS_KEY_BITS;
-#pragma unroll
-      for (int q = 0; q < NW - 1; ++q) wd0[u][q] = 0u;
-      if (r < s1[u]) {  // the run's first BS_GROUP records
-        key0[u] = rec[u][r * NW];
-#pragma unroll
-        for (int q = 0; q < NW - 1; ++q) wd0[u][q] = rec[u][r * NW + 1 + q];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < BS_UNROLL; ++u) {  // the next iteration's offsets
-      const int wn = w0 + (BS_UNROLL + u) * NGRP;
-      s0n[u] = s1n[u] = 0u;
-      if (wn < n_wg) { s0n[u] = o0[wn]; s1n[u] = o1[wn]; }
-    }
-#pragma unroll
-    for (int u = 0; u < BS_UNROLL; ++u) {
-      add(key0[u], wd0[u]);  // an absent record carries zeros: no atomics issued
-      for (uint32_t r = s0[u] + l16 + BS_GROUP; r < s1[u]; r += BS_GROUP) {
-        uint32_t wd[NW - 1];
-#pragma unroll
-        for (int q = 0; q < NW - 1; ++q) wd[q] = rec[u][r * NW + 1 + q];
-        add(rec[u][r * NW], wd);
+        for (int q = 0; q < NW; ++q) rv[q] = rec[1 + q];
+        add(rv);
       }
     }
   }
@@ -504,185 +641,20 @@ __global__ void __launch_bounds__(1024) bin_pass2_kernel(GridDesc desc, int shif
   const double inv = (double)out_scale / (double)fxs;
   float* o = out + ((size_t)desc.offset[lvl] + lo) * NV;
   for (int i = threadIdx.x; i < n_el; i += blockDim.x) {  // i = entry * NV + j in the table's layout
-    const long long v = acc[(i % NV) * seg + i / NV];
-    if (v != 0) o[i] += (float)((double)v * inv);  // sole owner of this segment
-  }
-}
-
-// ---- pass 2, flattened -----------------------------------------------------------------------------------------------------
-// bin_pass2_kernel gives every run (one pass-1 tile's records for this bin: 8 on average with pair records, Poisson-distributed)
-// to a group of BS_GROUP lanes, and a wavefront runs as many rounds as its LONGEST run needs: with 8 +- 3 records per run nearly
-// every wavefront runs two rounds of eight lanes per group for eight records -- half the lanes of every instruction idle in a
-// kernel that is bound by its ~100 VALU instructions per record (SQ_ACTIVE_INST_VALU x 8 wavefronts per SIMD = 80 %).
-// Here a wavefront takes 64 CONSECUTIVE tiles, reads their 64 + 64 bin offsets with two dense loads, forms the exclusive prefix of
-// the run lengths, and walks the concatenation of the 64 runs 64 records at a time: lane j of round q0 handles record q0 + j,
-// whichever run it belongs to.  The owner of a record position is found without a search: every tile's lane stamps its lane
-// number at the position where its run enters the 64-record window (LDS, one word per position, tagged with the round so that
-// nothing is ever cleared), and an inclusive maximum scan over the lanes (six DPP steps) hands every position the last stamp at
-// or before it -- runs are laid out in lane order, so that is its owner.  One ds_bpermute brings the owner's (slot start - prefix).
-template <int D, int NV, int CSHIFT = 0>
-__global__ void __launch_bounds__(1024) bin_pass2_flat_kernel(GridDesc desc, int shift_rt, int n_wg, int64_t P,
-                                                            const uint16_t* __restrict__ offs, const uint32_t* __restrict__ bins,
-                                                            const float* __restrict__ lvl_max, float* __restrict__ out, float out_scale) {
-  constexpr int NC = 1 << D;
-  constexpr int NW = RecWords<NV>::n;
-  extern __shared__ long long acc[];
-  __shared__ uint32_t owner_tag[16][64];  // (not volatile: that turned the accesses into flat_load / flat_store; the asm memory clobber below orders them)
-  const int shift = CSHIFT > 0 ? CSHIFT : shift_rt;
-  const int lvl = blockIdx.y;
-  const int b = (BS_XCD_BINS && gridDim.x % 8 == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
-  const uint32_t size = desc.size[lvl];
-  const bool hashed = (desc.hashed_mask >> lvl) & 1u;
-  const int nbins = (int)((size + (1u << shift) - 1) >> shift);
-  if (!hashed || !is_pow2(size) || nbins > BS_MAX_BINS || nbins <= 1 || b >= nbins) return;
-  const float gmax = lvl_max[lvl];
-  if (!(gmax > 0.0f)) return;
-  const uint32_t lo = (uint32_t)b << shift;
-  if (nonfinite(gmax)) {
-    if (threadIdx.x == 0) out[((size_t)desc.offset[lvl] + lo) * NV] = __builtin_nanf("");
-    return;
-  }
-  const int seg = CSHIFT > 0 ? (1 << CSHIFT) : (1 << shift);
-  const int n_ent = (int)min(1u << shift, size - lo);
-  const int n_el = n_ent * NV;
-  for (int i = threadIdx.x; i < seg * NV; i += blockDim.x) acc[i] = 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  owner_tag[wave][lane] = 0xFFFFFFFFu;
-  __syncthreads();
-  const float fxs = fx_scale(gmax * 16.5f, 30);
-  // one record = NW words, kept as ONE register tuple from its load to its use (separate scalars made the register allocator copy
-  // the words out of the load's destination right behind the load, i.e. wait for it there)
-  typedef uint32_t RecVec __attribute__((ext_vector_type(NW)));
-  auto add = [&](const RecVec rv) {  // as in bin_pass2_kernel
-    const uint32_t w0 = rv[0];
-    // (the halfs are taken out of the payload WORDS here, with shifts: read through a half_t pointer the words were split into
-    // 16-bit pieces where they are loaded)
-    auto hv_at = [&](int j) -> half_t { return __builtin_bit_cast(half_t, (unsigned short)(rv[1 + (j >> 1)] >> (16 * (j & 1)))); };
-    const uint32_t local = w0 & ((1u << BS_KEY_BITS) - 1u), code = (w0 >> BS_KEY_BITS) & 15u;
-    const bool single = code == BS_CODE_SINGLE;
-    const float f1 = single ? 0.0f : (float)(w0 >> (BS_KEY_BITS + 4)) * (1.0f / BS_FX_ONE);
-    const float s0 = (1.0f - f1) * fxs, s1 = f1 * fxs;
-    const uint32_t other = local ^ ((2u << code) - 1u);
-    unsigned long long* a0 = reinterpret_cast<unsigned long long*>(acc) + local;
-    unsigned long long* a1 = reinterpret_cast<unsigned long long*>(acc) + other;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const float v = h2f(hv_at(j));
-      if (v != 0.0f) {
-        const float2_t p = float2_t{s0, s1} * v;  // one v_pk_mul_f32
-        atomicAdd(a0 + j * seg, (unsigned long long)(long long)fx_round(p[0]));
-        if (!single) atomicAdd(a1 + j * seg, (unsigned long long)(long long)fx_round(p[1]));
-      }
-    }
-  };
-  const uint16_t* o0 = offs + ((uint64_t)lvl * (BS_MAX_BINS + 1) + b) * n_wg;
-  const uint16_t* o1 = o0 + n_wg;
-  constexpr uint32_t SLOT = (uint32_t)(BS_THREADS * NC) * NW;
-  const uint32_t* lvl_bins = bins + (uint64_t)lvl * n_wg * SLOT;
-  uint32_t stamp = 0u;
-  const int n_batches = (n_wg + 63) >> 6;
-  // the offsets of a wavefront's NEXT batch are fetched while the current one is walked
-  int w_n = wave * 64 + lane;
-  uint32_t s0_n = 0u, s1_n = 0u;
-  if (wave < n_batches && w_n < n_wg) { s0_n = o0[w_n]; s1_n = o1[w_n]; }
-  // Walk state (wave-uniform): the open batch of 64 tiles and the window position inside its concatenated runs.
-  int batch = wave - n_waves, tile0 = 0, base = 0;
-  uint32_t c = 0u, P0 = 0u, T = 0u, q0 = 0u;
-  // fetch: the next window of 64 records (opening the next batches as needed) -- finds every position's owner and ISSUES the record
-  // loads into (key, wd); nothing here waits for them.  false: no records left.
-  auto fetch = [&](RecVec& rv, bool& ok) -> bool {
-    while (q0 >= T) {  // (wave-uniform)
-      batch += n_waves;
-      if (batch >= n_batches) return false;
-      const uint32_t s0 = s0_n;
-      c = s1_n - s0_n;
-      tile0 = batch * 64;
-      {
-        const int wn = (batch + n_waves) * 64 + lane;
-        s0_n = s1_n = 0u;
-        if (batch + n_waves < n_batches && wn < n_wg) { s0_n = o0[wn]; s1_n = o1[wn]; }
-      }
-      // inclusive prefix sum of the run lengths over the wavefront (DPP: row scan, then the row totals carried upwards)
-      uint32_t inc = c;
-#define L4D_ADD_DPP(ctrl, rmask) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, ctrl, rmask, 0xf, true)
-      L4D_ADD_DPP(0x111, 0xf);  // row_shr:1 (bound_ctrl: lanes without a source add 0)
-      L4D_ADD_DPP(0x112, 0xf);
-      L4D_ADD_DPP(0x114, 0xf);
-      L4D_ADD_DPP(0x118, 0xf);
-      L4D_ADD_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-      L4D_ADD_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
-#undef L4D_ADD_DPP
-      P0 = inc - c;                                                   // records of the batch in front of this tile's run
-      T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);         // records of the batch
-      base = (int)s0 - (int)P0;                                       // record position q -> index in the tile's slot
-      q0 = 0u;
-    }
-    ++stamp;
-    // this tile's run enters the window [q0, q0 + 64) at position max(P0, q0) - q0, if it overlaps it at all
-    if (c != 0u && P0 < q0 + 64u && P0 + c > q0) owner_tag[wave][P0 > q0 ? P0 - q0 : 0u] = (stamp << 8) | (uint32_t)lane;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const uint32_t tv = owner_tag[wave][lane];
-    int own = (tv >> 8) == stamp ? (int)(tv & 255u) : -1;
-#define L4D_MAXI_DPP(ctrl, rmask) own = max(own, __builtin_amdgcn_update_dpp(-1, own, ctrl, rmask, 0xf, false))
-    L4D_MAXI_DPP(0x111, 0xf);
-    L4D_MAXI_DPP(0x112, 0xf);
-    L4D_MAXI_DPP(0x114, 0xf);
-    L4D_MAXI_DPP(0x118, 0xf);
-    L4D_MAXI_DPP(0x142, 0xa);
-    L4D_MAXI_DPP(0x143, 0xc);
-#undef L4D_MAXI_DPP
-    const uint32_t q = q0 + (uint32_t)lane;
-    ok = q < T;  // (then own >= 0: position q0 lies inside a run, whose tile stamped position 0)
-    const int ob = __shfl(base, ok ? own : lane, 64);
-    // UNCONDITIONAL loads (lanes behind the batch's last record read the level's first record and ignore it): loads inside an
-    // `if (ok)` made the compiler wait for them at the end of that block -- the merge with the default values is a copy
-    const uint32_t* rec = ok ? lvl_bins + (uint64_t)(uint32_t)(tile0 + own) * SLOT + (uint32_t)(ob + (int)q) * NW : lvl_bins;
-    __builtin_memcpy(&rv, rec, NW * sizeof(uint32_t));  // one global_load_dwordx2 / x3 (4-byte aligned; a 3-vector's size is 16)
-    q0 += 64u;
-    return true;
-  };
-  // Two windows in flight: the records of window n + 1 are requested before window n is accumulated (~100 VALU instructions and up
-  // to 2 NV LDS atomics per record), two register sets in turn so that no copy waits for a load.  (One window at a time, every
-  // wavefront sat out a full memory latency per 64 records: 1.86 ms against an issue floor of 1.0, profiles/r04_floor_table.md.)
-  RecVec rec_a = {}, rec_b = {};
-  bool ok_a, ok_b;
-  // The empty asm is where a window's records are waited for: BEFORE the next window is requested, so that exactly one request is
-  // outstanding at every wait (the compiler's s_waitcnt at a control-flow join is vmcnt(0): with two requests in flight it waited
-  // for the newer one as well, right behind its issue); the request then has the whole accumulation of the previous window to land.
-  bool more = fetch(rec_a, ok_a);
-  while (more) {
-    asm volatile("" : "+v"(rec_a));
-    const bool more_b = fetch(rec_b, ok_b);
-    if (ok_a) add(rec_a);
-    if (!more_b) break;
-    asm volatile("" : "+v"(rec_b));
-    more = fetch(rec_a, ok_a);
-    if (ok_b) add(rec_b);
-  }
-  __syncthreads();
-  const double inv = (double)out_scale / (double)fxs;
-  float* o = out + ((size_t)desc.offset[lvl] + lo) * NV;
-  for (int i = threadIdx.x; i < n_el; i += blockDim.x) {
-    const long long v = acc[(i % NV) * seg + i / NV];
-    if (v != 0) o[i] += (float)((double)v * inv);
+    const long long vv = acc[(i % NV) * seg + i / NV];
+    if (vv != 0) o[i] += (float)((double)vv * inv);  // sole owner of this segment
   }
 }
 
 // ---- host side ----------------------------------------------------------------------------------
 // Entries per bin = 2^shift: the bin's int64 accumulators take 2^shift * NV * 8 bytes of LDS in pass 2 (64 KB -> two
-// workgroups per CU, which is what hides the latency of the record walk), and more, smaller bins spread the pass-1
-// histogram atomics.  L4D_BS_SHIFT4 / L4D_BS_SHIFT2 override (tuning).
-static int bs_shift(int NV) {
-  const char* e = getenv(NV == 4 ? "L4D_BS_SHIFT4" : NV == 2 ? "L4D_BS_SHIFT2" : "L4D_BS_SHIFT1");
-  if (e && atoi(e) >= 9 && atoi(e) <= BS_KEY_BITS) return atoi(e);
-  return NV == 4 ? 11 : NV == 2 ? 11 : 13;  // (NV = 2, the flow grid: 4,096-entry bins 1.01 ms in the flattened pass 2, 2,048: 0.89, 1,024: 0.93)
-}
+// workgroups per CU), and more, smaller bins spread the pass-1 histogram atomics.  (NV = 2, the flow grid: 4,096-entry bins
+// 1.01 ms in pass 2, 2,048: 0.89, 1,024: 0.93; NV = 4: 4,096-entry bins need one workgroup per CU: 1.84 -> 2.14 ms.)
+static int bs_shift(int NV) { return NV == 4 ? 11 : NV == 2 ? 11 : 13; }
 
-// L4D_BS_FLAT=0 selects the run-per-lane-group form of pass 2 (bin_pass2_kernel); default: the flattened walk
-static bool bs_flat() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("L4D_BS_FLAT"); v = (e && atoi(e) == 0) ? 0 : 1; }
-  return v != 0;
+static inline bool bs_binned(const GridDesc& d, int l, int shift) {
+  const int64_t nb = ((int64_t)d.size[l] + (1 << shift) - 1) >> shift;
+  return ((d.hashed_mask >> l) & 1u) && is_pow2(d.size[l]) && nb <= BS_MAX_BINS && nb > 1;
 }
 
 BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
@@ -690,11 +662,33 @@ BsPlan bs_plan(const GridDesc& d, int n_dims, int NV, int64_t P) {
   pl.shift = bs_shift(NV);
   pl.rec_words = 1 + (NV + 1) / 2;
   pl.n_wg = ceil_div64(P, BS_THREADS);
-  const int64_t rec_per_wg = (int64_t)BS_THREADS << n_dims;  // room for 2^D records per lane (only those that exist are written)
+  // control block (zero-filled per call): level maxima, list cursors, overflow cursors, per-bin overflow counters
   pl.off_max = 0;
-  pl.off_offs = 256;
-  pl.off_bins = (pl.off_offs + (int64_t)d.n_levels * pl.n_wg * (BS_MAX_BINS + 1) * 2 + 255) / 256 * 256;
-  pl.bytes = pl.off_bins + (int64_t)d.n_levels * pl.n_wg * rec_per_wg * pl.rec_words * 4;
+  pl.off_cur = 256;
+  pl.off_ovf_cur = pl.off_cur + (int64_t)L4D_MAX_LEVELS * BS_LISTS * BS_MAX_BINS * 4;
+  pl.off_ovf_cnt = pl.off_ovf_cur + L4D_MAX_LEVELS * 4;
+  pl.ctrl_bytes = pl.off_ovf_cnt + (int64_t)L4D_MAX_LEVELS * BS_MAX_BINS * 4;
+  pl.off_lists = (pl.ctrl_bytes + 255) / 256 * 256;
+  uint64_t n_list = 0, n_ovf = 0;  // records
+  for (int l = 0; l < L4D_MAX_LEVELS; ++l) {
+    pl.lay.cap[l] = pl.lay.ovf_cap[l] = 0;
+    pl.lay.list_base[l] = n_list;
+    pl.lay.ovf_base[l] = n_ovf;
+    if (l >= d.n_levels || !bs_binned(d, l, pl.shift)) continue;
+    const int64_t nbins = ((int64_t)d.size[l] + (1 << pl.shift) - 1) >> pl.shift;
+    // expected share of a list: pair records (2^(D-1) per sample) spread over bins x lists; + 25 % + 8 sigma + 64, a multiple of 32
+    // records (list starts stay 128-byte aligned for 8- and 12-byte records)
+    const double mean = (double)P * (double)(1 << (n_dims - 1)) / (double)(nbins * BS_LISTS);
+    int64_t cap = (int64_t)(mean * 1.25 + 8.0 * sqrt(mean) + 64.0);
+    cap = (cap + 31) / 32 * 32;
+    const int64_t most = P << n_dims;  // a level cannot produce more records than this
+    pl.lay.cap[l] = (uint32_t)std::min<int64_t>(cap, (most + 31) / 32 * 32);
+    pl.lay.ovf_cap[l] = (uint32_t)std::min<int64_t>(most, 0xFFFFFFFFll);
+    n_list += (uint64_t)nbins * BS_LISTS * pl.lay.cap[l];
+    n_ovf += pl.lay.ovf_cap[l];
+  }
+  pl.off_ovf = (pl.off_lists + (int64_t)n_list * pl.rec_words * 4 + 255) / 256 * 256;
+  pl.bytes = pl.off_ovf + (int64_t)n_ovf * (pl.rec_words + 1) * 4;
   return pl;
 }
 
@@ -704,46 +698,32 @@ int bs_scatter(const GridDesc& desc, int n_dims, int NV, const float* x, int64_t
   const BsPlan pl = bs_plan(desc, n_dims, NV, P);
   char* ws = (char*)workspace;
   float* lvl_max = (float*)(ws + pl.off_max);
-  uint16_t* offs = (uint16_t*)(ws + pl.off_offs);
-  uint32_t* bins = (uint32_t*)(ws + pl.off_bins);
-  l4d_fill_async(ws, 0u, 256, stream);
+  uint32_t* cur = (uint32_t*)(ws + pl.off_cur);
+  uint32_t* ovf_cur = (uint32_t*)(ws + pl.off_ovf_cur);
+  uint32_t* ovf_cnt = (uint32_t*)(ws + pl.off_ovf_cnt);
+  uint32_t* lists = (uint32_t*)(ws + pl.off_lists);
+  uint32_t* ovf = (uint32_t*)(ws + pl.off_ovf);
+  if ((P << n_dims) >= ((int64_t)1 << 32)) { l4d_set_error(1, "bs_scatter: too many points for one launch"); return 1; }
+  l4d_fill_async(ws, 0u, pl.ctrl_bytes, stream);
   BsCols c;
   for (int d = 0; d < 3; ++d) c.c[d] = d < n_dims ? cols[d] : 0;
-  if ((int64_t)desc.n_levels * (BS_MAX_BINS + 1) * pl.n_wg >= ((int64_t)1 << 32)) { l4d_set_error(1, "bs_scatter: too many points for one launch"); return 1; }
-  for (int l = 0; l < desc.n_levels; ++l) {  // the pair records carry their code in key bits 24..27: BINNED levels only (hashed,
+  for (int l = 0; l < desc.n_levels; ++l)  // the pair records carry their code in key bits 24..27: BINNED levels only (hashed,
     // power-of-two table, <= BS_MAX_BINS bins); larger tables never reach the binned path (atomic fallback) and need no limit
-    const int64_t nb = ((int64_t)desc.size[l] + (1 << pl.shift) - 1) >> pl.shift;
-    const bool binned = ((desc.hashed_mask >> l) & 1u) && is_pow2(desc.size[l]) && nb <= BS_MAX_BINS && nb > 1;
-    if (binned && desc.size[l] > (1u << 24)) { l4d_set_error(1, "bs_scatter: more than 2^24 entries in a binned level"); return 1; }
-  }
+    if (bs_binned(desc, l, pl.shift) && desc.size[l] > (1u << 24)) { l4d_set_error(1, "bs_scatter: more than 2^24 entries in a binned level"); return 1; }
   int max_bins = 1;
   for (int l = 0; l < desc.n_levels; ++l) max_bins = std::max<int>(max_bins, (int)(((int64_t)desc.size[l] + (1 << pl.shift) - 1) >> pl.shift));
   max_bins = std::min(max_bins, BS_MAX_BINS);
   dim3 grid1((unsigned)xcd_grid(pl.n_wg));
   dim3 grid2(max_bins, desc.n_levels);
   const int lds2 = (1 << pl.shift) * NV * 8;
-#define BS_LAUNCH(D, V)                                                                                                      \
-  {                                                                                                                          \
-    L4D_LAUNCH((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride,   \
-                       g_col, pre_scale, pl.shift, (int64_t)pl.n_wg, offs, bins, lvl_max, out, out_scale);                                     \
-    constexpr int DEF = V == 4 ? 11 : V == 2 ? 11 : 13;  /* bs_shift()'s defaults: compile-time bin size */                       \
-    if (pl.shift == DEF && bs_flat()) {                                                                                      \
-      (void)hipFuncSetAttribute((const void*)bin_pass2_flat_kernel<D, V, DEF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);  \
-      L4D_LAUNCH((bin_pass2_flat_kernel<D, V, DEF>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins, \
-                 lvl_max, out, out_scale);                                                                                   \
-    } else if (bs_flat()) { /* a bin size other than the compiled-in one (L4D_BS_SHIFT*: tuning) */                          \
-      (void)hipFuncSetAttribute((const void*)bin_pass2_flat_kernel<D, V, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);    \
-      L4D_LAUNCH((bin_pass2_flat_kernel<D, V, 0>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins,   \
-                 lvl_max, out, out_scale);                                                                                   \
-    } else if (pl.shift == DEF) {                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V, DEF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);       \
-      L4D_LAUNCH((bin_pass2_kernel<D, V, DEF>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins,  \
-                 lvl_max, out, out_scale);                                                                                   \
-    } else {                                                                                                                 \
-      (void)hipFuncSetAttribute((const void*)bin_pass2_kernel<D, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);            \
-      L4D_LAUNCH((bin_pass2_kernel<D, V>), grid2, dim3(1024), lds2, stream, desc, pl.shift, (int)pl.n_wg, P, offs, bins,       \
-                 lvl_max, out, out_scale);                                                                                   \
-    }                                                                                                                        \
+#define BS_LAUNCH(D, V)                                                                                                          \
+  {                                                                                                                              \
+    L4D_LAUNCH((bin_pass1_kernel<D, V>), grid1, dim3(BS_THREADS), 0, stream, desc, x, P, x_stride, c, g, g_stride, g_col, pre_scale, \
+               pl.shift, (int64_t)pl.n_wg, pl.lay, cur, ovf_cur, ovf_cnt, lists, ovf, lvl_max, out, out_scale);                  \
+    constexpr int DEF = V == 4 ? 11 : V == 2 ? 11 : 13; /* bs_shift(): compile-time bin size */                                  \
+    (void)hipFuncSetAttribute((const void*)bin_reduce_kernel<D, V, DEF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);       \
+    L4D_LAUNCH((bin_reduce_kernel<D, V, DEF>), grid2, dim3(1024), lds2, stream, desc, pl.shift, pl.lay, cur, ovf_cur, ovf_cnt, lists, \
+               ovf, lvl_max, out, out_scale);                                                                                    \
   }
   if (n_dims == 3 && NV == 4) BS_LAUNCH(3, 4)
   else if (n_dims == 3 && NV == 2) BS_LAUNCH(3, 2)
