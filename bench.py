@@ -302,8 +302,8 @@ def parity_against(ref_path, dev, scale):
         o = m.render(pro.to(dev), prd.to(dev), torch.tensor([[25 / 50]], device=dev), num_steps=768, perturb=True, noise=noise.to(dev))
     rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
     depth, image = o["depth_lidar"].cpu().numpy(), o["image_lidar"].cpu().numpy()
-    from lidar4d_amd import mask_indices
-    got = set(mask_indices(o).tolist())
+    cnt = int(o["mask_count"])
+    got = set(o["mask_idx"][:cnt].tolist())
     want = set(np.nonzero(ref["mask"].reshape(-1))[0].tolist())
     w = ref["weights"].reshape(-1)
     off_threshold = [i for i in got ^ want if abs(float(w[i]) - 1e-4) >= 1e-7]

@@ -189,14 +189,6 @@ int l4d_sample_rays(const float* rays_o, const float* rays_d, const float* lin, 
 int l4d_composite_fwd(const float* sigma, const float* z_vals, int64_t N, int32_t T, float sample_dist,
                       float density_scale, int32_t active_sensor, float* weights, float* weights_sum,
                       float* depth, uint8_t* mask, int32_t* mask_idx, int32_t* mask_count, void* stream);
-/* l4d_composite_fwd with a PADDED work list: every ray's run of entries in mask_idx is at least pad_min long (1 <= pad_min <= 64,
- * <= T), short runs are filled up with -1 ("no sample"); mask_count[0] = rows of the list (padding included), mask_count[1] =
- * samples with weight > 1e-4 (what l4d_composite_fwd's mask_count holds).  A tile of pad_min consecutive rows then meets at most
- * two rays: the contract of l4d_attr_nets_fwd / _bwd (pad_min 32).  mask_idx: room for N * T entries. */
-int l4d_composite_fwd_padded(const float* sigma, const float* z_vals, int64_t N, int32_t T, float sample_dist,
-                             float density_scale, int32_t active_sensor, float* weights, float* weights_sum,
-                             float* depth, uint8_t* mask, int32_t* mask_idx, int32_t* mask_count /*[2]*/, int32_t pad_min,
-                             void* stream);
 /* image [N,C] = sum_t weights * attr [N*T, C]  (renderer.py:129) */
 int l4d_composite_image(const float* weights, const float* attr, int64_t N, int32_t T, int32_t C,
                         float* image, void* stream);
@@ -258,28 +250,6 @@ int l4d_attr_mlp_bwd_gathered(const int32_t* idx, const int32_t* count, int64_t 
                               const void* dy, const void* weights, void* dx_tail, float* grad_w, float inv_loss_scale,
                               const float* d_attr, const float* attr_compact, int32_t channel, float loss_scale, void* dh,
                               int32_t dh_accumulate, void* stream);
-
-/* BOTH attribute networks (model/lidar4d.py:208-216: raydrop_net and intensity_net read the same row h) with the direction
- * encoding hoisted out of the per-sample product: its share of the first layer, W1[:, 0:72] . enc(d), is one 64-vector per ray and
- * network (ray_term [2][n_rays][64] fp32, written by the forward, read again by the backward) and starts the first layer's
- * accumulator; per sample a K = 32 step over [1, g0 .. g14 | padding] is left.  The backward forms the encoding's weight gradient
- * from per-ray row sums of dZ1 (csrc/attr.hip).  Shape: in_pad 96, n_enc 72, n_geo 15, n_hidden 2 (the reference's defaults,
- * main_lidar4d.py:49-59); work list from l4d_composite_fwd_padded(pad_min = 32), count = its mask_count[0], cap < 2^31.
- * fwd: attr_dense [P,2] fp32 (zero-filled by the caller) <- (sigmoid(raydrop), sigmoid(intensity)) per listed sample, rounded to
- *      fp16 like the reference's; attr_compact [cap,2] <- the same per row.
- * bwd: d_attr [P,2], attr_compact as written by the forward; dh [P,16] fp16 holds the density activation's adjoint in column 0
- *      (l4d_sigma_bwd_rows) and receives the geo-feature gradients of both networks in columns 1 .. 15; grad_raydrop /
- *      grad_intensity: the networks' fp32 gradients [64 x 96 | 64 x 64 | 16 x 64] (+=, scaled by inv_loss_scale); workspace:
- *      l4d_attr_nets_bwd_workspace(n_rays, cap) bytes. */
-int l4d_attr_nets_fwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t n_rays, int32_t T, const void* dir_enc,
-                      int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* w_raydrop,
-                      const void* w_intensity, float* ray_term, float* attr_dense, float* attr_compact, void* stream);
-int64_t l4d_attr_nets_bwd_workspace(int32_t n_rays, int64_t cap);
-int l4d_attr_nets_bwd(const int32_t* idx, const int32_t* count, int64_t cap, int32_t n_rays, int32_t T, const void* dir_enc,
-                      int32_t n_enc, const void* h, int32_t n_geo, int32_t in_pad, int32_t n_hidden, const void* w_raydrop,
-                      const void* w_intensity, const float* ray_term, const float* d_attr, const float* attr_compact,
-                      float loss_scale, void* dh, float* grad_raydrop, float* grad_intensity, float inv_loss_scale,
-                      void* workspace, void* stream);
 /* sigma = trunc_exp(h[:,0]) (model/activation.py:6-20) on the sigma net's fp16 output h [P,16], and its
  * adjoint dh[:,0] = d_sigma * exp(clamp(h0,-15,15)) * loss_scale (fp16) */
 int l4d_sigma_from_h(const void* h, int64_t P, float* sigma, void* stream);

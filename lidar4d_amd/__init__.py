@@ -5,11 +5,11 @@ state-dict keys); kernels are hand-written HIP behind the C ABI of include/lidar
 fallback: the CPU restatement used for parity checks lives in ``oracle/`` (test infrastructure).
 """
 from . import tcnn  # noqa: F401  (tinycudann-compatible Encoding / Network)
-from .lidar4d import LiDAR4D, mask_indices  # noqa: F401
+from .lidar4d import LiDAR4D  # noqa: F401
 from .renderer import LiDAR_Renderer  # noqa: F401
 from .hash_field import HashGrid4D, HashGridT  # noqa: F401
 from .planes_field import Planes4D  # noqa: F401
 from .flow_field import FlowField  # noqa: F401
 from .activation import trunc_exp  # noqa: F401
 
-__all__ = ["LiDAR4D", "LiDAR_Renderer", "HashGrid4D", "HashGridT", "Planes4D", "FlowField", "trunc_exp", "tcnn", "mask_indices"]
+__all__ = ["LiDAR4D", "LiDAR_Renderer", "HashGrid4D", "HashGridT", "Planes4D", "FlowField", "trunc_exp", "tcnn"]

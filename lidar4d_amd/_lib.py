@@ -78,7 +78,6 @@ SIGNATURES = {
     "l4d_sample_rays": [P, P, P, P, I64, I32, F32, F32, F32, P, P, P],
     "l4d_sample_rays_xt": [P, P, P, P, P, I64, I32, F32, F32, F32, P, P, P],
     "l4d_composite_fwd": [P, P, I64, I32, F32, F32, I32, P, P, P, P, P, P, P],
-    "l4d_composite_fwd_padded": [P, P, I64, I32, F32, F32, I32, P, P, P, P, P, P, I32, P],
     "l4d_composite_image": [P, P, I64, I32, I32, P, P],
     "l4d_composite_bwd": [P, P, P, P, I64, I32, I32, F32, F32, I32, P, P, P, P, P, P, P],
     "l4d_attr_gather": [P, P, I64, I32, P, I32, P, I32, P, I32, P],
@@ -89,9 +88,6 @@ SIGNATURES = {
     "l4d_mlp_fwd_sigma": [P, I64, I32, I32, P, P, P, P, P],
     "l4d_attr_mlp_bwd": [P, P, I64, I32, I32, I32, I32, P, P, P, P, P, F32, P],
     "l4d_attr_mlp_bwd_gathered": [P, P, I64, I32, P, I32, P, I32, I32, I32, P, P, P, P, P, F32, P, P, I32, F32, P, I32, P],
-    "l4d_attr_nets_fwd": [P, P, I64, I32, I32, P, I32, P, I32, I32, I32, P, P, P, P, P, P],
-    "l4d_attr_nets_bwd_workspace": [I32, I64],
-    "l4d_attr_nets_bwd": [P, P, I64, I32, I32, P, I32, P, I32, I32, I32, P, P, P, P, P, F32, P, P, P, F32, P, P],
     "l4d_sigma_from_h": [P, I64, P, P],
     "l4d_sigma_bwd": [P, P, I64, F32, P, P],
     "l4d_sigma_bwd_rows": [P, P, I64, F32, P, P],

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64 * CF_RAYS) composite_fwd_kernel(const float
                                                            int active, float* __restrict__ weights,
                                                            float* __restrict__ weights_sum, float* __restrict__ depth,
                                                            uint8_t* __restrict__ mask, int32_t* __restrict__ mask_idx,
-                                                           int32_t* __restrict__ mask_count, int pad_min) {
+                                                           int32_t* __restrict__ mask_count) {
   // The work list's slots are reserved per WORKGROUP (16 rays): one returning atomic per ray on the one counter was 16,384
   // same-address atomics per launch, served one after the other -- 0.2 ms whatever the rest of the kernel did.
   __shared__ int wave_keep[CF_RAYS], block_base;
@@ -144,22 +144,14 @@ __global__ void __launch_bounds__(64 * CF_RAYS) composite_fwd_kernel(const float
     }
     // compaction: the workgroup's wavefronts post their counts, ONE atomicAdd reserves the slots of all of them (requested before
     // the stores below, consumed behind them), every wavefront takes its share in ray order
-    // pad_min > 0 (l4d_composite_fwd_padded): a ray's run of entries is never shorter than pad_min -- short runs are filled up
-    // with -1 ("no sample") -- so that a tile of pad_min consecutive work-list rows meets at most two rays (csrc/attr.hip);
-    // mask_count[0] then counts the rows of the list, mask_count[1] the samples
-    const int n_slots = (n_keep > 0 && n_keep < pad_min) ? pad_min : n_keep;
     if (mask_idx) {  // (uniform)
-      if (lane == 0) wave_keep[wave] = n_slots | (n_keep << 16);  // (both <= 64 * MAXC)
+      if (lane == 0) wave_keep[wave] = n_keep;
       __syncthreads();
       if (threadIdx.x == 0) {
-        int tot = 0, tot_true = 0;
+        int tot = 0;
 #pragma unroll
-        for (int w = 0; w < CF_RAYS; ++w) {
-          tot += wave_keep[w] & 0xFFFF;
-          tot_true += wave_keep[w] >> 16;
-        }
+        for (int w = 0; w < CF_RAYS; ++w) tot += wave_keep[w];
         block_base = tot > 0 ? atomicAdd(mask_count, tot) : 0;
-        if (pad_min > 0 && tot_true > 0) atomicAdd(mask_count + 1, tot_true);
       }
     }
     if (live) {
@@ -176,8 +168,7 @@ __global__ void __launch_bounds__(64 * CF_RAYS) composite_fwd_kernel(const float
     if (mask_idx) {
       __syncthreads();
       int base = block_base;
-      for (int w = 0; w < wave; ++w) base += wave_keep[w] & 0xFFFF;  // (wave-uniform)
-      if (lane < n_slots - n_keep) mask_idx[base + n_keep + lane] = -1;  // (padding: fewer than pad_min <= 64 entries)
+      for (int w = 0; w < wave; ++w) base += wave_keep[w];  // (wave-uniform)
       if (n_keep > 0) {
 #pragma unroll
         for (int k = 0; k < MAXC; ++k) {
@@ -551,28 +542,8 @@ extern "C" int l4d_composite_fwd(const float* sigma, const float* z_vals, int64_
     l4d_fill_async(mask_count, 0u, sizeof(int32_t), (hipStream_t)stream);
   }
   L4D_LAUNCH(composite_fwd_kernel, dim3((unsigned)ceil_div64(N, CF_RAYS)), dim3(64 * CF_RAYS), 0, (hipStream_t)stream, sigma, z_vals,
-                     N, T, sample_dist, density_scale, active_sensor, weights, weights_sum, depth, mask, mask_idx, mask_count, 0);
+                     N, T, sample_dist, density_scale, active_sensor, weights, weights_sum, depth, mask, mask_idx, mask_count);
   L4D_LAUNCH_CHECK("l4d_composite_fwd");
-  return 0;
-}
-
-// l4d_composite_fwd with a padded work list: every ray's run of entries in mask_idx is at least pad_min (<= 64, <= T) long, short
-// runs filled up with -1; mask_count[0] = rows of the list (padding included), mask_count[1] = samples with weight > 1e-4.
-// mask_idx needs room for N * T entries (a run is padded to at most T).
-extern "C" int l4d_composite_fwd_padded(const float* sigma, const float* z_vals, int64_t N, int32_t T, float sample_dist,
-                                        float density_scale, int32_t active_sensor, float* weights, float* weights_sum,
-                                        float* depth, uint8_t* mask, int32_t* mask_idx, int32_t* mask_count, int32_t pad_min,
-                                        void* stream) {
-  // (rays longer than one segment of 64 * MAXC samples are compacted segment by segment: the last one must hold pad_min samples too)
-  if (!mask_idx || !mask_count || pad_min < 1 || pad_min > 64 || pad_min > T || (T % (64 * MAXC) != 0 && T % (64 * MAXC) < pad_min)) {
-    l4d_set_error(1, "l4d_composite_fwd_padded: needs mask_idx, mask_count[2] and 1 <= pad_min <= min(64, T, T mod 1024 if not 0)");
-    return 1;
-  }
-  l4d_fill_async(mask_count, 0u, 2 * sizeof(int32_t), (hipStream_t)stream);
-  if (N == 0) return 0;
-  L4D_LAUNCH(composite_fwd_kernel, dim3((unsigned)ceil_div64(N, CF_RAYS)), dim3(64 * CF_RAYS), 0, (hipStream_t)stream, sigma, z_vals,
-                     N, T, sample_dist, density_scale, active_sensor, weights, weights_sum, depth, mask, mask_idx, mask_count, pad_min);
-  L4D_LAUNCH_CHECK("l4d_composite_fwd_padded");
   return 0;
 }
 

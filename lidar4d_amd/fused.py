@@ -124,28 +124,16 @@ class RenderFn(torch.autograd.Function):
                                                     save_act=train and not ops.mlp_recompute_supported(sn.in_pad, sn.n_hidden_layers))
 
         # compositing + mask compaction (renderer.py:98-110)
-        denc = ops.freq_fwd(((rays_d + 1) / 2).contiguous(), model.view_encoder.n_frequencies)
-        an = model.intensity_net
-        # the default shape: both attribute networks in one launch per direction, the direction encoding hoisted per ray
-        # (csrc/attr.hip); needs the padded work list (every ray's run of entries >= 32 rows)
-        paired = ops.attr_nets_supported(an.in_pad, denc.shape[1], model.geo_feat_dim, an.n_hidden_layers, T)
-        if paired:
-            weights, wsum, depth, idx, counts = ops.composite_fwd_padded(sigma, z_vals, sample_dist, model.density_scale, model.active_sensor)
-            rows, count = counts[0:1], counts[1:2]  # rows of the work list (with padding) / samples with weight > 1e-4
-        else:
-            weights, wsum, depth, _, idx, count = ops.composite_fwd(sigma, z_vals, sample_dist, model.density_scale,
-                                                                    model.active_sensor, want_mask=False, want_idx=True)
-            rows = count
+        weights, wsum, depth, _, idx, count = ops.composite_fwd(sigma, z_vals, sample_dist, model.density_scale,
+                                                                model.active_sensor, want_mask=False, want_idx=True)
 
         # attribute (lidar4d.py:191-223) on the compacted work list
+        denc = ops.freq_fwd(((rays_d + 1) / 2).contiguous(), model.view_encoder.n_frequencies)
+        an = model.intensity_net
         gathered = ops.attr_mlp_supported(an.in_pad, denc.shape[1], model.geo_feat_dim)
         attr = torch.zeros(P, 2, dtype=torch.float32, device=dev)
         attr_c = torch.empty(P, 2, dtype=torch.float32, device=dev)
-        XA = actR = actI = ray_term = None
-        if paired:
-            ray_term = ops.attr_nets_fwd(idx, rows, P, N, T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.raydrop_net.params),
-                                         store.half(model.intensity_net.params), an.n_hidden_layers, attr, attr_c)
-        elif gathered:  # the networks assemble their input rows themselves, forward and backward (three hidden layers: the first
+        if gathered:  # the networks assemble their input rows themselves, forward and backward (three hidden layers: the first
             # one stores them for the backward pass), and apply the sigmoid + scatter into the dense [P, 2] image as their
             # epilogue (lidar4d.py:210-219)
             keep_rows = train and not ops.attr_mlp_bwd_gathered_supported(an.n_hidden_layers)
@@ -163,21 +151,21 @@ class RenderFn(torch.autograd.Function):
         image = ops.composite_image(weights, attr, 2)
 
         if train:
-            ctx.model, ctx.T, ctx.sample_dist, ctx.gathered, ctx.paired = model, T, sample_dist, gathered, paired
+            ctx.model, ctx.T, ctx.sample_dist, ctx.gathered = model, T, sample_dist, gathered
             # the slice pair of THIS forward (LiDAR4D.run sets it per call; a later forward -- gradient accumulation, a no-grad
             # render -- must not change what this node's backward sees)
             ctx.slice_pair = getattr(model, "_host_slice_pair", None)
-            ctx.save_for_backward(t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, rows,
-                                  XA, actR, actI, attr, attr_c, denc, ray_term)
-        ctx.mark_non_differentiable(z_vals, idx, count, rows)
-        return depth, image, wsum, weights, z_vals, idx, count, rows
+            ctx.save_for_backward(t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count,
+                                  XA, actR, actI, attr, attr_c, denc)
+        ctx.mark_non_differentiable(z_vals, idx, count)
+        return depth, image, wsum, weights, z_vals, idx, count
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, d_depth, d_image, d_wsum, d_weights, _dz, _di, _dc, _dr):
+    def backward(ctx, d_depth, d_image, d_wsum, d_weights, _dz, _di, _dc):
         model, T, sample_dist = ctx.model, ctx.T, ctx.sample_dist
         (t_dev, tinfo, z_vals, xt, xf, flow16, act_f, X, h, act_s, sigma, weights, idx, count, XA, actR, actI, attr,
-         attr_c, denc, ray_term) = ctx.saved_tensors  # (count: rows of the work list, padding included)
+         attr_c, denc) = ctx.saved_tensors
         store = model._store
         store.prepare_grads()
         # the current frame's time-slice pair is what receives dynamic-hash gradients (hash_field.py:79-85): raise its
@@ -195,16 +183,7 @@ class RenderFn(torch.autograd.Function):
         an = model.intensity_net
         n_enc = model.view_encoder.n_output_dims
         sigma_done = False
-        if ctx.paired:
-            # both networks: the sigmoid-scatter adjoint in front, the sum + scatter of the two geo-feature gradients behind them, the
-            # direction encoding's weight gradient from per-ray row sums (csrc/attr.hip); dh starts as [density adjoint, 0 x 15]
-            dh = torch.empty(P, 16, dtype=torch.float16, device=dev)
-            ops.sigma_bwd_rows(sigma.view(-1), d_sigma.view(-1), ls, dh)
-            sigma_done = True
-            ops.attr_nets_bwd(idx, count, P, z_vals.shape[0], T, denc, h, model.geo_feat_dim, an.in_pad, store.half(model.raydrop_net.params),
-                              store.half(model.intensity_net.params), an.n_hidden_layers, ray_term, d_attr, attr_c, ls, dh,
-                              store.grad_view(model.raydrop_net.params), store.grad_view(model.intensity_net.params), inv)
-        elif ctx.gathered and XA is None:
+        if ctx.gathered and XA is None:
             # rows assembled again; the sigmoid-scatter adjoint in front of each network and the sum + scatter of the two
             # geo-feature gradients behind them run inside the kernels (first network stores into dh, second adds).  dh starts as
             # whole rows [density activation's adjoint, 0 x 15] (one dense pass instead of a zero fill + a strided column pass

@@ -125,20 +125,16 @@ class LiDAR4D(LiDAR_Renderer):
             t_host = time_host if time_host is not None else (float(time.reshape(-1)[0]) if torch.is_tensor(time) else float(time))
             idx = np.float32(t_host) * np.float32(n_slices - 1)
             self._host_slice_pair = (int(np.floor(idx)), int(np.ceil(idx)))
-        depth, image, wsum, weights, z_vals, idx, count, rows = RenderFn.apply(self, rays_o, rays_d, t_dev, noise, num_steps,
-                                                                              train, *params)
+        depth, image, wsum, weights, z_vals, idx, count = RenderFn.apply(self, rays_o, rays_d, t_dev, noise, num_steps,
+                                                                        train, *params)
         return {
             "depth_lidar": depth.view(*prefix),
             "image_lidar": image.view(*prefix, self.out_lidar_dim),
             "weights_sum_lidar": wsum,
             "weights": weights,
             "z_vals": z_vals,
-            # extras: the attribute work list = the `weights > 1e-4` sample indices (renderer.py:110), grouped by ray; for the default
-            # network shape every ray's run of entries is padded to >= 32 with -1 (csrc/attr.hip): mask_idx[:mask_rows] holds
-            # mask_count valid entries (device int32s; ``mask_indices(out)`` returns them as one tensor)
-            "mask_idx": idx,
-            "mask_rows": rows,
-            "mask_count": count,
+            "mask_idx": idx,      # extra: compacted `weights > 1e-4` sample indices (renderer.py:110) ...
+            "mask_count": count,  # ... and their number (device int32), the attribute work list
         }
 
     # -- operator-level API (lidar4d.py:124-223) -----------------------------------------------------------
@@ -206,10 +202,3 @@ class LiDAR4D(LiDAR_Renderer):
             {"params": self.intensity_net.parameters(), "lr": 0.1 * lr},
             {"params": self.raydrop_net.parameters(), "lr": 0.1 * lr},
         ]
-
-
-def mask_indices(out):
-    """The `weights > 1e-4` flat sample indices of a render result (the reference's ``x[mask]`` rows, renderer.py:110), without
-    the padding entries of the work list.  One host read of the list length."""
-    idx = out["mask_idx"][:int(out["mask_rows"])]
-    return idx[idx >= 0]

@@ -268,22 +268,6 @@ def composite_fwd(sigma, z_vals, sample_dist, density_scale, active_sensor, want
     return weights, wsum, depth, mask, idx, count
 
 
-def composite_fwd_padded(sigma, z_vals, sample_dist, density_scale, active_sensor, pad_min=32):
-    """composite_fwd whose work list pads every ray's run of entries to at least ``pad_min`` with -1 (csrc/render.hip
-    l4d_composite_fwd_padded).  -> weights, wsum, depth, idx, counts [2] int32 = (rows of the list, samples with weight > 1e-4)."""
-    _chk(sigma, torch.float32, "sigma"), _chk(z_vals, torch.float32, "z_vals")
-    N, T = z_vals.shape
-    dev = z_vals.device
-    weights = torch.empty(N, T, dtype=torch.float32, device=dev)
-    wsum = torch.empty(N, dtype=torch.float32, device=dev)
-    depth = torch.empty(N, dtype=torch.float32, device=dev)
-    idx = torch.empty(N * T, dtype=torch.int32, device=dev)
-    counts = torch.empty(2, dtype=torch.int32, device=dev)
-    call("l4d_composite_fwd_padded", _p(sigma), _p(z_vals), N, T, float(sample_dist), float(density_scale), int(active_sensor),
-         _p(weights), _p(wsum), _p(depth), None, _p(idx), _p(counts), int(pad_min), _stream())
-    return weights, wsum, depth, idx, counts
-
-
 def composite_image(weights, attr, C_out):
     _chk(weights, torch.float32, "weights"), _chk(attr, torch.float32, "attr")
     N, T = weights.shape
@@ -333,36 +317,6 @@ def attr_mlp_fwd(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, weights16, n
     call("l4d_attr_mlp_fwd", _p(idx), _p(count), cap, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad, n_hidden,
          _p(weights16), _p(y), _p(act), _p(x_rows_out), _p(attr_dense), _p(attr_compact), int(channel), _stream())
     return y, act
-
-
-def attr_nets_supported(in_pad, n_enc, n_geo, n_hidden, T):
-    """Shape of l4d_attr_nets_fwd / _bwd (both attribute networks, direction encoding hoisted per ray): the reference's defaults."""
-    return in_pad == 96 and n_enc == 72 and n_geo == 15 and n_hidden == 2 and T >= 32 and (T % 1024 == 0 or T % 1024 >= 32)
-
-
-def attr_nets_fwd(idx, count, cap, n_rays, T, dir_enc16, h16, n_geo, in_pad, w_raydrop16, w_intensity16, n_hidden, attr_dense, attr_compact):
-    """Both attribute networks on the padded work list (ops.composite_fwd_padded) -> ray_term [2, n_rays, 64] fp32 (kept for the
-    backward); attr_dense [P,2] / attr_compact [cap,2] receive the sigmoid outputs (raydrop, intensity)."""
-    _chk(idx, torch.int32, "idx"), _chk(count, torch.int32, "count"), _chk(dir_enc16, torch.float16, "dir_enc"), _chk(h16, torch.float16, "h")
-    _chk(w_raydrop16, torch.float16, "w_raydrop"), _chk(w_intensity16, torch.float16, "w_intensity")
-    _chk(attr_dense, torch.float32, "attr_dense"), _chk(attr_compact, torch.float32, "attr_compact")
-    ray_term = torch.empty(2, n_rays, 64, dtype=torch.float32, device=h16.device)
-    call("l4d_attr_nets_fwd", _p(idx), _p(count), cap, n_rays, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad, n_hidden,
-         _p(w_raydrop16), _p(w_intensity16), _p(ray_term), _p(attr_dense), _p(attr_compact), _stream())
-    return ray_term
-
-
-def attr_nets_bwd(idx, count, cap, n_rays, T, dir_enc16, h16, n_geo, in_pad, w_raydrop16, w_intensity16, n_hidden, ray_term, d_attr,
-                  attr_compact, loss_scale, dh16, grad_raydrop, grad_intensity, inv_loss_scale):
-    """Backward of attr_nets_fwd: parameter gradients (+=) and the geo-feature gradients of both networks into dh16[:, 1:16]
-    (column 0 = the density activation's adjoint, written before by sigma_bwd_rows, is kept)."""
-    _chk(idx, torch.int32, "idx"), _chk(count, torch.int32, "count"), _chk(dir_enc16, torch.float16, "dir_enc"), _chk(h16, torch.float16, "h")
-    _chk(ray_term, torch.float32, "ray_term"), _chk(d_attr, torch.float32, "d_attr"), _chk(attr_compact, torch.float32, "attr_compact")
-    _chk(dh16, torch.float16, "dh"), _chk(grad_raydrop, torch.float32, "grad_raydrop"), _chk(grad_intensity, torch.float32, "grad_intensity")
-    ws = torch.empty(_lib.lib().l4d_attr_nets_bwd_workspace(n_rays, cap), dtype=torch.uint8, device=h16.device)
-    call("l4d_attr_nets_bwd", _p(idx), _p(count), cap, n_rays, T, _p(dir_enc16), dir_enc16.shape[1], _p(h16), n_geo, in_pad, n_hidden,
-         _p(w_raydrop16), _p(w_intensity16), _p(ray_term), _p(d_attr), _p(attr_compact), float(loss_scale), _p(dh16),
-         _p(grad_raydrop), _p(grad_intensity), float(inv_loss_scale), _p(ws), _stream())
 
 
 def mlp_fwd_sigma(x16, weights16, n_hidden, save_act=True):

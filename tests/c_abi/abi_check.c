@@ -16,9 +16,6 @@ int main(void) {
       (fn_t)&l4d_attr_mlp_bwd,
       (fn_t)&l4d_attr_mlp_bwd_gathered,
       (fn_t)&l4d_attr_mlp_fwd,
-      (fn_t)&l4d_attr_nets_fwd,
-      (fn_t)&l4d_attr_nets_bwd,
-      (fn_t)&l4d_attr_nets_bwd_workspace,
       (fn_t)&l4d_attr_scatter,
       (fn_t)&l4d_attr_scatter_bwd,
       (fn_t)&l4d_cast_f32_to_f16,
@@ -38,7 +35,6 @@ int main(void) {
       (fn_t)&l4d_chamfer_workspace,
       (fn_t)&l4d_composite_bwd,
       (fn_t)&l4d_composite_fwd,
-      (fn_t)&l4d_composite_fwd_padded,
       (fn_t)&l4d_composite_image,
       (fn_t)&l4d_density_encode_bwd,
       (fn_t)&l4d_density_encode_bwd_workspace,

@@ -98,9 +98,8 @@ def render_both(ref, hip, frame, n_rays, steps, key):
     print(f"frame {frame}: " + " ".join(f"{k} {v:.2e}" for k, v in errs.items()) +
           f"  mask fraction {float(o_ref['mask'].float().mean()):.3f}")
     assert errs["depth"] < 1e-3 and errs["raydrop"] < 1e-3 and errs["intensity"] < 1e-3, errs
-    from lidar4d_amd import mask_indices
-    got = set(mask_indices(o).tolist())
-    assert len(got) == int(o["mask_count"])
+    cnt = int(o["mask_count"])
+    got = set(o["mask_idx"][:cnt].tolist())
     want = set(torch.nonzero(o_ref["mask"].reshape(-1)).reshape(-1).tolist())
     wref = o_ref["weights"].reshape(-1)
     for i in got ^ want:

@@ -462,78 +462,6 @@ def test_attr_mlp_gathered_equals_materialised():
     assert y.shape == (P, 16)
 
 
-@pytest.mark.parametrize("n_rays,T,keep_p", [(37, 64, 0.6), (300, 96, 0.5), (64, 768, 0.97), (129, 64, 0.06)])
-def test_attr_nets_hoisted_equals_gathered(n_rays, T, keep_p):
-    """l4d_attr_nets_fwd / _bwd (both attribute networks, the direction encoding's share of the first layer computed once per ray
-    and its weight gradient formed from per-ray row sums: csrc/attr.hip) against l4d_attr_mlp_fwd / _bwd_gathered, which multiply
-    every row by all 96 columns: the same fp16 operands and rounding points; the fp32 accumulation order of the first layer
-    differs (72 sequential products + one MFMA step instead of three steps), so results agree to an fp16 ulp on a few per cent of
-    the values.  The work list comes from l4d_composite_fwd_padded: every ray's run of entries is >= 32 rows, padded with -1
-    (keep_p 0.06: most runs are padding; 0.97 at T = 768: long runs, a tile boundary inside almost every ray)."""
-    from lidar4d_amd import ops
-    n_geo, in_pad, n_hidden, ls = 15, 96, 2, 128.0
-    P = n_rays * T
-    g = torch.Generator().manual_seed(n_rays)
-    dirs = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1).to(DEV)
-    denc = ops.freq_fwd(((dirs + 1) / 2).contiguous(), 12)
-    h = (torch.rand(P, 16, generator=g) * 2 - 1).half().to(DEV)
-    # a density whose compositing weights pass the 1e-4 threshold on about keep_p of the samples
-    z = torch.linspace(0.1, 1.0, T).repeat(n_rays, 1).contiguous().to(DEV)
-    sigma = (torch.rand(n_rays, T, generator=g) < keep_p).float().to(DEV) * 0.5 + 1e-7
-    _, _, _, idx_p, counts = ops.composite_fwd_padded(sigma, z, 0.9 / T, 1.0, False)
-    weights, _, _, _, idx_c, count_c = ops.composite_fwd(sigma, z, 0.9 / T, 1.0, False, want_mask=False, want_idx=True)
-    rows, M = int(counts[0]), int(counts[1])
-    assert M == int(count_c) and rows >= M and M > 0
-    listed = idx_p[:rows]
-    valid = listed[listed >= 0]
-    assert valid.numel() == M and set(valid.tolist()) == set(idx_c[:M].tolist())
-    # the padding contract: runs of one ray (valid entries followed by their -1s) are >= 32 rows long
-    ray_of = torch.where(listed >= 0, listed // T, torch.full_like(listed, -1))
-    run_id = torch.cumsum(((ray_of != torch.roll(ray_of, 1)) & (ray_of >= 0)).int(), 0)
-    run_id[0] = 1 if int(ray_of[0]) >= 0 else 0
-    assert int(torch.bincount(run_id[run_id > 0]).clamp(min=0)[1:].min()) >= 32
-    wR = (torch.rand(64 * in_pad + 64 * 64 + 16 * 64, generator=g) * 0.6 - 0.3).half().to(DEV)
-    wI = (torch.rand(64 * in_pad + 64 * 64 + 16 * 64, generator=g) * 0.6 - 0.3).half().to(DEV)
-    assert ops.attr_nets_supported(in_pad, denc.shape[1], n_geo, n_hidden, T)
-    # forward
-    a0, c0 = torch.zeros(P, 2, device=DEV), torch.zeros(P, 2, device=DEV)
-    for ch, w in ((0, wR), (1, wI)):
-        ops.attr_mlp_fwd(idx_c, count_c, P, T, denc, h, n_geo, in_pad, w, n_hidden, save_act=False, attr_dense=a0, attr_compact=c0, channel=ch)
-    a1, c1 = torch.zeros(P, 2, device=DEV), torch.zeros(P, 2, device=DEV)
-    ray_term = ops.attr_nets_fwd(idx_p, counts[0:1], P, n_rays, T, denc, h, n_geo, in_pad, wR, wI, n_hidden, a1, c1)
-    d = (a0 - a1).abs()
-    assert float(d.max()) <= 2e-3 and float((d > 0).float().mean()) < 0.05 and float(a1.abs().max()) > 0, (float(d.max()), float((d > 0).float().mean()))
-    assert bool(((a1 != 0).any(dim=1) == (a0 != 0).any(dim=1)).all())  # the same samples written
-    # backward (the hoisted path's own compact sigmoid outputs on its rows; the gathered path's on its rows)
-    d_attr = (torch.rand(P, 2, generator=g) * 2 - 1).to(DEV)
-    dsig = (torch.rand(P, generator=g) * 2 - 1).to(DEV)
-    sg = torch.ones(P, device=DEV)
-    dh0, dh1 = torch.empty(P, 16, dtype=torch.float16, device=DEV), torch.empty(P, 16, dtype=torch.float16, device=DEV)
-    ops.sigma_bwd_rows(sg, dsig, ls, dh0), ops.sigma_bwd_rows(sg, dsig, ls, dh1)
-    gR0, gI0, gR1, gI1 = (torch.zeros(wR.numel(), device=DEV) for _ in range(4))
-    for ch, (w, gw) in enumerate(((wR, gR0), (wI, gI0))):
-        ops.attr_mlp_bwd_gathered(idx_c, count_c, P, T, denc, h, n_geo, in_pad, None, None, w, n_hidden, gw, 1.0 / ls, d_attr=d_attr,
-                                  attr_compact=c0, channel=ch, loss_scale=ls, dh16=dh0, accumulate=(1 if ch == 1 else 0) | 2)
-    ops.attr_nets_bwd(idx_p, counts[0:1], P, n_rays, T, denc, h, n_geo, in_pad, wR, wI, n_hidden, ray_term, d_attr, c1, ls, dh1, gR1, gI1, 1.0 / ls)
-    assert torch.equal(dh0[:, 0], dh1[:, 0])  # the density activation's adjoint stays
-    ddh = (dh0.float() - dh1.float()).abs()
-    assert float(ddh.max()) <= 2e-2 * float(dh0.float().abs().max()) and float((ddh > 0).float().mean()) < 0.2, (float(ddh.max()), float(dh0.float().abs().max()))
-    for name, ga, gb in (("raydrop", gR0, gR1), ("intensity", gI0, gI1)):
-        scale = float(ga.abs().max())
-        assert scale > 0
-        e = (ga - gb).abs()
-        # every block of the parameter vector: W1's encoding columns (from the per-ray sums), its per-sample columns, W2, Wo
-        W1a, W1b = ga[:64 * 96].view(64, 96), gb[:64 * 96].view(64, 96)
-        for what, sl in (("W1 enc", (slice(None), slice(0, 72))), ("W1 geo", (slice(None), slice(72, 96)))):
-            blk = float(W1a[sl].abs().max())
-            assert blk > 0 and float((W1a[sl] - W1b[sl]).abs().max()) <= 5e-3 * blk, (name, what, float((W1a[sl] - W1b[sl]).abs().max()), blk)
-        assert float(e.max()) <= 5e-3 * scale, (name, float(e.max()), scale)
-    # empty list
-    zero = torch.zeros(2, dtype=torch.int32, device=DEV)
-    ops.attr_nets_fwd(idx_p, zero[0:1], P, n_rays, T, denc, h, n_geo, in_pad, wR, wI, n_hidden, a1, c1)
-    ops.attr_nets_bwd(idx_p, zero[0:1], P, n_rays, T, denc, h, n_geo, in_pad, wR, wI, n_hidden, ray_term, d_attr, c1, ls, dh1, gR1, gI1, 1.0 / ls)
-
-
 def test_mlp_fwd_sigma_epilogue():
     """l4d_mlp_fwd_sigma == l4d_mlp_fwd followed by l4d_sigma_from_h, bit for bit, on every width the model configs use."""
     from lidar4d_amd import ops

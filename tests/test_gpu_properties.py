@@ -130,13 +130,8 @@ def test_render_invariants_full_size(big):
     assert bool((z[:, 1:] > z[:, :-1]).all())                            # sortedness of sample positions
     assert float((out["depth_lidar"].view(-1) - (w * z).sum(-1)).abs().max()) < 1e-5
     assert bool((out["image_lidar"] >= 0).all()) and bool((out["image_lidar"] <= 1.0 + 1e-5).all())
-    from lidar4d_amd import mask_indices
     cnt = int(out["mask_count"])
-    idx = mask_indices(out).long()
-    # the work list's padding (csrc/attr.hip): every ray's run of entries is at least 32 rows, filled up with -1
-    listed = out["mask_idx"][:int(out["mask_rows"])]
-    starts = torch.nonzero(torch.cat([torch.ones(1, dtype=torch.bool, device=listed.device), (listed[1:] // T != listed[:-1] // T) & (listed[1:] >= 0)]))
-    assert idx.numel() == cnt and int(out["mask_rows"]) >= cnt and starts.numel() > 0
+    idx = out["mask_idx"][:cnt].long()
     assert cnt == int((w > 1e-4).sum()) and bool((w.view(-1)[idx] > 1e-4).all())   # compaction == dense mask
     assert idx.unique().numel() == cnt
     # staged (4 chunks of 4096 rays, renderer.py:159-177) == unstaged

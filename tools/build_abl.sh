@@ -9,9 +9,9 @@ make -s -j8 >/dev/null
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function"
 mkdir -p ../../tools/abl/obj_$name
 objs=""
-for src in hashgrid planes mlp attr render optim fused field_bwd binscatter chamfer convert glue; do
+for src in hashgrid planes mlp render optim fused field_bwd binscatter chamfer convert glue; do
   if [[ " $* " == *" $src.hip "* ]]; then
-    extra=""; [[ ( $src == mlp || $src == attr ) && "$defs" != *NO_VGPR_FORM* ]] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+    extra=""; [[ $src == mlp && "$defs" != *NO_VGPR_FORM* ]] && extra="-mllvm -amdgpu-mfma-vgpr-form"
     /opt/rocm/bin/hipcc $FLAGS $extra $defs -c $src.hip -o ../../tools/abl/obj_$name/$src.o
     objs="$objs ../../tools/abl/obj_$name/$src.o"
   else
