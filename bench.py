@@ -354,6 +354,9 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the per-kernel timing pass (0: no roofline block)")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of each secondary measurement (0: skip them)")
     ap.add_argument("--trained-steps", type=int, default=200, help="further training steps before the trained-state measurement")
+    ap.add_argument("--force-dist", action="store_true", help="under torchrun with ONE rank: take the multi-rank code path anyway (RCCL init, barrier, two-phase gradient all-reduce) -- exercises the data-parallel path on a single-GPU box")
+    ap.add_argument("--grad-transport", default="fp32", choices=("fp32", "bf16"), help="wire format of the hash-table / plane gradient ranges in the all-reduce (trainer.GradReducer)")
+    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce of the whole gradient arena behind the backward pass instead of two overlapped phases")
     return ap.parse_args()
 
 
@@ -542,9 +545,9 @@ def _run(args):
         return _run_plumbing(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # L4D_FORCE_DIST=1: take the multi-rank code path (RCCL init, barrier, gradient all-reduce) even with one rank --
+    # --force-dist: take the multi-rank code path (RCCL init, barrier, gradient all-reduce) even with one rank --
     # lets the data-parallel path be exercised on a single-GPU box (python -m torch.distributed.run --nproc-per-node 1)
-    force_dist = os.environ.get("L4D_FORCE_DIST") == "1" and "RANK" in os.environ
+    force_dist = args.force_dist and "RANK" in os.environ
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
@@ -561,7 +564,8 @@ def _run(args):
                              frame_seed=1000)  # every rank: its own rays, the same frame sequence (equal work per step)
     use_chamfer, use_flow = not args.no_chamfer, not args.no_flow
     trainer = Trainer(model, data, chamfer=use_chamfer and not inference, flow=use_flow and not inference, urf=args.urf,
-                      ema_decay=None if args.no_ema else 0.95)
+                      ema_decay=None if args.no_ema else 0.95, force_allreduce=force_dist, overlap_allreduce=not args.no_overlap,
+                      grad_transport=args.grad_transport)
     if inference:
         from lidar4d_amd.data import KITTI360_FOV
         from lidar4d_amd.metrics import PointsMeter
@@ -597,9 +601,6 @@ def _run(args):
             t0 = time.perf_counter()
             for k in range(data.num_frames):
                 trainer.train_step_graphed(k)
-                if os.environ.get("L4D_BENCH_TRACE"):
-                    torch.cuda.synchronize()
-                    sys.stderr.write("captured frame %d\n" % k), sys.stderr.flush()
             torch.cuda.synchronize()
             capture_s = time.perf_counter() - t0
             from lidar4d_amd.params import bump_epoch
@@ -638,9 +639,6 @@ def _run(args):
         while applied_in_a_row < 51 and settle_steps < args.settle_max:
             step()
             settle_steps += 1
-            if os.environ.get("L4D_BENCH_TRACE"):
-                torch.cuda.synchronize()
-                sys.stderr.write("settle step %d done\n" % settle_steps), sys.stderr.flush()
             now = int(opt_.steps.max())
             applied_in_a_row = applied_in_a_row + 1 if now > last else 0
             last = now

@@ -113,10 +113,9 @@ static SidePool* cur_pool() {
 #define g_event_next (pool->event_next)
 
 extern "C" int l4d_streams_mask(void) {
-  if (g_streams_mask < 0) {
-    const char* e = getenv("L4D_STREAMS");
-    g_streams_mask = e ? atoi(e) : 0;  // measured: the kernels of this path share their bottlenecks; concurrency buys 0 +- 0.4 ms
-  }
+  // (set through l4d_streams_config only; default 0.  Measured, DESIGN.md section 4: the kernels of this path share their
+  // bottlenecks; concurrency buys 0 +- 0.4 ms)
+  if (g_streams_mask < 0) g_streams_mask = 0;
   return g_streams_mask;
 }
 extern "C" int l4d_streams_config(int32_t mask) {

@@ -794,7 +794,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   half_t* gvs = (half_t*)(ws + w.gvs);
   half_t* gdynT = (half_t*)(ws + w.gdynT);
   float* xsoa = (float*)(ws + w.xsoa);  // [3][P] coordinates, written by the prep kernel
-  float* segb = getenv("L4D_NO_SEG_BOUNDS") ? nullptr : (float*)(ws + w.segb);  // [3][P / 64][2] first / last coordinate per 64-sample segment
+  float* segb = (float*)(ws + w.segb);  // [3][P / 64][2] first / last coordinate per 64-sample segment
   l4d_fill_async(ws, 0u, (int64_t)w.gvs, stream);  // stats + Hbuf
   l4d_copy_words_async(stats + ST_VMAX, plane_abs_max, 1, stream);
 
@@ -812,10 +812,8 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   // With the largest |dX| of the time-plane columns known beforehand (gd_absmax, from the sigma network's backward) the prep
   // kernel's work is done by the time-plane kernel itself (planes_dyn_lds_kernel<.., PREP = true>).
   const int colsA_ = 2 * d.planes.n_scales * 8, colD_ = colsA_ + d.hs.n_levels * 4;
-  const bool fused_prep = gd_absmax && plane_rows && colD_ % 8 == 0 && L3 % 8 == 0 && L3 <= 24 && in_pad % 8 == 0 && getenv("L4D_NO_FUSED_PREP") == nullptr;
-  // (L4D_PREP_SIDE=1, experiment: the prep kernel stays a launch of its own, but on the side stream of its consumers, next to the
-  // time-plane kernel -- possible for the same reason, the time planes' scale no longer comes from it)
-  const bool prep_side = !fused_prep && forked && gd_absmax && getenv("L4D_PREP_SIDE") != nullptr;
+  const bool fused_prep = gd_absmax && plane_rows && colD_ % 8 == 0 && L3 % 8 == 0 && L3 <= 24 && in_pad % 8 == 0;
+  const bool prep_side = false;  // (the preparation kernel on the side stream of its consumers: measured no gain in round 4, switch removed)
   if (fused_prep || prep_side) {
     l4d_copy_words_async(stats + ST_GD_MAX, gd_absmax, 1, stream);
   }
@@ -837,18 +835,15 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   // chunking: one chunk per workgroup column; few enough chunks that the flush traffic stays small
   // (one chunk per CU from 2,048 samples per chunk on: at the reference's own batch of 1,024 rays -- 786 k samples -- the former
   // rule of >= 8,192 samples per chunk left 96 workgroups for 256 CUs in the time-plane kernel, whose grid is the chunks)
-  static int chunk_min = -1;
-  if (chunk_min < 0) { const char* e = getenv("L4D_BWD_CHUNK_MIN"); chunk_min = (e && atoi(e) >= 64) ? atoi(e) : 2048; }
+  constexpr int chunk_min = 2048;
   int n_chunks = (int)std::min<int64_t>(256, std::max<int64_t>(1, ceil_div64(P, chunk_min)));
   const int64_t chunk = ceil_div64(P, n_chunks);
   n_chunks = (int)ceil_div64(P, chunk);
   // consecutive-lane = consecutive-sample-of-one-ray property, needed for the wave-level band skip
   const int wave_skip = samples_per_ray > 0 && samples_per_ray % 64 == 0 && chunk % 64 == 0;
   // the multi-pass LDS kernels may cut the samples into fewer, larger chunks than the time-plane kernel (whose grid IS the chunks):
-  // every workgroup flushes its whole LDS window once, so fewer chunks = less flush traffic (L4D_PSTAT_CHUNKS / L4D_DYNHASH_CHUNKS: tuning)
-  auto chunks_for = [&](const char* env, int dflt, int* n_out) -> int64_t {
-    const char* e = getenv(env);
-    int n = (e && atoi(e) >= 1 && atoi(e) <= 4096) ? atoi(e) : dflt;
+  // every workgroup flushes its whole LDS window once, so fewer chunks = less flush traffic
+  auto chunks_for = [&](int n, int* n_out) -> int64_t {
     n = (int)std::min<int64_t>(n, std::max<int64_t>(1, ceil_div64(P, 8192)));
     int64_t c = ceil_div64(ceil_div64(P, n), 64) * 64;  // whole 64-sample segments
     *n_out = (int)ceil_div64(P, c);
@@ -856,8 +851,8 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   };
   int n_chunks_ps = n_chunks, n_chunks_dh = n_chunks;
   // measured at C3 (gpurun_out/r4d): 128 chunks 1.67 / 1.47 ms (static planes / dynamic hash), 256: 1.72 / 1.50, 512: 2.00 / 1.60, 64: 1.74 / 1.53
-  const int64_t chunk_ps = wave_skip ? chunks_for("L4D_PSTAT_CHUNKS", 128, &n_chunks_ps) : chunk;
-  const int64_t chunk_dh = wave_skip ? chunks_for("L4D_DYNHASH_CHUNKS", 128, &n_chunks_dh) : chunk;
+  const int64_t chunk_ps = wave_skip ? chunks_for(128, &n_chunks_ps) : chunk;
+  const int64_t chunk_dh = wave_skip ? chunks_for(128, &n_chunks_dh) : chunk;
 
   // time planes
   {
@@ -921,12 +916,8 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     }
     // Levels larger than one 64 KB window (the xy stack: 2^15 entries = 256 KB of int64 accumulators) are walked in table parts,
     // and every part streams all samples again.  Those levels get a launch of their own with 128 KB parts (one workgroup per CU,
-    // half the passes; L4D_DYNHASH_BIG_KB = 64: the old form); the levels that fit 64 KB keep two workgroups per CU.
-    static int big_kb = -1;
-    if (big_kb < 0) {
-      const char* e = getenv("L4D_DYNHASH_BIG_KB");
-      big_kb = (e && (atoi(e) == 128 || atoi(e) == 64)) ? atoi(e) : 128;  // measured 1.51 -> 1.46 ms (gpurun_out/r4f)
-    }
+    // half the passes: measured 1.51 -> 1.46 ms against 64 KB parts, gpurun_out/r4f); the levels that fit 64 KB keep two workgroups per CU.
+    constexpr int big_kb = 128;
     for (int group = 0; group < 2; ++group) {  // 0: levels that fit DYNHASH_LDS_KB; 1: larger ones
       const int lds_kb = group == 0 ? DYNHASH_LDS_KB : big_kb;
       const int max_entries = (lds_kb * 1024) / 8, fit = (DYNHASH_LDS_KB * 1024) / 8;

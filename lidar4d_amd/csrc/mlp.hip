@@ -793,26 +793,15 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
 // Workgroups of a backward launch: every wavefront ends with a flush of its whole dW (atomics on the same few thousand
 // addresses from every wavefront of the grid), so no more workgroups than fill the chip: one per CU where the accumulators
 // leave one wavefront per SIMD (everything but the narrowest single-hidden-layer networks), two otherwise.  Measured at C3
-// (256 CUs): 256 workgroups 5.57 ms of backward kernels, 512 5.69, 384 7.17 (a round and a half).  L4D_MLP_BWD_GRID overrides.
+// (256 CUs): 256 workgroups 5.57 ms of backward kernels, 512 5.69, 384 7.17 (a round and a half).
 static int bwd_grid_cap(int in_pad, int n_hidden) {
-  static int n_cu = 0, forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("L4D_MLP_BWD_GRID");
-    forced = (e && atoi(e) >= 64 && atoi(e) <= 4096) ? atoi(e) : 0;
+  static int n_cu = 0;
+  if (n_cu <= 0) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
       n_cu = 256;
   }
-  if (forced) return forced;
-  if (in_pad <= 32) {  // the 16-/32-wide (flow) network: small accumulators; L4D_MLP_BWD_GRID_NARROW = workgroups per CU (tuning)
-    static int narrow = -1;
-    if (narrow < 0) {
-      const char* e = getenv("L4D_MLP_BWD_GRID_NARROW");
-      narrow = (e && atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0;
-    }
-    if (narrow) return narrow * n_cu;
-    if (in_pad <= 16 && n_hidden <= 2) return 2 * n_cu;  // compiled for two wavefronts per SIMD (MLP_BWD_NARROW_WAVES): two workgroups per CU
-  }
+  if (in_pad <= 16 && n_hidden <= 2) return 2 * n_cu;  // compiled for two wavefronts per SIMD (MLP_BWD_NARROW_WAVES): two workgroups per CU
   return (n_hidden >= 2 || in_pad >= 64) ? n_cu : 2 * n_cu;
 }
 

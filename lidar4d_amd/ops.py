@@ -205,8 +205,6 @@ def mlp_recompute_supported(in_pad, n_hidden):
     backward 1.64 -> 1.41 ms at 12.6 M rows) and, since round 5, the 128 -> 64 -> 16 density network (round 2 had measured that
     trade neutral, forward 0.91 -> 0.67 ms, backward 1.93 -> 2.13 ms; with today's kernels it is -0.17 ms per step).  Wider / deeper
     shapes spill registers and keep their activations."""
-    if os.environ.get("L4D_MLP_STORE_ACT") == "1":  # tuning: store the activations after all
-        return False
     if in_pad == 128 and n_hidden == 1:
         # the density network (round 5): its forward runs as the encode kernel's epilogue and stores 128 B less per sample, the backward
         # reads 128 B less and recomputes the hidden layer from the row it reads anyway: 32.08 -> 31.91 ms per step (gpurun_out/s6;
@@ -349,8 +347,8 @@ def attr_mlp_bwd_gathered_supported(n_hidden):
 
 def attr_mlp_recompute_supported(n_hidden):
     """Shapes for which l4d_attr_mlp_bwd_gathered recomputes the hidden activations (act = None): the forward then stores
-    nothing but the sigmoid outputs.  L4D_ATTR_RECOMP=0 switches it off (A/B)."""
-    return n_hidden <= 2 and os.environ.get("L4D_ATTR_RECOMP", "1") != "0"
+    nothing but the sigmoid outputs."""
+    return n_hidden <= 2
 
 
 def attr_mlp_bwd_gathered(idx, count, cap, T, dir_enc16, h16, n_geo, in_pad, act, dy16, weights16, n_hidden, grad_w, inv_loss_scale,

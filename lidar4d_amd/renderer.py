@@ -91,12 +91,12 @@ class LiDAR_Renderer(nn.Module):
         }
 
     # Staged inference renders a frame as 16-32 chunks of max_ray_batch rays (renderer.py:142-186).  With ``graph_staged``
-    # (opt in: attribute, or L4D_GRAPH_STAGED=1) full-size chunks of a no-grad render are captured ONCE into a hipGraph --
+    # (opt in: the attribute) full-size chunks of a no-grad render are captured ONCE into a hipGraph --
     # fixed shapes, the call's time stays on the device, no host decision depends on the data -- and replayed per chunk.
     # Bit-identical (tests/test_gpu_properties.py); measured on the 131,072-ray frame of BASELINE C5: 108.2 vs 107.7 ms, i.e.
     # nothing -- a 4096-ray chunk is 3.4 ms of kernel time and the host stays ahead of it.  Off by default; it pays where the
     # chunks are small (max_ray_batch of a few hundred rays).
-    graph_staged = os.environ.get("L4D_GRAPH_STAGED", "0") == "1"
+    graph_staged = False
 
     def _run_chunk_graphed(self, rays_o, rays_d, time, kwargs):
         """One full-size chunk through the captured graph.  The graph is keyed on the parameter state (ParamStore._key):

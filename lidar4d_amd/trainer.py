@@ -607,14 +607,14 @@ class GradReducer:
     and waits.  Without a preceding ``early()`` it falls back to one all-reduce of the whole arena."""
 
     def __init__(self, model, transport=None):
-        """transport: "fp32" (default: plain SUM all-reduce) or "bf16" (``L4D_GRAD_TRANSPORT=bf16``): the encoder range --
+        """transport: "fp32" (default: plain SUM all-reduce) or "bf16" (``Trainer(grad_transport="bf16")``): the encoder range --
         planes + hash tables, 97 % of the bytes -- travels as bf16 with fp32 accumulation on arrival: every rank sends chunk r
         of its gradient to rank r (all-to-all), sums the world_size chunks it received in fp32, and the reduced chunks are
         all-gathered as bf16.  Same wire pattern as a ring all-reduce (reduce-scatter + all-gather) at half the bytes per
         xGMI link; the reduced value is rounded to bf16 once (2^-9 relative: noise Adam's normalisation tolerates; inf / nan
         survive, so the overflow check still works).  The network ranges and the gates stay fp32."""
         self.store = st = model._store
-        self.transport = transport or os.environ.get("L4D_GRAD_TRANSPORT", "fp32")
+        self.transport = transport or "fp32"
         if self.transport not in ("fp32", "bf16"):
             raise ValueError(f"GradReducer: unknown transport {self.transport!r}")
         flow = [(off, n) for name, _, off, n, _ in st.entries if name.startswith("flow_net.")]
@@ -707,7 +707,8 @@ class Trainer:
 
     def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=True, flow=True, urf=False,
                  ema_decay=None, loss_scaler=True, init_scale=65536.0, depth_loss="l1", raydrop_loss="mse",
-                 intensity_loss="mse", epoch_steps=None):
+                 intensity_loss="mse", epoch_steps=None, fused_losses=True, force_allreduce=False, overlap_allreduce=True,
+                 grad_transport="fp32", graph_batch_inside=True):
         """Defaults follow the reference's default run: the ray chamfer term is always part of its step
         (runner.py:215-220) and ``--flow_loss`` defaults to True (main_lidar4d.py:67).
         chamfer: a mean over the rank's own rays, so under data parallelism it is scaled by 1/world before the SUM
@@ -718,10 +719,11 @@ class Trainer:
         self.model, self.dataset, self.num_steps, self.chamfer = model, dataset, num_steps, chamfer
         self.flow, self.urf, self.iters = flow, urf, iters
         self.loss_kinds = dict(depth_loss=depth_loss, raydrop_loss=raydrop_loss, intensity_loss=intensity_loss)
-        # the default criteria run as one fused node (primary_losses); any other choice, or L4D_TORCH_LOSSES=1, takes the torch
-        # restatement of runner.py:179-220 (lidar_loss / ray_chamfer_loss)
-        self.fused_losses = (depth_loss, raydrop_loss, intensity_loss) == ("l1", "mse", "mse") and os.environ.get("L4D_TORCH_LOSSES") != "1"
-        self.fused_flow_loss = os.environ.get("L4D_TORCH_LOSSES") != "1"  # the scene-flow term as one autograd node (_SceneFlowLossFn)
+        # the default criteria run as one fused node (primary_losses); any other choice, or fused_losses=False, takes the torch
+        # restatement of runner.py:179-220 (lidar_loss / ray_chamfer_loss; what the tests compare the fused nodes with)
+        self.fused_losses = (depth_loss, raydrop_loss, intensity_loss) == ("l1", "mse", "mse") and bool(fused_losses)
+        self.fused_flow_loss = bool(fused_losses)  # the scene-flow term as one autograd node (_SceneFlowLossFn)
+        self.graph_batch_inside = bool(graph_batch_inside)
         self.ema = FlatEMA(model, ema_decay) if ema_decay is not None else None  # runner.py:97-98
         self.epoch_steps = epoch_steps if epoch_steps is not None else getattr(dataset, "num_frames", 1)
         self.local_step = 0
@@ -731,12 +733,12 @@ class Trainer:
         self.scaler = DynamicLossScaler(model._store.flat.device, init_scale=init_scale) if loss_scaler else None
         model.reference_grad_none = False  # untouched time slices are gated on the device (FlatAdam), no host read-back
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        # a one-rank process group still runs the collective when asked to (bench.py L4D_FORCE_DIST: exercises RCCL on one GPU)
-        self.force_allreduce = dist.is_available() and dist.is_initialized() and os.environ.get("L4D_FORCE_DIST") == "1"
+        # a one-rank process group still runs the collective when asked to (bench.py --force-dist: exercises RCCL on one GPU)
+        self.force_allreduce = dist.is_available() and dist.is_initialized() and bool(force_allreduce)
         self.reducer = None
         if self.world > 1 or self.force_allreduce:
-            self.reducer = GradReducer(model)
-            if os.environ.get("L4D_NO_OVERLAP") != "1":
+            self.reducer = GradReducer(model, transport=grad_transport)
+            if overlap_allreduce:  # (False: one all-reduce of the whole arena behind the backward pass)
                 model._grads_ready_hook = self.reducer.early
 
     def compute_loss(self, data, out):
@@ -791,9 +793,9 @@ class Trainer:
             frame = self.dataset.next_frame()
         st = self.__dict__.setdefault("_step_graphs", {"pool": None, "graphs": {}})
         self.opt.device_schedule()
-        # L4D_GRAPH_BATCH=outside: the batch is drawn by eager launches into static buffers before every replay (debugging aid;
-        # default: the draw is part of the graph, the dataset's device generator is registered with it)
-        outside = os.environ.get("L4D_GRAPH_BATCH", "inside") == "outside"
+        # graph_batch_inside=False: the batch is drawn by eager launches into static buffers before every replay (debugging aid,
+        # tests/test_gpu_optim.py; default: the draw is part of the graph, the dataset's device generator is registered with it)
+        outside = not self.graph_batch_inside
         rec = st["graphs"].get(frame)
         if rec is None:
             static = None

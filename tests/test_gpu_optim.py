@@ -340,14 +340,13 @@ def test_graph_replay_equals_eager_step(streams, monkeypatch):
     from lidar4d_amd.data import KITTI360_SCALE, SyntheticKitti360
     from lidar4d_amd.params import bump_epoch
     from lidar4d_amd.trainer import Trainer
-    monkeypatch.setenv("L4D_GRAPH_BATCH", "outside")
     mask_was = ops.streams_mask()
     _lib.lib().l4d_streams_config(streams)
     try:
         torch.manual_seed(0)
         m = LiDAR4D(near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE).to(DEV)
         data = SyntheticKitti360(DEV, W=1024, num_rays=1024, seed=7, frame_seed=7)
-        tr = Trainer(m, data, iters=200, chamfer=True, flow=True, ema_decay=None, init_scale=1024.0)
+        tr = Trainer(m, data, iters=200, chamfer=True, flow=True, ema_decay=None, init_scale=1024.0, graph_batch_inside=False)
         st, opt = m._store, tr.opt
         batch = {k: (v.contiguous().clone() if torch.is_tensor(v) else v) for k, v in data.batch_for(20).items()}
         monkeypatch.setattr(data, "batch_for", lambda frame: batch)

@@ -44,11 +44,12 @@ print(json.dumps({"depth": h(out["depth_lidar"]), "image": h(out["image_lidar"])
 """
 
 
-def _run(env_extra):
+def _run(env_extra, want_stderr=False):
     env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    return (d, r.stderr) if want_stderr else d
 
 
 @pytest.fixture(scope="module")
@@ -66,3 +67,16 @@ def test_switch_reproduces_the_default_path(switch, default_digest):
     for k in ("grad_abs_sum", "grad_max", "grad_proj"):  # backward: the same contributions; float atomics order the dW / plane flushes
         a, b = got[k], default_digest[k]
         assert abs(a - b) <= 2e-4 * max(abs(b), 1e-12) + (1e-6 * default_digest["grad_abs_sum"] if k == "grad_proj" else 0.0), (switch, k, a, b)
+
+
+
+def test_trace_switch_names_every_launch_and_changes_nothing(default_digest):
+    """L4D_TRACE=1 (csrc/capi.cpp): every launch of the library is announced on stderr and followed by a stream synchronisation
+    whose status is printed -- the tool that finds the kernel behind an asynchronous fault.  Same outputs, same gradients."""
+    got, err = _run({"L4D_TRACE": "1"}, want_stderr=True)
+    for k in ("depth", "image", "weights"):
+        assert got[k] == default_digest[k], k
+    for name in ("density_encode_fwd_kernel", "composite_fwd_kernel", "bin_pass1_kernel", "bin_reduce_kernel", "planes_dyn_lds_kernel"):
+        assert "[l4d] launch (" + name in err or "[l4d] launch " + name in err, name
+    done = [l for l in err.splitlines() if l.startswith("[l4d] done")]
+    assert done and all(l.endswith(": ok") for l in done)

@@ -54,8 +54,8 @@ L4D_BENCH_DETAIL=$PWD/$O/bench_c3_1k_detail.json python bench.py --workload c3-1
 L4D_BENCH_DETAIL=$PWD/$O/bench_c3_1k_graph_detail.json python bench.py --workload c3-1k --graph --steps 40 --warmup 5 --no-cpu-baseline --variant-steps 0 --profile-steps 0 > $O/bench_c3_1k_graph.json 2> $O/bench_c3_1k_graph.err; echo "c3-1k graph rc=$?"
 export L4D_BENCH_DETAIL=$PWD/$O/bench_dist_detail.json
 D="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --no-cpu-baseline --variant-steps 0 --profile-steps 0"
-L4D_FORCE_DIST=1 $D > $O/bench_dist1.json 2> $O/bench_dist1.err; echo "dist1 rc=$?"
-L4D_FORCE_DIST=1 L4D_GRAD_TRANSPORT=bf16 $D > $O/bench_dist1_bf16.json 2> $O/bench_dist1_bf16.err; echo "dist1 bf16 rc=$?"
+$D --force-dist > $O/bench_dist1.json 2> $O/bench_dist1.err; echo "dist1 rc=$?"
+$D --force-dist --grad-transport bf16 > $O/bench_dist1_bf16.json 2> $O/bench_dist1_bf16.err; echo "dist1 bf16 rc=$?"
 python - <<PY
 import json
 for f in ("bench", "bench_graph", "bench_c2", "bench_c5", "bench_c3_1k", "bench_c3_1k_graph", "bench_dist1", "bench_dist1_bf16"):
