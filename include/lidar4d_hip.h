@@ -84,7 +84,9 @@ int l4d_hashgrid_fwd(const l4d_grid_desc* desc /*host*/, const float* x, int64_t
 /* The same with l4d_hashgrid_fwd_workspace() bytes of device scratch: the levels are evaluated one after the other over the whole
  * chip (every XCD's L2 then holds the ONE table in use instead of all of them), x-neighbour entry pairs in one 16-byte load where
  * they share an aligned pair (F = 4, 16-byte aligned table), level-major into the scratch, and a second streaming kernel writes
- * the rows.  Worthwhile from ~1e6 points with tables that exceed an L2 (4 MB). */
+ * the rows.  Worthwhile from ~1e6 points with tables that exceed an L2 (4 MB).
+ * With x_stride == 4 and cols = (0, 1, 2) (rows [x, y, z, t]) the level-major kernels read a point's row as ONE 16-byte load:
+ * x must then hold 4 * P readable floats (the fourth one of every row is loaded and ignored); l4d_hashgrid_t_fwd_ws likewise. */
 int64_t l4d_hashgrid_fwd_workspace(const l4d_grid_desc* desc /*host*/, int64_t P);
 int l4d_hashgrid_fwd_ws(const l4d_grid_desc* desc /*host*/, const float* x, int64_t P, int32_t x_stride,
                         const int32_t* cols /*host*/, const void* table, void* out, int32_t out_stride, void* workspace,
@@ -168,8 +170,8 @@ int l4d_mlp_fwd_sigma(const void* x, int64_t P, int32_t in_pad, int32_t n_hidden
 /* dy [P,16] fp16 (already multiplied by the caller's loss scale); dx [P, in_pad] fp16 or null;
  * grad_w fp32, same layout as weights, ACCUMULATED with 1/loss_scale applied.
  * act: the forward's saved activations, or null = recompute them from x inside the kernel (saves 128 B/row/layer of HBM
- * traffic twice; built for in_pad <= 32 with 1-3 hidden layers -- measured neutral at in_pad 128, and wider / deeper shapes
- * would spill registers: those return an error).
+ * traffic twice; built for in_pad <= 32 with 1-3 hidden layers and for the 128 -> 64 -> 16 density network, where it is the
+ * default of the fused path since round 5: -0.17 ms per step; other shapes would spill registers and return an error).
  * dx_absmax: null, or a device fp32 that receives (atomic max; zero it first) the largest |dx| of the input columns
  * [absmax_col_lo, absmax_col_hi) (multiples of 16) as the kernel stores them, +inf if one of them is not finite -- the
  * consumer of those columns then needs no pass of its own to scale its fixed-point accumulators (l4d_density_encode_bwd). */

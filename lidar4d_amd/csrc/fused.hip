@@ -538,11 +538,14 @@ static inline int64_t enc_ws_hs_offset(const l4d_field_desc* f, int64_t P) {
   const int64_t n_dyn = f->hash_dynamic[0].n_levels + f->hash_dynamic[1].n_levels + f->hash_dynamic[2].n_levels;
   return (n_dyn * P * 2 + 255) / 256 * 256 + (3 * P * 4 + 255) / 256 * 256 + (6 * P * 2 + 255) / 256 * 256;
 }
+// (the static grid's columns only where the pre-pass can run: F = 4 and enough points -- 0.8 GB at 12.6 M samples otherwise unused)
 extern "C" int64_t l4d_density_encode_fwd_workspace(const l4d_field_desc* f, int64_t P) {
-  return enc_ws_hs_offset(f, P) + (int64_t)f->hash_static.n_levels * P * 8;
+  const bool hs_cols = f->hash_static.n_features == 4 && P >= ENC_SPLIT_MIN_POINTS;
+  return enc_ws_hs_offset(f, P) + (hs_cols ? (int64_t)f->hash_static.n_levels * P * 8 : 0);
 }
 
 L4D_INTERNAL int l4d_hs_pairld();
+L4D_INTERNAL int l4d_hs_pair_ok(const GridDesc* g, int n_features, const void* table);
 L4D_INTERNAL int l4d_hashgrid_levels_launch(const GridDesc* g, int n_dims, int n_features, const float* x, int64_t P, int x_stride,
                                             const int* cols3, const void* table, void* lvlT, void* stream);
 // static grid through the level-major pre-pass (default; L4D_ENC_HS_SPLIT=0: gathered inside the encode kernel as in rounds 1-4)
@@ -624,10 +627,14 @@ static int encode_fwd_impl(const l4d_field_desc* f, const float* xt, const void*
              (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr, no_sigma)
   const SigmaOut no_sigma{nullptr, nullptr, nullptr, nullptr, 0};
   // the density network as the kernel's epilogue: the default network shape behind the level-major form of the encode
-  const bool sigma_fused = so && hs_pre && in_pad == 128 && n_hidden == 1 && enc_sigma_fused();
+  bool sigma_fused = so && hs_pre && in_pad == 128 && n_hidden == 1 && enc_sigma_fused();
+  const int lds = ENC_SIGMA_FRAGS * 1024 + ENC_SIGMA_THREADS * (in_pad + 8) * 2;
+  // (154 KB of dynamic LDS: a device that does not grant it takes the two-launch path below instead of failing at the launch)
+  if (sigma_fused && hipFuncSetAttribute((const void*)density_encode_fwd_kernel<true, true, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    (void)hipGetLastError();
+    sigma_fused = false;
+  }
   if (sigma_fused) {
-    const int lds = ENC_SIGMA_FRAGS * 1024 + ENC_SIGMA_THREADS * (in_pad + 8) * 2;
-    (void)hipFuncSetAttribute((const void*)density_encode_fwd_kernel<true, true, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     static int persistent = -1, n_cu = 0;
     if (persistent < 0) {
       const char* e = getenv("L4D_ENC_PERSISTENT");
@@ -643,7 +650,7 @@ static int encode_fwd_impl(const l4d_field_desc* f, const float* xt, const void*
   } else if (hs_pre) {
     L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 1>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
                (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)hsT, no_sigma);
-  } else if (!split && hd_scratch && plane_rows && l4d_hs_pairld() && (reinterpret_cast<uintptr_t>(d.hs_table) & 15) == 0) {
+  } else if (!split && hd_scratch && plane_rows && l4d_hs_pair_ok(&d.hs, f->hash_static.n_features, d.hs_table)) {
     L4D_LAUNCH((density_encode_fwd_kernel<true, true, 0, 2>), egrid, dim3(ENC_THREADS), enc_lds, main_s, d, xt,
                (const half_t*)flow16, tinfo, P, (const half_t*)hd_scratch, (half_t*)X, in_pad, pr, (const half_t*)nullptr, no_sigma);
   } else if (split) {  // plane columns while the side stream evaluates the xz / yz stacks, then the hash columns

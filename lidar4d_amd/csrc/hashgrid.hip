@@ -87,7 +87,10 @@ template <> struct NtVec<4> { typedef u32x2_t type; };
 template <> struct NtVec<8> { typedef u32x4_t type; };
 
 // coordinates of point p for the level-major kernels, non-temporal.  The render path's points are rows [x, y, z, t] of four floats:
-// one 16-byte load instead of three 4-byte loads into the same 16 bytes (block-uniform test)
+// one 16-byte load instead of three 4-byte loads into the same 16 bytes (block-uniform test).  The vector form reads the row's
+// FOURTH float as well: callers of the public entry points that pass x_stride == 4 and columns (0, 1, 2) must own 4 P floats
+// (include/lidar4d_hip.h, l4d_hashgrid_fwd_ws / l4d_hashgrid_t_fwd_ws) -- with any other stride or column choice only
+// the named columns are touched.
 template <int D>
 __device__ __forceinline__ void load_coords_nt(const float* __restrict__ x, int64_t p, int x_stride, const Cols& cols, float xin[D]) {
   if (D == 3 && x_stride == 4 && cols.c[0] == 0 && cols.c[1] == 1 && cols.c[2] == 2 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
@@ -158,6 +161,15 @@ L4D_INTERNAL int l4d_hs_pairld() {
   return v;
 }
 
+// The x-neighbour pair loads are legal where every pair is one aligned 16-byte load: F = 4, a 16-byte aligned table, and levels
+// that start on an even entry.  ONE predicate for both users (the level-major pre-pass below and the pair loads inside the
+// fused encode, fused.hip HSMODE 2: ADVICE r5).
+L4D_INTERNAL int l4d_hs_pair_ok(const GridDesc* g, int n_features, const void* table) {
+  bool ok = n_features == 4 && l4d_hs_pairld() && (reinterpret_cast<uintptr_t>(table) & 15) == 0;
+  for (int l = 0; l < g->n_levels; ++l) ok = ok && (g->offset[l] & 1u) == 0;
+  return ok ? 1 : 0;
+}
+
 // lvlT[level][P][F] <- grid (library-internal: also the first stage of l4d_density_encode_fwd's static-grid columns)
 L4D_INTERNAL int l4d_hashgrid_levels_launch(const GridDesc* g, int n_dims, int n_features, const float* x, int64_t P, int x_stride,
                                             const int* cols3, const void* table, void* lvlT, void* stream) {
@@ -171,8 +183,7 @@ L4D_INTERNAL int l4d_hashgrid_levels_launch(const GridDesc* g, int n_dims, int n
 #define CALL(D, F)                                                                                                             \
   L4D_LAUNCH((hashgrid_fwd_levels_kernel<D, F>), grid, block, 0, (hipStream_t)stream, *g, x, P, x_stride, c, (const half_t*)table, \
              n_tiles, (half_t*)lvlT, order);
-  bool pair_ok = n_features == 4 && l4d_hs_pairld() && (reinterpret_cast<uintptr_t>(table) & 15) == 0;  // 16-byte pairs need a 16-byte aligned table
-  for (int l = 0; l < g->n_levels; ++l) pair_ok = pair_ok && (g->offset[l] & 1u) == 0;                   // ... and levels that start on an even entry
+  const bool pair_ok = l4d_hs_pair_ok(g, n_features, table) != 0;
   if (pair_ok) {
     if (n_dims == 2)
       L4D_LAUNCH((hashgrid_fwd_levels_kernel<2, 4, true>), grid, block, 0, (hipStream_t)stream, *g, x, P, x_stride, c, (const half_t*)table, n_tiles, (half_t*)lvlT, order);

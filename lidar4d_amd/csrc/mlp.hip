@@ -876,7 +876,7 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
                (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1}, no_epi, dstat);    \
     done = true;                                                                                                     \
   }
-  X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3) X(8, 1)  // <8, 1> (the density network): measured neutral in round 2, again in round 5 (L4D_MLP_RECOMP_SIGMA=1); <6, 2> and wider / deeper spill registers
+  X(1, 1) X(1, 2) X(1, 3) X(2, 1) X(2, 2) X(2, 3) X(8, 1)  // <8, 1> (the density network): the fused path's default since round 5 (-0.17 ms per step; L4D_MLP_RECOMP_SIGMA=0 stores the activations); <6, 2> and wider / deeper spill registers
 #undef X
   if (!done && !act) {
     l4d_set_error(1, "l4d_mlp_bwd: act == null (recompute the activations) is only built for in_pad <= 32 and for the 128 -> 64 -> 16 shape");
