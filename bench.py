@@ -171,16 +171,13 @@ def kernel_models(model, P, M):
     m[f"mlp_fwd_kernel<{it_a}, {nh_a}>"] = dict(bound="hbm", bytes=(2 * a_pad + 32 + nh_a * 128) * M, flops=fl(a_pad, nh_a) * M, note="materialised input rows")
     m[f"mlp_bwd_kernel<{it_a}, {nh_a}, 0, {it_a}, true>"] = dict(bound="hbm", bytes=(4 * a_pad + nh_a * 128 + 32) * M, flops=2 * fl(a_pad, nh_a) * M, note="materialised input rows")
     rec = 4 * 12  # one 12-byte record per x-neighbour PAIR of corners (upper bound: equal-cell runs along a ray are merged first)
-    m["bin_pass1_kernel<3, 4>"] = dict(bound="hbm", bytes=(16 + 8 * L + L * rec) * P, note="static grid: xt + dX columns read, sorted records written (upper bound)")
-    m["bin_pass2_kernel<3, 4>"] = dict(bound="hbm", bytes=L * rec * P, note="static grid: records read, segments reduced in LDS")
+    m["bin_pass1_kernel<3, 4>"] = dict(bound="hbm", bytes=(16 + 8 * L + L * rec) * P, note="static grid: xt + dX columns read, records appended to the bin-major lists (upper bound)")
+    m["bin_reduce_kernel<3, 4, DEF>"] = dict(bound="hbm", bytes=L * rec * P, note="static grid: the bin's record lists streamed (whole lines, once), segments reduced in LDS int64 accumulators")
     rec2 = 4 * 8
     # (the flow grid's coarse levels -- 32 ... 345 cells per axis -- hold 5 ... 59 consecutive samples of a ray per cell: their runs
     # are merged before a record is formed, so far fewer than 4 records per sample and level exist: an upper bound)
     m["bin_pass1_kernel<3, 2>"] = dict(bound="hbm", bytes=(16 + 4 * Lf + Lf * rec2) * P, upper_bound=True, note="flow grid records (upper bound: merged runs emit fewer)")
-    m["bin_pass2_kernel<3, 2>"] = dict(bound="hbm", bytes=Lf * rec2 * P, upper_bound=True, note="flow grid records (upper bound: merged runs emit fewer)")
-    for k in ("bin_pass2_kernel<3, 4>", "bin_pass2_kernel<3, 2>"):  # launch-site names of the compile-time / run-time bin size variants
-        m[k[:-1] + ", DEF>"] = m[k[:-1] + ", 0>"] = m[k]
-        m[k.replace("pass2_kernel", "pass2_flat_kernel")[:-1] + ", DEF>"] = dict(m[k], note=m[k]["note"] + " (flattened walk: 64 tiles' runs per wavefront)")
+    m["bin_reduce_kernel<3, 2, DEF>"] = dict(bound="hbm", bytes=Lf * rec2 * P, upper_bound=True, note="flow grid records (upper bound: merged runs emit fewer)")
     m["field_bwd_prep_kernel"] = dict(bound="hbm", bytes=(16 + X + 3 * nS * 16 + 2 * n_dyn) * P, note="dX row read, plane factors + transposed dyn gradient written")
     m["planes_dyn_lds_kernel<true, false>"] = m["planes_dyn_lds_kernel<false, false>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
     m["planes_dyn_lds_kernel<true, true>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32 + 3 * nS * 16 + 2 * n_dyn + 12) * P,

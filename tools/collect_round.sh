@@ -20,5 +20,5 @@ cp $O/hbm_traffic_$T.json $P/hbm_traffic_$T.json
 cp $O/${T}_mfma_pmc.json $P/${T}_mfma_pmc.json
 cp $O/${T}_counter_calibration.txt $P/${T}_counter_calibration.txt
 { echo "library sha256[:16] $(cat gpurun_out/${T}_final/lib_sha.txt); python -m pytest tests -m gpu -q -rfE --tb=short (tools/gpu_final.sh $T)"; tail -n 6 gpurun_out/${T}_final/pytest.log; } > $P/${T}_pytest_gpu_final.txt
-python tools/floor_table.py $P/${T}_bench_c3_final_detail.json $O/pmc_inst.json $P/hbm_traffic_$T.json --md > $P/${T}_floor_table.md
+python tools/floor_table.py $P/${T}_bench_c3_final_detail.json $O/pmc_inst.json $P/hbm_traffic_$T.json --stats $P/${T}_kernel_stats_final.txt --md > $P/${T}_floor_table.md
 tail -n 2 $P/${T}_pytest_gpu_final.txt
