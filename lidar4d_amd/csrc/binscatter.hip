@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // Held 4 dwords (16 bytes of the row) at a time: the next 16 bytes are fetched while the last level of the current ones is
   // ranked.  (The kernel sits at the 128-register limit of its four wavefronts per SIMD: 8 dwords at a time -- rounds 4-5 -- left
   // no room for the four list reservations that wavefront 0 now carries from one level into the next.)
-  constexpr int GW = 4;
+  constexpr int GW = 4;  // (8 dwords at a time -- half the line fetches, 3.2 GB less at the fabric -- fits 126 registers but is slower: 2.00 -> 2.13 ms, session s18)
   const bool g_in_regs = n_lv * NV <= 32 && (g_stride * 2) % 16 == 0 && (g_col * 2) % 16 == 0;  // block-uniform
   typedef uint32_t GwVec __attribute__((ext_vector_type(GW)));  // a vector, so that a uniform index becomes relative VGPR addressing
   GwVec gw;
@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       gw[4 * q + 0] = u.x; gw[4 * q + 1] = u.y; gw[4 * q + 2] = u.z; gw[4 * q + 3] = u.w;
     }
   };
-  gw = GwVec{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int q = 0; q < GW; ++q) gw[q] = 0u;
   if (g_in_regs) gw_load(0);
   auto gw_pick = [&](int k) -> uint32_t { return gw[k & (GW - 1)]; };
   half_t gnext[NV];

@@ -17,6 +17,9 @@ Roofs (all measured on this chip):
   hbm     compulsory bytes of the byte model (bench.py kernel_models) / 6.3 TB/s achievable.
   miss    gather kernels: lines that miss an XCD's L2 arrive at 64 G lines/s (TCC_MISS of the traffic file).
   gather  gather kernels: 292 G distinct-address slots/s when every line hits (table-entry gathers only).
+  lds     LDS integer atomics: lane-operations of the kernel's accumulation scheme (per sample, from the kernels' own design:
+          the table below) x samples / the measured rate on random addresses (profiles/r01_ubench_lds_atomics.txt: ds_add_u32
+          4.8 T lane-ops/s, ds_add_u64 2.9 T/s chip-wide).  An upper bound of the count where zero contributions are skipped.
   taps    the fused encode's coherent plane taps: 240 vector loads per wavefront and 64 samples, >= 18 clocks of the CU's address
           path each however few texels they touch (tools/ubench/gather.hip run-length rows).
   gather+miss(+taps)  the sum (round 5: they add: level-major kernels run at slots / 292 G/s + misses / 64 G/s to within 10 %).
@@ -39,6 +42,14 @@ HBM = 6.3e12
 MISS_LINES = 64e9
 GATHER = 292e9
 TAP_LOADS_PER_WAVE, TAP_CLOCKS = 240, 18.0
+# LDS atomic lane-operations per SAMPLE and the rate that applies (the accumulation scheme of each kernel)
+LDS_U32, LDS_U64 = 4.8e12, 2.9e12
+LDS_ATOMICS = {"bin_reduce_kernel<3, 4": (8 * 4 * 2 * 4, LDS_U64),   # 8 levels x 4 pair records x 2 entries x 4 values
+               "bin_reduce_kernel<3, 2": (7 * 4 * 2 * 2, LDS_U64),   # flow grid: 7 binned levels, 2 values (upper bound: merged runs emit fewer)
+               "planes_static_lds_kernel": (384, LDS_U32),            # 3 planes x 4 scales x 4 texels x 8 channels
+               "dynhash_lds_kernel": (3 * 8 * 4, LDS_U64),            # 3 planes x 8 levels x 4 corners, one scalar per entry
+               "planes_dyn_lds_kernel": (50, LDS_U32),                # after the segmented row scans (measured average)
+               "bin_pass1_kernel<3, 4": (8 * 4, LDS_U32), "bin_pass1_kernel<3, 2": (7 * 4, LDS_U32)}  # ranks (returning)
 # wavefronts per SIMD where no kernel-trace summary is given (registers / LDS / workgroup size of the default build)
 OCCUPANCY = {"density_encode_fwd_kernel": 2, "planes_dyn_lds_kernel": 3, "mlp_bwd_kernel<6": 1, "mlp_bwd_kernel<8": 1, "mlp_bwd_kernel<1": 2,
              "dynhash_fwd_lds_kernel": 4, "bin_pass1_kernel": 4, "bin_reduce_kernel": 8, "hashgrid_fwd_levels_kernel": 8,
@@ -117,6 +128,10 @@ def main():
             floors["miss"] = tv["l2_misses"] / MISS_LINES * 1e3 * r.get("modelled_launches_per_step", n)
         if "hash_gathers_G_per_s" in r:
             floors["gather"] = r["hash_gathers_G_per_s"] * 1e9 * r["modelled_launch_ms"] * 1e-3 / GATHER * 1e3 * r.get("modelled_launches_per_step", n)
+        for k, (per_sample, rate) in LDS_ATOMICS.items():
+            samples = detail.get("roofline", {}).get("samples_per_launch") or 0
+            if name.startswith(k) and samples:
+                floors["lds"] = per_sample * samples / rate * 1e3
         if name.startswith("density_encode_fwd_kernel") and r.get("bytes_per_launch"):
             samples = detail.get("roofline", {}).get("samples_per_launch") or 0
             if samples:
