@@ -351,6 +351,8 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the per-kernel timing pass (0: no roofline block)")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of each secondary measurement (0: skip them)")
     ap.add_argument("--trained-steps", type=int, default=200, help="further training steps before the trained-state measurement")
+    ap.add_argument("--flow-stream", dest="flow_stream", action="store_true", default=None, help="the scene-flow term on a stream of its own next to the render path (Trainer(flow_loss_stream=True))")
+    ap.add_argument("--no-flow-stream", dest="flow_stream", action="store_false", help="... on the render path's stream")
     ap.add_argument("--force-dist", action="store_true", help="under torchrun with ONE rank: take the multi-rank code path anyway (RCCL init, barrier, two-phase gradient all-reduce) -- exercises the data-parallel path on a single-GPU box")
     ap.add_argument("--grad-transport", default="fp32", choices=("fp32", "bf16"), help="wire format of the hash-table / plane gradient ranges in the all-reduce (trainer.GradReducer)")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce of the whole gradient arena behind the backward pass instead of two overlapped phases")
@@ -562,7 +564,7 @@ def _run(args):
     use_chamfer, use_flow = not args.no_chamfer, not args.no_flow
     trainer = Trainer(model, data, chamfer=use_chamfer and not inference, flow=use_flow and not inference, urf=args.urf,
                       ema_decay=None if args.no_ema else 0.95, force_allreduce=force_dist, overlap_allreduce=not args.no_overlap,
-                      grad_transport=args.grad_transport)
+                      grad_transport=args.grad_transport, flow_loss_stream=args.flow_stream is not False)
     if inference:
         from lidar4d_amd.data import KITTI360_FOV
         from lidar4d_amd.metrics import PointsMeter

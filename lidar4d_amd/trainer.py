@@ -323,9 +323,17 @@ class _SceneFlowLossFn(torch.autograd.Function):
             ggrid = torch.zeros(g_grid.numel(), dtype=torch.float32, device=dev)
             dxf = ops.mlp_bwd(xf, act, dy16, w16, fn.n_hidden, gw, 1.0)
             ops.hashgrid_t_bwd(fn.grid_enc.meta, xt, (0, 1, 2), 1, xt[0, 3:4], dxf, [ggrid], 1.0)
-            ops.call("l4d_axpy_dev", ops._p(g_w), ops._p(gw), gw.numel(), ops._p(inv), ops._stream())
-            ops.call("l4d_axpy_dev", ops._p(g_grid), ops._p(ggrid), ggrid.numel(), ops._p(inv), ops._stream())
+            pending = getattr(model, "_flow_loss_pending", None)
+            if pending is not None:  # (Trainer with the scene-flow term on a side stream: added to the arena once the render path's own
+                pending.append((g_w, gw, g_grid, ggrid, inv))  # flow-field gradients are in -- both write the same ranges, plain stores)
+            else:
+                _apply_flow_grads(g_w, gw, g_grid, ggrid, inv)
         return (None,) * (6 + len(fn_params(model)))
+
+
+def _apply_flow_grads(g_w, gw, g_grid, ggrid, inv):
+    ops.call("l4d_axpy_dev", ops._p(g_w), ops._p(gw), gw.numel(), ops._p(inv), ops._stream())
+    ops.call("l4d_axpy_dev", ops._p(g_grid), ops._p(ggrid), ggrid.numel(), ops._p(inv), ops._stream())
 
 
 def fn_params(model):
@@ -708,7 +716,7 @@ class Trainer:
     def __init__(self, model, dataset, lr=1e-2, iters=30000, num_steps=768, chamfer=True, flow=True, urf=False,
                  ema_decay=None, loss_scaler=True, init_scale=65536.0, depth_loss="l1", raydrop_loss="mse",
                  intensity_loss="mse", epoch_steps=None, fused_losses=True, force_allreduce=False, overlap_allreduce=True,
-                 grad_transport="fp32", graph_batch_inside=True):
+                 grad_transport="fp32", graph_batch_inside=True, flow_loss_stream=True):
         """Defaults follow the reference's default run: the ray chamfer term is always part of its step
         (runner.py:215-220) and ``--flow_loss`` defaults to True (main_lidar4d.py:67).
         chamfer: a mean over the rank's own rays, so under data parallelism it is scaled by 1/world before the SUM
@@ -724,6 +732,10 @@ class Trainer:
         self.fused_losses = (depth_loss, raydrop_loss, intensity_loss) == ("l1", "mse", "mse") and bool(fused_losses)
         self.fused_flow_loss = bool(fused_losses)  # the scene-flow term as one autograd node (_SceneFlowLossFn)
         self.graph_batch_inside = bool(graph_batch_inside)
+        # flow_loss_stream: the scene-flow term (about 50 small launches on a frame's point clouds, none of which fills the chip) runs
+        # on a stream of its own next to the render path's forward and backward (eager steps only; a captured step keeps one stream)
+        self.flow_loss_stream = bool(flow_loss_stream)
+        self._flow_stream = None
         self.ema = FlatEMA(model, ema_decay) if ema_decay is not None else None  # runner.py:97-98
         self.epoch_steps = epoch_steps if epoch_steps is not None else getattr(dataset, "num_frames", 1)
         self.local_step = 0
@@ -741,18 +753,19 @@ class Trainer:
             if overlap_allreduce:  # (False: one all-reduce of the whole arena behind the backward pass)
                 model._grads_ready_hook = self.reducer.early
 
-    def compute_loss(self, data, out):
-        """The reference's training loss (runner.py:179-276,277-367) for one batch and its render outputs."""
+    def compute_loss(self, data, out, flow_term=None):
+        """The reference's training loss (runner.py:179-276,277-367) for one batch and its render outputs.
+        flow_term: the scene-flow term if the caller has evaluated it already (train_step on a side stream)."""
         if self.fused_losses and out["depth_lidar"].is_cuda:
             loss = primary_losses(out, data, self.dataset.scale, chamfer=self.chamfer, world=self.world)
         else:
             loss = lidar_loss(out, data["images_lidar"], scale=self.dataset.scale, **self.loss_kinds)
             if self.chamfer:
                 loss = loss + ray_chamfer_loss(out, data, self.dataset.scale) / self.world
-        if self.flow:
-            known = frame_index(data["time_host"], self.dataset.num_frames) if "time_host" in data else None
-            loss = loss + flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames,
-                                    frame_idx=known, fused=self.fused_flow_loss)
+        if self.flow and flow_term is not None:
+            loss = loss + flow_term
+        elif self.flow:
+            loss = loss + self._flow_term(data)
         patch = getattr(self.dataset, "patch_size_lidar", 1)
         if patch != 1:  # rays were drawn as pixel patches (runner.py:277-367); a sum over this rank's patches
             gt = data["images_lidar"]
@@ -762,6 +775,11 @@ class Trainer:
             gt = data["images_lidar"]
             loss = loss + urf_loss(out, gt[:, :, 2] * gt[:, :, 0], self.opt.step_count, self.iters) / self.world
         return loss
+
+    def _flow_term(self, data):
+        known = frame_index(data["time_host"], self.dataset.num_frames) if "time_host" in data else None
+        return flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames, frame_idx=known,
+                         fused=self.fused_flow_loss)
 
     def train_step(self, data=None):
         data = data if data is not None else self.dataset.batch()
@@ -837,11 +855,36 @@ class Trainer:
 
     def _step_device_work(self, data):
         self.opt.zero_grad()
-        out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
-                                num_steps=self.num_steps, time_host=data.get("time_host"))
-        loss = self.compute_loss(data, out)
-        (self.scaler.scale(loss) if self.scaler is not None else loss).backward()  # runner.py:506
         st = self.model._store
+        side, flow_term = None, None
+        try:
+            if (self.flow and self.flow_loss_stream and self.fused_flow_loss and st.flat.is_cuda
+                    and not torch.cuda.is_current_stream_capturing()):
+                # the scene-flow term on its own stream: forward next to the render forward, backward (autograd runs a node on the
+                # stream of its forward) next to the render backward; its parameter gradients wait in private buffers
+                # (model._flow_loss_pending).  Measured at C3: 30.19 -> 29.76 ms per step (session s19 of round 6).
+                main = torch.cuda.current_stream()
+                side = self._flow_stream = self._flow_stream or torch.cuda.Stream()
+                side.wait_stream(main)  # (the gradient fill above, last step's Adam: parameters and fp16 copies are current)
+                self.model._flow_loss_pending = []
+                with torch.cuda.stream(side):
+                    flow_term = self._flow_term(data)
+            out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
+                                    num_steps=self.num_steps, time_host=data.get("time_host"))
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+                flow_term.record_stream(torch.cuda.current_stream())
+            loss = self.compute_loss(data, out, flow_term=flow_term)
+            (self.scaler.scale(loss) if self.scaler is not None else loss).backward()  # runner.py:506
+            if side is not None:  # the render path's flow-field gradients are in the arena: add the scene-flow term's
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for args in self.model._flow_loss_pending:
+                        _apply_flow_grads(*args)
+                torch.cuda.current_stream().wait_stream(side)
+        finally:
+            if side is not None:
+                self.model._flow_loss_pending = None
         if self.flow:
             st.prepare_grads()  # fold gradients autograd produced outside the fused node into the arena
         if self.reducer is not None:

@@ -100,6 +100,48 @@ def test_trainer_step_fused_equals_torch_losses():
     assert differing < 2e-3, differing
 
 
+def test_flow_loss_on_its_own_stream_equals_single_stream(monkeypatch):
+    """Trainer(flow_loss_stream=True): the scene-flow term's forward and backward run on a second stream next to the render path; its
+    parameter gradients wait in private buffers and are added to the arena once the render path's own flow-field gradients are in
+    (both write the same ranges with plain stores).  Same loss and -- compared BEFORE the optimiser touches them -- the same gradient
+    arena as the one-stream step, several steps in a row from the same state (a race would show as a run-to-run difference), on a
+    batch large enough that the two streams really overlap."""
+    from lidar4d_amd import LiDAR4D
+    from lidar4d_amd.data import KITTI360_SCALE, SyntheticKitti360
+    from lidar4d_amd import trainer as trainer_mod
+    from lidar4d_amd.trainer import Trainer
+    torch.manual_seed(0)
+    model = LiDAR4D(near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE).to(DEV)
+    data = SyntheticKitti360(DEV, W=1024, num_rays=2048, seed=7, frame_seed=7)
+    # (the ground points' random time is pinned: on its own stream the term is evaluated BEFORE the render draws its sample jitter,
+    # i.e. the two orders consume the generator differently)
+    tg, fl_fn = torch.tensor([0.37], device=DEV), trainer_mod.flow_loss
+    monkeypatch.setattr(trainer_mod, "flow_loss", lambda *a, **kw: fl_fn(*a, **{**kw, "t_ground": tg}))
+    batch = {k: (v.contiguous().clone() if torch.is_tensor(v) else v) for k, v in data.batch_for(20).items()}
+    grads = {}
+    for side in (False, True, True, False, True):
+        tr = Trainer(model, data, iters=200, chamfer=True, flow=True, ema_decay=None, init_scale=1024.0, flow_loss_stream=side)
+        got = []
+        step = tr.opt.step
+        tr.opt.step = lambda **kw: got.append(model._store.flat_grad.detach().clone())  # (no update: every run starts from the same state)
+        torch.manual_seed(5)
+        loss = float(tr.train_step(batch))
+        tr.opt.step = step
+        torch.cuda.synchronize()
+        grads.setdefault(side, []).append((loss, got[0]))
+    l0, g0 = grads[False][0]
+    scale = float(g0.abs().max())
+    fl = model._store
+    lo, hi = fl.group_ranges[1][0], fl.grad_numel  # (the flow field opens the second learning-rate group)
+    assert scale > 0 and float(g0[lo:hi].abs().max()) > 0
+    for side in (False, True):
+        for loss, g in grads[side]:
+            assert abs(loss - l0) <= 1e-5 * abs(l0), (side, loss, l0)
+            # float atomics order the network gradients; the tables' sums are integers (bit-equal up to the float atomics of dense levels)
+            assert float((g - g0).abs().max()) <= 1e-4 * scale, (side, float((g - g0).abs().max()), scale)
+            assert bool(torch.isfinite(g).all())
+
+
 def test_fused_flow_loss_equals_torch_path():
     """trainer.flow_loss(fused=True) (_SceneFlowLossFn: csrc/glue.hip around the flow field's kernels, gradients straight into the
     arena) == the torch restatement of runner.py:222-253 that test_flow_loss_vs_oracle pins against the oracle: loss value and
