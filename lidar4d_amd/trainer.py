@@ -753,7 +753,7 @@ class Trainer:
             if overlap_allreduce:  # (False: one all-reduce of the whole arena behind the backward pass)
                 model._grads_ready_hook = self.reducer.early
 
-    def compute_loss(self, data, out, flow_term=None):
+    def compute_loss(self, data, out, flow_term=None, t_ground=None):
         """The reference's training loss (runner.py:179-276,277-367) for one batch and its render outputs.
         flow_term: the scene-flow term if the caller has evaluated it already (train_step on a side stream)."""
         if self.fused_losses and out["depth_lidar"].is_cuda:
@@ -765,7 +765,7 @@ class Trainer:
         if self.flow and flow_term is not None:
             loss = loss + flow_term
         elif self.flow:
-            loss = loss + self._flow_term(data)
+            loss = loss + self._flow_term(data, t_ground)
         patch = getattr(self.dataset, "patch_size_lidar", 1)
         if patch != 1:  # rays were drawn as pixel patches (runner.py:277-367); a sum over this rank's patches
             gt = data["images_lidar"]
@@ -776,10 +776,10 @@ class Trainer:
             loss = loss + urf_loss(out, gt[:, :, 2] * gt[:, :, 0], self.opt.step_count, self.iters) / self.world
         return loss
 
-    def _flow_term(self, data):
+    def _flow_term(self, data, t_ground=None):
         known = frame_index(data["time_host"], self.dataset.num_frames) if "time_host" in data else None
         return flow_loss(self.model, self.pc_list, self.pc_ground_list, data["time"], self.dataset.num_frames, frame_idx=known,
-                         fused=self.fused_flow_loss)
+                         fused=self.fused_flow_loss, t_ground=t_ground)
 
     def train_step(self, data=None):
         data = data if data is not None else self.dataset.batch()
@@ -857,6 +857,9 @@ class Trainer:
         self.opt.zero_grad()
         st = self.model._store
         side, flow_term = None, None
+        # the ground points' random time of the scene-flow term (runner.py:247) is drawn here, in front of the render's sample jitter,
+        # whichever stream the term then runs on: one random stream for both forms of the step
+        t_ground = torch.rand(1, device=st.flat.device) if self.flow else None
         try:
             if (self.flow and self.flow_loss_stream and self.fused_flow_loss and st.flat.is_cuda
                     and not torch.cuda.is_current_stream_capturing()):
@@ -868,13 +871,13 @@ class Trainer:
                 side.wait_stream(main)  # (the gradient fill above, last step's Adam: parameters and fp16 copies are current)
                 self.model._flow_loss_pending = []
                 with torch.cuda.stream(side):
-                    flow_term = self._flow_term(data)
+                    flow_term = self._flow_term(data, t_ground)
             out = self.model.render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], staged=False, perturb=True,
                                     num_steps=self.num_steps, time_host=data.get("time_host"))
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
                 flow_term.record_stream(torch.cuda.current_stream())
-            loss = self.compute_loss(data, out, flow_term=flow_term)
+            loss = self.compute_loss(data, out, flow_term=flow_term, t_ground=t_ground)
             (self.scaler.scale(loss) if self.scaler is not None else loss).backward()  # runner.py:506
             if side is not None:  # the render path's flow-field gradients are in the arena: add the scene-flow term's
                 side.wait_stream(torch.cuda.current_stream())
