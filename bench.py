@@ -697,6 +697,8 @@ def _run(args):
         # is timed alone on the chip, which is what its roofline fraction refers to
         mask_was = ops.streams_mask()
         _lib.lib().l4d_streams_config(0)
+        fls_was = getattr(trainer, "flow_loss_stream", False)
+        trainer.flow_loss_stream = False  # (the scene-flow term back on the launch stream: its small kernels are timed alone, too)
         prof_step = step if inference else trainer.train_step
         if rank == 0:
             _lib.profile_start()
@@ -704,6 +706,7 @@ def _run(args):
             prof_step()
         barrier()
         _lib.lib().l4d_streams_config(mask_was)
+        trainer.flow_loss_stream = fls_was
     if rank == 0 and args.profile_steps > 0:
         kernels = {}
         for name, ms in _lib.profile_stop():
@@ -946,6 +949,7 @@ def _run(args):
                        "loss_scale_after_timed_region": scale_after, "skipped_steps_in_timed_region": skipped,
                        "skipped_steps_in_warmup": skipped_warmup, "scaler_settling_steps_before_warmup": settle_steps, "step_mode": step_mode,
                        "side_streams_mask": ops.streams_mask(),
+                       "scene_flow_term_on_its_own_stream": bool(getattr(trainer, "flow_loss_stream", False)) and not inference and use_flow and step_mode.startswith("eager"),
                        "rccl_ranks_seen": ranks_seen, "distinct_gpus_seen": gpus_seen, "allreduce": allreduce},
             "roofline": roofline,
             "roofline_kernels": roofline_kernels,
