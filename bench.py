@@ -355,6 +355,7 @@ def parse_args():
     ap.add_argument("--no-flow-stream", dest="flow_stream", action="store_false", help="... on the render path's stream")
     ap.add_argument("--force-dist", action="store_true", help="under torchrun with ONE rank: take the multi-rank code path anyway (RCCL init, barrier, two-phase gradient all-reduce) -- exercises the data-parallel path on a single-GPU box")
     ap.add_argument("--grad-transport", default="fp32", choices=("fp32", "bf16"), help="wire format of the hash-table / plane gradient ranges in the all-reduce (trainer.GradReducer)")
+    ap.add_argument("--streams", type=int, default=None, help="l4d_streams_config mask (bit 0: encode in parts, 1: field adjoint forked, 2: static-grid pre-pass next to the LDS kernel); default: the library's")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce of the whole gradient arena behind the backward pass instead of two overlapped phases")
     return ap.parse_args()
 
@@ -556,6 +557,8 @@ def _run(args):
     from lidar4d_amd.trainer import Trainer
 
     model_kw, n_rays, desc = WORKLOADS[args.workload]
+    if args.streams is not None:
+        _lib.lib().l4d_streams_config(int(args.streams))
     torch.manual_seed(0)  # identical initial replicas on every rank
     model = LiDAR4D(near_lidar=1.0 * KITTI360_SCALE, far_lidar=81.0 * KITTI360_SCALE, num_frames=51, **model_kw).to(dev)
     inference = args.workload in INFERENCE

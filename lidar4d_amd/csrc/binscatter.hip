@@ -51,6 +51,9 @@
 
 #define BS_THREADS 512
 #define BS_MAX_BINS 256
+#ifndef BS_SCAN_MAX_HEADS
+#define BS_SCAN_MAX_HEADS 32  // merged-run form of a binned level up to this many runs per wavefront (<= 32: at most NC / 2 records per lane)
+#endif
 #define BS_MIN_WAVES 4  // pass 1: wavefronts per SIMD the register allocation must leave room for (128 registers)
 
 // key + packed halfs.  Records are stored whole (8 or 12 bytes).  ``split`` stores 12-byte records as a dword key stream + an 8-byte
@@ -71,6 +74,28 @@ __device__ __forceinline__ void pack_payload(const float v[NV], uint32_t out[(NV
     out[q] = __builtin_bit_cast(uint32_t, h);
   }
 }
+
+// -DBS_PHASE_CLOCK (tools/build_abl.sh, tools/bs_phase.py): cycles (s_memtime) that the wavefronts of pass 1 spend in every phase of a
+// level, summed over the launch -- [0: wavefront 0 (the scanning one), 1: the others][phase]; not compiled into the shipped library
+#ifdef BS_PHASE_CLOCK
+__device__ unsigned long long bs_phase_clk[2][18];
+extern "C" int l4d_debug_bs_phase_clk(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(bs_phase_clk), sizeof(bs_phase_clk)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[2][18] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bs_phase_clk), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+// (sampled: wavefronts 1 -- one of the four that reserve -- 4 and 7 of every 16th workgroup -- s_memtime from every wavefront made the kernel ten times slower)
+#define BS_CLK_DECL const bool clk_on = (blockIdx.x & 15) == 0 && (threadIdx.x >> 6) % 3 == 1; uint32_t clk_acc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t clk_last = clk_on ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
+#define BS_CLK(i) if (clk_on) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); clk_acc[i] += now_ - clk_last; clk_last = now_; }
+#define BS_CNT(i) if (clk_on) clk_acc[i] += 1u;
+#else
+#define BS_CLK_DECL
+#define BS_CLK(i)
+#define BS_CNT(i)
+#endif
 
 template <int D, int NV>
 __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride,
@@ -145,7 +170,9 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   half_t gnext[NV];
   for (int i = threadIdx.x; i < BS_MAX_BINS; i += BS_THREADS) hist[i] = 0;
   if (threadIdx.x < L4D_MAX_LEVELS) lmax_s[threadIdx.x] = 0u;
+  BS_CLK_DECL
   __syncthreads();
+  BS_CLK(0)  // head: coordinates, first gradient piece, first barrier
   // The level loop exists twice (a generic lambda over GREG = "gradient dwords in the register window"): the loads of the other
   // shapes' path, in ONE loop with the common path, made the compiler wait for every outstanding memory operation at the join --
   // the gradient dwords just requested and the previous level's copy-out stores included -- on the common path as well.
@@ -289,28 +316,30 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // (No barrier here: the histogram was left zeroed by the scan of the previous binned level, and this level's staging writes and
   // bin offsets come behind the barriers below, which every wavefront reaches only behind its share of the previous level's copy-out.)
 
+  BS_CLK(11)  // (behind the second barrier:) reservation issued, records staged
   Cell<D> c = locate<D>(xin, desc.scale[lvl]);
   uint32_t keys[NC];
   float vals[NC][NV];
   bool emit[NC];
   uint32_t pos[NC];
   // Consecutive lanes are consecutive samples of a ray: on coarse levels several of them sit in one cell and hit the same
-  // 2^D entries.  Binned levels merge such runs inside 16-lane rows with the DPP scan (one record per run and corner);
-  // the dense fallback keeps the wave-wide shuffle reduction (global atomics are the expensive resource there).
+  // 2^D entries.  Such runs are merged over the whole wavefront with the DPP scan of wave_dev.h -- one record (binned levels) or
+  // one atomic (dense levels) per run, corner and value.  (Round 6: the dense levels used the shuffle reduction wave_run_reduce,
+  // 6 ds_bpermute round trips per value and corner -- half of the 14 k cycles a workgroup spent on the flow grid's dense level,
+  // tools/bs_phase.py; merging inside 16-lane rows only tripled their atomics, which all rays aim at the same few cells around
+  // the sensor: pass 1 2x slower.)
   int n_heads = 64;
-  RowRuns runs;
+  WaveRuns runs;
   bool use_scan = false;
-  if (binned) {
-    bool same = true;  // same cell as the previous lane (the first lane of a row never is: old = ~cell, bound_ctrl off)
+  {
+    bool same = true;  // same cell as the previous lane (lane 0 never is: old = ~cell, bound_ctrl off)
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp((int)~c.cell[d], (int)c.cell[d], 0x111, 0xf, 0xf, false);
+      const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp((int)~c.cell[d], (int)c.cell[d], 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
       same &= pv == c.cell[d];
     }
-    // key = running id that changes exactly where the cell changes (lanes without a gradient carry zeros: harmless)
-    const unsigned long long brk = __ballot(!same);
-    runs = row_runs((uint32_t)__popcll(brk & (~0ull >> (63 - lane))), &n_heads);
-    use_scan = n_heads <= 32;  // wave-uniform: merged runs emit single records, at most NC per run = NC / 2 per lane
+    runs = wave_runs(__ballot(!same), &n_heads);  // (lanes without a gradient carry zeros: harmless in any run)
+    use_scan = binned && n_heads <= BS_SCAN_MAX_HEADS;  // wave-uniform: merged runs emit single records, NC per run
   }
   const bool pairs = binned && !use_scan;  // wave-uniform
   uint32_t fxq = 0u;  // keys[] carry the record's tz code in bits 24..27 from here on (entries per level <= 2^24: checked by the host side)
@@ -335,7 +364,13 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       keys[q] = k0 | ((paired[q] ? (uint32_t)(__popc(m) - 1) : BS_CODE_SINGLE) << 24);
       keys[q + NC / 2] = k1 | (BS_CODE_SINGLE << 24);
     }
+    BS_CLK(1)  // pair form: cell, hashes, weights
     take_gradient();
+#ifdef BS_PHASE_CLOCK
+#pragma unroll
+    for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(gv[j]));  // (the values exist before the clock is read)
+#endif
+    BS_CLK(2)  // the level's gradient values (the wait for outstanding memory operations)
     wave_any = __any(any);
 #pragma unroll
     for (int q = 0; q < NC / 2; ++q) {
@@ -363,7 +398,17 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       wk[k] = corner<D>(c, k, gg);
       keys[k] = binned ? grid_index_fast<D>(gg, size - 1u) : grid_index<D>(gg, desc.res[lvl], size, hashed);
     }
+#ifdef BS_PHASE_CLOCK
+#pragma unroll
+    for (int k = 0; k < NC; ++k) asm volatile("" : "+v"(keys[k]), "+v"(wk[k]));
+#endif
+    BS_CLK(12)  // merged-run / dense form: cell, run flags, hashes, weights
     take_gradient();
+#ifdef BS_PHASE_CLOCK
+#pragma unroll
+    for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(gv[j]));
+#endif
+    BS_CLK(13)  // ... gradient values
     wave_any = __any(any);
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
@@ -372,11 +417,15 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     if (binned) {
       emit[k] = any;
       if (use_scan) {
-        row_scan<NV>(runs, vals[k]);
+        wave_scan<NV>(runs, vals[k]);
         emit[k] = runs.tail;
       }
     } else {
-      emit[k] = wave_any ? wave_run_reduce<NV>(keys[k], any, vals[k]) : false;
+      emit[k] = false;
+      if (wave_any) {  // (wave-uniform)
+        wave_scan<NV>(runs, vals[k]);
+        emit[k] = runs.tail;
+      }
     }
     if (emit[k]) {
       bool nz = false;
@@ -394,16 +443,29 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       if (emit[k]) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
+#ifndef BS_DENSE_NOATOMIC
           if (vals[k][j] != 0.0f) atomicAdd(o + (size_t)keys[k] * NV + j, vals[k][j] * out_scale);
+#else
+          if (vals[k][j] == 12345.0f) atomicAdd(o + (size_t)keys[k] * NV + j, vals[k][j] * out_scale);
+#endif
       }
+    BS_CLK(8)  // a dense level: scans, atomics
+    BS_CNT(16)
     continue;  // block-uniform: next level
   }
+  if (!pairs) { BS_CLK(10) BS_CNT(15) } else { BS_CNT(14) }  // merged-run form of a binned level: values, scans
   amax = wave_max(amax);
   if (lane == 0 && amax > 0.0f) atomicMax(&lmax_s[lvl], __float_as_uint(amax));  // (ds_max_u32, nothing returned: no wait)
 
   // In pair mode the upper half of the slots only holds the second halves of pairs that straddle two bins (one pair in 2^shift):
   // a wavefront without one skips their ranking and staging code altogether (wave-uniform branch instead of exec-masked no-ops).
   bool upper = true;
+  if (pairs) {
+    bool up = false;
+#pragma unroll
+    for (int k = NC / 2; k < NC; ++k) up |= emit[k];
+    upper = __any(up);
+  }
   // rank inside the workgroup
 #pragma unroll
   for (int k = 0; k < NC / 2; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
@@ -412,8 +474,11 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     for (int k = NC / 2; k < NC; ++k) pos[k] = emit[k] ? atomicAdd(&hist[(keys[k] & 0xFFFFFFu) >> shift], 1u) : 0u;
   }
   // (the reservations of the level that is still staged have had this level's head and ranking phase to return)
+  BS_CLK(3)  // records, ranks (returned)
   if (threadIdx.x < BS_MAX_BINS && copy_lvl >= 0) finish_reserve();
+  BS_CLK(4)  // records, ranks, the previous level's reservation consumed (the clock is read where the barrier waits for the LDS anyway)
   __syncthreads();
+  BS_CLK(5)  // first barrier
   const int par = nb & 1;
   if (threadIdx.x < 64) {  // exclusive scan of the bin totals by one wave: BPL consecutive bins per lane
     uint32_t c[BPL], sum = 0;
@@ -450,7 +515,9 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   } else if (copy_lvl >= 0) {
     copy_out((int)threadIdx.x - 64, BS_THREADS - 64);  // the previous binned level's records, under the scan
   }
+  BS_CLK(6)  // scan (wavefront 0) / copy-out (the others)
   __syncthreads();
+  BS_CLK(7)  // second barrier
   // this level's reservations: ONE returning atomic per bin on the list cursor [level][list][bin], issued by the bin's thread (the
   // first four wavefronts; 64 lanes = 64 consecutive counters = two lines).  Unconditional (a bin without records adds 0): a
   // conditional one is waited for where it is issued.  Consumed by finish_reserve() in front of the NEXT level's first barrier.
@@ -459,10 +526,18 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     asm volatile("" : "+v"(b));  // (as above: scalar base + 32-bit lane offset, formed here)
     resv = atomicAdd(cur + ((uint32_t)lvl * BS_LISTS + (uint32_t)list_k) * BS_MAX_BINS + b, boff[b + 1] - boff[b]);
   }
+  // The bins' offsets for ALL slots are requested first, unconditionally (a slot without a record reads its key's bin all the same):
+  // read inside the slot's own branch, each offset was an LDS round trip of its own -- eight in a row per level, a fifth of the
+  // kernel's time (tools/bs_phase.py) -- and every wait for one also waited for the previous slot's stores.
+  uint32_t sbase[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) sbase[k] = (k < NC / 2 || upper) ? boff[(keys[k] & 0xFFFFFFu) >> shift] : 0u;  // (wave-uniform condition)
+#pragma unroll
+  for (int k = 0; k < NC; ++k) asm volatile("" : "+v"(sbase[k]));  // (all of them in flight before the first is used)
   auto stage_slot = [&](int k) {
     if (emit[k]) {
       const uint32_t b = (keys[k] & 0xFFFFFFu) >> shift;
-      const uint32_t r = boff[b] + pos[k];
+      const uint32_t r = sbase[k] + pos[k];
       const uint32_t code = keys[k] >> 24;
       rbin[r] = (uint8_t)b;
       stage[r * NW] = (keys[k] & ((1u << shift) - 1u)) | (code << BS_KEY_BITS) | (code == BS_CODE_SINGLE ? 0u : fxq << (BS_KEY_BITS + 4));
@@ -490,6 +565,13 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     copy_out((int)threadIdx.x, BS_THREADS);
   }
   __syncthreads();
+  BS_CLK(9)  // tail: the last level's copy-out
+#ifdef BS_PHASE_CLOCK
+  if (lane == 0 && clk_on) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) atomicAdd(&bs_phase_clk[threadIdx.x < 256 ? 0 : 1][i], (unsigned long long)clk_acc[i]);
+  }
+#endif
   if ((int)threadIdx.x < n_lv) {
     const uint32_t m = lmax_s[threadIdx.x];
     if (m != 0u) atomic_max_nonneg(lvl_max + threadIdx.x, __uint_as_float(m));

@@ -93,6 +93,51 @@ __device__ __forceinline__ void row_scan(const RowRuns& r, float v[K]) {
 #undef L4D_FMAC_DPP
 }
 
+// Run merge over the WHOLE wavefront: the row scan above, then the row totals carried into runs that reach back over the start of
+// their row -- three more v_fmac_f32_dpp per value (row_bcast:15 hands lane 15 of a row to every lane of the next one; row_mask
+// picks the row that takes it, so rows 1, 2, 3 follow each other and a run that covers several rows collects all of them).  Seven
+// DPP instructions per value and no LDS, where wave_run_reduce() needs six ds_bpermute round trips per value; the run's total ends
+// up in its LAST lane.  heads: ballot of "this lane starts a run" over the wavefront (bit 0 is always set).
+struct WaveRuns {
+  RowRuns row;  // the row-local part (runs cut at multiples of 16 lanes)
+  float fc;     // 1.0 if the lane's run started in an earlier row
+  bool tail;    // this lane is the last of its run
+};
+__device__ __forceinline__ WaveRuns wave_runs(unsigned long long heads, int* n_heads = nullptr) {
+  const int lane = __lane_id();
+  heads |= 1ull;
+  if (n_heads) *n_heads = __popcll(heads);
+  const unsigned long long H = heads | 0x0001000100010001ull;          // row-local runs
+  const unsigned long long le = H & (~0ull >> (63 - lane));
+  const int off = lane - (63 - __clzll((long long)le));
+  WaveRuns r;
+  r.row.f1 = off >= 1 ? 1.0f : 0.0f;
+  r.row.f2 = off >= 2 ? 1.0f : 0.0f;
+  r.row.f4 = off >= 4 ? 1.0f : 0.0f;
+  r.row.f8 = off >= 8 ? 1.0f : 0.0f;
+  r.tail = lane == 63 || ((heads >> (lane + 1)) & 1ull) != 0ull;
+  r.row.tail = r.tail;
+  // no head between the start of this lane's row and the lane itself: the run comes from the row before
+  const unsigned long long in_row = (heads >> (lane & 48)) & (0xFFFFull >> (15 - (lane & 15)));
+  r.fc = in_row == 0ull ? 1.0f : 0.0f;
+  return r;
+}
+template <int K>
+__device__ __forceinline__ void wave_scan(const WaveRuns& r, float v[K]) {
+  row_scan<K, 16>(r.row, v);
+#define L4D_FMAC_BCAST(x, f, rmask) asm volatile("v_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:" #rmask " bank_mask:0xf" : "+v"(x) : "v"(f))
+  if (K < 3) asm volatile("s_nop 1");
+#pragma unroll
+  for (int k = 0; k < K; ++k) L4D_FMAC_BCAST(v[k], r.fc, 0x2);
+  if (K < 3) asm volatile("s_nop 1");
+#pragma unroll
+  for (int k = 0; k < K; ++k) L4D_FMAC_BCAST(v[k], r.fc, 0x4);
+  if (K < 3) asm volatile("s_nop 1");
+#pragma unroll
+  for (int k = 0; k < K; ++k) L4D_FMAC_BCAST(v[k], r.fc, 0x8);
+#undef L4D_FMAC_BCAST
+}
+
 // running maximum of |v| that turns into +inf as soon as a non-finite value is seen (fmaxf alone drops nan): the
 // fixed-point statistics double as the "gradient overflowed" signal of the adjoint chain (common.h, f2h_grad)
 __device__ __forceinline__ float amax_nf(float m, float v) { return nonfinite(v) ? __builtin_inff() : fmaxf(m, fabsf(v)); }

@@ -3,6 +3,7 @@
 #   bash tools/gpu_ab.sh <tag> [tests=none|quick|full] [VARIANT ...]
 # VARIANT = name              -> bench with L4D_LIB=tools/abl/lib_<name>.so (tools/build_abl.sh)
 #         = name:ENV=V,ENV=V  -> bench with the in-tree library (or lib_<name>.so if it exists) under those env settings
+#           (LIB=<other> picks tools/abl/lib_<other>.so; ARGS=--flag+value adds bench flags, '+' for blanks)
 # Every bench is the short form (8 timed steps, per-kernel pass, no CPU baseline / variants); the per-kernel table goes to
 # gpurun_out/<tag>/<name>.txt, the compact line to <name>.json, the side file to <name>_detail.json.
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -21,7 +22,9 @@ fi
 B="python bench.py --steps 8 --warmup 3 --no-cpu-baseline --variant-steps 0"
 run() {  # name, env assignments...
   name=$1; shift
-  env L4D_BENCH_DETAIL=$PWD/$O/${name}_detail.json "$@" $B > $O/$name.json 2> $O/$name.err; echo "bench $name rc=$? ($*)"
+  extra=""
+  for a in "$@"; do [[ "$a" == ARGS=* ]] && extra=$(echo "${a#ARGS=}" | tr '+' ' '); done
+  env L4D_BENCH_DETAIL=$PWD/$O/${name}_detail.json "$@" $B $extra > $O/$name.json 2> $O/$name.err; echo "bench $name rc=$? ($*)"
   python - "$O/$name.json" "$O/${name}_detail.json" > $O/$name.txt <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); det = json.load(open(sys.argv[2]))
@@ -35,6 +38,7 @@ for V in "$@"; do
   name=${V%%:*}; envs=""
   [[ "$V" == *:* ]] && envs=$(echo "${V#*:}" | tr ',' ' ')
   lib=""; [ -f tools/abl/lib_$name.so ] && lib="L4D_LIB=$PWD/tools/abl/lib_$name.so"
+  for a in $envs; do [[ "$a" == LIB=* ]] && lib="L4D_LIB=$PWD/tools/abl/lib_${a#LIB=}.so"; done
   run $name X=1 $lib $envs
 done
 python - $O "$@" <<'PY'
