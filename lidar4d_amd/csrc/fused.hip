@@ -348,10 +348,7 @@ __global__ void __launch_bounds__(256) warp_coords_kernel(const float* __restric
   for (int k = 0; k < 6; ++k) flowT[(int64_t)k * P + p] = fh[k];
 }
 
-#ifndef DH_WAVES
-#define DH_WAVES 4
-#endif
-__global__ void __launch_bounds__(DH_THREADS, DH_WAVES) dynhash_fwd_lds_kernel(FieldDesc fd, const float* __restrict__ xs,
+__global__ void __launch_bounds__(DH_THREADS) dynhash_fwd_lds_kernel(FieldDesc fd, const float* __restrict__ xs,
                                                                     const half_t* __restrict__ flowT,
                                                                     const float* __restrict__ tinfo, int64_t P, int64_t chunk,
                                                                     half_t* __restrict__ hdT) {
