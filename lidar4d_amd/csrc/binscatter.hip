@@ -146,10 +146,10 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
   // halfs): read level by level -- 2 to 8 bytes out of a 256-byte-strided row per level phase -- every level pulled its own
   // 64-byte sector across the fabric (PMC: 5.4 GB fetched for 0.8 GB of values).  The level loop is not unrolled, so the
   // level's dwords are picked by a uniform index into a register VECTOR (an indexed array would live in scratch).
-  // Held 4 dwords (16 bytes of the row) at a time: the next 16 bytes are fetched while the last level of the current ones is
-  // ranked.  (The kernel sits at the 128-register limit of its four wavefronts per SIMD: 8 dwords at a time -- rounds 4-5 -- left
-  // no room for the four list reservations that wavefront 0 now carries from one level into the next.)
-  constexpr int GW = 4;  // (8 dwords at a time -- half the line fetches, 3.2 GB less at the fabric -- fits 126 registers but is slower: 2.00 -> 2.13 ms, session s18)
+  // Held 8 dwords (32 bytes of the row) at a time: the next 32 bytes are fetched while the last level of the current ones is
+  // ranked.
+  constexpr int GW = 8;  // (round 6, first layout: 8 dwords left no room for the list reservations at 126 registers, 2.00 -> 2.13 ms, session s18; with the
+                         // wave-wide merge the kernel holds 116: 2.04 -> 2.01 ms and 3 GB less over the fabric, session s28)
   const bool g_in_regs = n_lv * NV <= 32 && (g_stride * 2) % 16 == 0 && (g_col * 2) % 16 == 0;  // block-uniform
   typedef uint32_t GwVec __attribute__((ext_vector_type(GW)));  // a vector, so that a uniform index becomes relative VGPR addressing
   GwVec gw;
