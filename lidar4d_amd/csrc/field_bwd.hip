@@ -210,6 +210,26 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 // plane instead of four taps), and the coordinate adjoint of a warped lookup is sum_c gv_c (row[x1] - row[x0])_c from the
 // same two texels -- 144 instead of 480 texel loads per sample in a kernel that is bound by their latency.
 #define TFRAMES 3
+// -DFB_PHASE_CLOCK (tools/build_abl.sh, tools/phase_probe.py): cycles (s_memtime) the time-plane kernel's wavefronts spend in every part of a
+// sample iteration, sampled (wavefront 0 of every 8th workgroup; every wavefront reading the clock slows a kernel tenfold: binscatter.hip)
+#ifdef FB_PHASE_CLOCK
+__device__ unsigned long long fb_phase_clk[16];
+extern "C" int l4d_debug_fb_phase_clk(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_phase_clk), sizeof(fb_phase_clk)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fb_phase_clk), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#define FB_CLK_DECL const bool clk_on = (blockIdx.x & 7) == 0 && threadIdx.x < 64; uint32_t clk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t clk_last = clk_on ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
+#define FB_CLK(i) if (clk_on) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); clk_acc[i] += now_ - clk_last; clk_last = now_; }
+#define FB_CLK_FLUSH if (clk_on && threadIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&fb_phase_clk[i_], (unsigned long long)clk_acc[i_]); atomicAdd(&fb_phase_clk[15], 1ull); }
+#else
+#define FB_CLK_DECL
+#define FB_CLK(i)
+#define FB_CLK_FLUSH
+#endif
 // lanes a run of equal texels is merged over before the LDS atomics (16 = a whole DPP row: 4 scan steps per value; 8: 3 steps)
 #define PDYN_MERGE 16
 #define PSTAT_MERGE 16
@@ -269,7 +289,9 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
   uint32_t dyn_bad = 0u;   // PREP: sticky "saw inf / nan in a dynamic-hash column"
 
   typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+  FB_CLK_DECL
   for (int64_t it = 0; it < n_iter; ++it) {
+    FB_CLK(0)  // loop tail / head
     const int64_t pr = lo_p + it * blockDim.x + threadIdx.x;
     const bool active = pr < hi_p;
     const int64_t p = active ? pr : hi_p - 1;
@@ -294,6 +316,11 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       __builtin_memcpy(&piece_next, row + min(k + 1, 2 * nS - 1) * C, 16);
       return cur;
     };
+#ifdef FB_PHASE_CLOCK
+    asm volatile("" : "+v"(fl[0]), "+v"(fl[5]));
+    { float cx = c4[0]; asm volatile("" : "+v"(cx)); }
+#endif
+    FB_CLK(1)  // coordinates and flow arrived
     if (PREP) {
       const int lane = __lane_id();
       if (active) {
@@ -336,6 +363,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
         smax = wave_max(smax);
         if (lane == ST_GVS_MAX + s) prep_stat = fmaxf(prep_stat, smax);
       }
+      FB_CLK(2)  // PREP: static planes' product-rule factors (taps, gvs stores)
       // dynamic hash: the current frame's share c0 of the upstream gradient, transposed (neighbour frames are no_grad)
       const int colD = 2 * nS * C + fd.hs.n_levels * 4;
       const int L3 = fd.hd[0].n_levels + fd.hd[1].n_levels + fd.hd[2].n_levels;
@@ -370,6 +398,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
         }
       }
     }
+    FB_CLK(3)  // PREP: dynamic-hash columns transposed
     float gflow[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // d/d(x1), d/d(x2): x1 = x + flow[:3], x2 = x + flow[3:]
     for (int s = 0; s < nS; ++s) {
       float gd[C];
@@ -390,6 +419,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
         float dv[3][C];  // ROWS: row[x1] - row[x0] per channel (d value / d ix)
         (void)dv;
         int cis[3];
+        FB_CLK(4)  // time planes: upstream gradient piece, frame set-up
         if (ROWS) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
@@ -411,6 +441,11 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
         } else {
           group_taps<C>(fd, s, xe, true, taps, v, cis);
         }
+#ifdef FB_PHASE_CLOCK
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(v[j][0]), "+v"(v[j][7]));
+#endif
+        FB_CLK(5)  // time planes: the frame's row texels loaded and interpolated
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const Tap& t = taps[j];
@@ -451,6 +486,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
             for (int k = 0; k < C; ++k) atomicAdd(dst + k, fx_round(vals[k]));
           }
         }
+        FB_CLK(6)  // time planes: product rule, coordinate adjoint, run scans, LDS atomics of a frame's three planes
       }
     }
     if (active) {  // d(flow), in dX's (loss-scaled) domain
@@ -461,7 +497,9 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       dst[0] = reinterpret_cast<uint4*>(out)[0];
       dst[1] = reinterpret_cast<uint4*>(out)[1];
     }
+    FB_CLK(7)  // d(flow) stored
   }
+  FB_CLK_FLUSH
   if (PREP) {
     const int lane = __lane_id();
     const int L3 = fd.hd[0].n_levels + fd.hd[1].n_levels + fd.hd[2].n_levels;
