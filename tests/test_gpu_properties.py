@@ -117,6 +117,51 @@ def test_binned_scatter_overflowing_lists(cloud):
     assert torch.equal(g2[dense_lvl0:], g_binned[dense_lvl0:]), "sorted scatter must be bit-reproducible, overflow list included"
 
 
+def test_binned_scatter_ray_ordered_runs():
+    """Samples in ray order (consecutive lanes = consecutive samples of a ray from a common origin): on the coarse levels runs of 2 - 30
+    samples share a cell and are merged over the whole wavefront before they become records (binned levels) or atomics (the dense
+    level 0) -- csrc/wave_dev.h wave_runs / wave_scan: runs that start and end anywhere, cross the 16-lane rows of the DPP scan and
+    stop at wavefront boundaries.  Against the atomic path's kernel (its own run reduction, by shuffles), level by level."""
+    from lidar4d_amd import ops
+    from lidar4d_amd.gridmeta import GridMeta
+    meta = GridMeta(3, 8, 8, 18, 32, np.exp2(np.log2(8192 / 32) / 7))
+    n_rays, T = 4096, 320  # (T not a multiple of 64: rays start anywhere in a wavefront)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    d = torch.randn(n_rays, 3, device=DEV, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    z = (torch.arange(T, device=DEV, dtype=torch.float32) + torch.rand(n_rays, T, device=DEV, generator=g)) / T  # jittered, monotone
+    pts = 0.5 + 0.45 * d[:, None, :] * z[..., None]  # all rays leave (0.5, 0.5, 0.5): every ray's first samples share the same cells
+    x = torch.cat([pts.reshape(-1, 3), torch.zeros(n_rays * T, 1, device=DEV)], dim=1).contiguous()
+    P = x.shape[0]
+    assert P * 8 >= ops.BINNED_SCATTER_MIN_RECORDS
+    t = torch.tensor([0.37], device=DEV)
+    dout = (torch.randn(P, 16, device=DEV, generator=g) * 0.1).half()
+    dout[torch.rand(P, device=DEV, generator=g) < 0.1] = 0  # samples without a gradient inside the runs
+    g_binned = torch.zeros(meta.n_params, device=DEV)
+    ops.hashgrid_t_bwd(meta, x, (0, 1, 2), 1, t, dout, [g_binned], 1.0)
+    prev = ops.BINNED_SCATTER_MIN_RECORDS
+    ops.BINNED_SCATTER_MIN_RECORDS = 1 << 62
+    try:
+        g_atomic = torch.zeros(meta.n_params, device=DEV)
+        ops.hashgrid_t_bwd(meta, x, (0, 1, 2), 1, t, dout, [g_atomic], 1.0)
+    finally:
+        ops.BINNED_SCATTER_MIN_RECORDS = prev
+    assert bool(torch.isfinite(g_binned).all())
+    for lvl in range(meta.n_levels):
+        lo, hi = meta.offset[lvl] * 8, (meta.offset[lvl] + meta.size[lvl]) * 8
+        a, b = g_atomic[lo:hi], g_binned[lo:hi]
+        scale = float(a.abs().max())
+        assert scale > 0
+        # (both paths add in fp32 or better; the binned one rounds every record's payload to fp16 once)
+        err = float((a - b).abs().max())
+        assert err < 3e-3 * scale, f"level {lvl}: {err / scale:.2e} of the level's largest gradient"
+        assert abs(float(a.double().sum()) - float(b.double().sum())) < 2e-3 * float(a.double().abs().sum())
+    g2 = torch.zeros(meta.n_params, device=DEV)
+    ops.hashgrid_t_bwd(meta, x, (0, 1, 2), 1, t, dout, [g2], 1.0)
+    dense_lvl0 = meta.size[0] * 8
+    assert torch.equal(g2[dense_lvl0:], g_binned[dense_lvl0:]), "sorted scatter must be bit-reproducible"
+
+
 def test_render_invariants_full_size(big):
     model, data = big
     b = data.batch_for(20)
