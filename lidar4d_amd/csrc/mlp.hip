@@ -420,13 +420,16 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
         for (int ks = 0; ks < KS_IN; ++ks)
           if (32 * ks + 8 * g < IN_PAD) t.x[a][ks] = attr_chunk_fix(src, 32 * ks + 8 * g, t.x[a][ks]);
       }
-      if (partial && !okr) {
+      if (partial) {  // (a real, wave-uniform branch -- the empty asm keeps it one: as selects this was 40 v_cndmask in EVERY tile of the attribute backward)
+        asm volatile("" ::: "memory");
+        if (!okr) {
 #pragma unroll
-        for (int ks = 0; ks < KS_IN; ++ks) t.x[a][ks] = make_uint4(0, 0, 0, 0);
+          for (int ks = 0; ks < KS_IN; ++ks) t.x[a][ks] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int l = 0; l < NACT; ++l)
+          for (int l = 0; l < NACT; ++l)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) t.h[l][a][ks] = make_uint4(0, 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) t.h[l][a][ks] = make_uint4(0, 0, 0, 0);
+        }
       }
     }
   };
@@ -576,9 +579,11 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           c[mt] = MFMA(FR(L::WOT_P + mt), dzf[a][0], (f4{0, 0, 0, 0}));
+          if (!RELU_GATE_ASM) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (!(hf[a][mt >> 1][4 * (mt & 1) + r] > (half_t)0.0f)) c[mt][r] = 0.0f;
+            for (int r = 0; r < 4; ++r)
+              if (!(hf[a][mt >> 1][4 * (mt & 1) + r] > (half_t)0.0f)) c[mt][r] = 0.0f;
+          }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -587,16 +592,27 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
             nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
             nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
           }
+          if (RELU_GATE_ASM) nz[a][ks] = relu_gate(nz[a][ks], hf[a][ks]);  // (element 4 (mt & 1) + r of hf[a][mt >> 1] gates c[mt][r])
         }
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         f4 t0 = MFMA(dzf[0][0], FR(L::WOT_N + nt), (f4{0, 0, 0, 0}));
         f4 t1 = MFMA(dzf[1][0], FR(L::WOT_N + nt), (f4{0, 0, 0, 0}));
+        if (RELU_GATE_ASM) {
+          h8 tv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h_grad(t0[r]) : (half_t)0.0f;
-          dzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h_grad(t1[r]) : (half_t)0.0f;
+          for (int r = 0; r < 4; ++r) {
+            tv[r] = f2h_grad(t0[r]);
+            tv[4 + r] = f2h_grad(t1[r]);
+          }
+          dzT[nt] = relu_gate(tv, hT[nt]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h_grad(t0[r]) : (half_t)0.0f;
+            dzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h_grad(t1[r]) : (half_t)0.0f;
+          }
         }
       }
 #pragma unroll
@@ -644,9 +660,11 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
         for (int mt = 0; mt < 4; ++mt) {
           c[mt] = MFMA(FR(fb + mt * 2 + 0), dzf[a][0], (f4{0, 0, 0, 0}));
           c[mt] = MFMA(FR(fb + mt * 2 + 1), dzf[a][1], c[mt]);
+          if (!RELU_GATE_ASM) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (!(hf[a][mt >> 1][4 * (mt & 1) + r] > (half_t)0.0f)) c[mt][r] = 0.0f;
+            for (int r = 0; r < 4; ++r)
+              if (!(hf[a][mt >> 1][4 * (mt & 1) + r] > (half_t)0.0f)) c[mt][r] = 0.0f;
+          }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -655,6 +673,7 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
             nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
             nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
           }
+          if (RELU_GATE_ASM) nz[a][ks] = relu_gate(nz[a][ks], hf[a][ks]);
         }
       }
 #pragma unroll
@@ -663,10 +682,20 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
         t0 = MFMA(dzf[0][1], FR(fb + 8 + nt * 2 + 1), t0);
         f4 t1 = MFMA(dzf[1][0], FR(fb + 8 + nt * 2 + 0), (f4{0, 0, 0, 0}));
         t1 = MFMA(dzf[1][1], FR(fb + 8 + nt * 2 + 1), t1);
+        if (RELU_GATE_ASM) {
+          h8 tv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          nzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h_grad(t0[r]) : (half_t)0.0f;
-          nzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h_grad(t1[r]) : (half_t)0.0f;
+          for (int r = 0; r < 4; ++r) {
+            tv[r] = f2h_grad(t0[r]);
+            tv[4 + r] = f2h_grad(t1[r]);
+          }
+          nzT[nt] = relu_gate(tv, hT[nt]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            nzT[nt][r] = (hT[nt][r] > (half_t)0.0f) ? f2h_grad(t0[r]) : (half_t)0.0f;
+            nzT[nt][4 + r] = (hT[nt][4 + r] > (half_t)0.0f) ? f2h_grad(t1[r]) : (half_t)0.0f;
+          }
         }
       }
 #pragma unroll

@@ -69,7 +69,35 @@ __device__ __forceinline__ h8 relu_pack(const f4& lo, const f4& hi) {
   return v;
 }
 
-// (ReLU masks of the backward as bit-pattern operations on the packed halfs: measured mixed -- attribute backward 2.82 -> 2.71 ms, flow
-// backward 1.26 -> 1.30 -- because the compiler turns them back into compares; removed in round 5.)
+// ReLU' on packed halfs: v's half survives where the same half of h -- a ReLU OUTPUT of relu_pack: never negative, and +0 where the
+// input was -0 (v_pk_max_f16 orders -0 below +0: tools/ubench/pk_max_zero.hip) -- is non-zero.  min(h, 1) on the bit patterns is 0 / 1,
+// and an integer multiply by it keeps or clears the half: TWO instructions per pair of elements, written as asm because the compiler turns
+// any C form back into a compare + select per element (round 5: mixed results for that reason).  Per 32-row tile of the attribute
+// backward: 128 v_cmp + 128 v_cndmask + 64 single conversions -> 64 v_pk_min_u16 + 64 v_pk_mul_lo_u16 + 32 more v_cvt_pk.
+// RELU_GATE_ASM 0: the compare form (A/B).
+#ifndef RELU_GATE_ASM
+#define RELU_GATE_ASM 1
+#endif
+__device__ __forceinline__ h8 relu_gate(const h8& v, const h8& h) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  // (plain dword arrays: with the dwords taken as elements of a 4-vector -- vb[q] -- the compiler multiplied dwords 1 .. 3 by the
+  // RESULT of dword 0, tools/ubench/relu_gate_check.hip)
+  uint32_t vw[4], hw[4];
+  __builtin_memcpy(vw, &v, 16);
+  __builtin_memcpy(hw, &h, 16);
+  const uint32_t one = 0x00010001u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // The minimum is asm (opaque: as C the pair min + multiply is folded back into compare + select); the MULTIPLY is C, so that the
+    // instruction that defines an MFMA operand is one the compiler's hazard recogniser sees.
+    uint32_t m;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(hw[q]), "s"(one));
+    const us2 r = __builtin_bit_cast(us2, vw[q]) * __builtin_bit_cast(us2, m);
+    vw[q] = __builtin_bit_cast(uint32_t, r);
+  }
+  h8 out;
+  __builtin_memcpy(&out, vw, 16);
+  return out;
+}
 __device__ __forceinline__ float clamp_h(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
 
