@@ -587,12 +587,15 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+          if (RELU_GATE_ASM) {
+            nz[a][ks] = relu_gate(c[2 * ks], c[2 * ks + 1], hf[a][ks]);  // (element 4 (mt & 1) + r of hf[a][mt >> 1] gates c[mt][r])
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
-            nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
+            for (int r = 0; r < 4; ++r) {
+              nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
+              nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
+            }
           }
-          if (RELU_GATE_ASM) nz[a][ks] = relu_gate(nz[a][ks], hf[a][ks]);  // (element 4 (mt & 1) + r of hf[a][mt >> 1] gates c[mt][r])
         }
       }
 #pragma unroll
@@ -600,13 +603,7 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
         f4 t0 = MFMA(dzf[0][0], FR(L::WOT_N + nt), (f4{0, 0, 0, 0}));
         f4 t1 = MFMA(dzf[1][0], FR(L::WOT_N + nt), (f4{0, 0, 0, 0}));
         if (RELU_GATE_ASM) {
-          h8 tv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            tv[r] = f2h_grad(t0[r]);
-            tv[4 + r] = f2h_grad(t1[r]);
-          }
-          dzT[nt] = relu_gate(tv, hT[nt]);
+          dzT[nt] = relu_gate(t0, t1, hT[nt]);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -668,12 +665,15 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+          if (RELU_GATE_ASM) {
+            nz[a][ks] = relu_gate(c[2 * ks], c[2 * ks + 1], hf[a][ks]);
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
-            nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
+            for (int r = 0; r < 4; ++r) {
+              nz[a][ks][r] = f2h_grad(c[2 * ks][r]);
+              nz[a][ks][4 + r] = f2h_grad(c[2 * ks + 1][r]);
+            }
           }
-          if (RELU_GATE_ASM) nz[a][ks] = relu_gate(nz[a][ks], hf[a][ks]);
         }
       }
 #pragma unroll
@@ -683,13 +683,7 @@ __global__ void __launch_bounds__(256, (IN_TILES == 1 && NH <= 2 ? MLP_BWD_NARRO
         f4 t1 = MFMA(dzf[1][0], FR(fb + 8 + nt * 2 + 0), (f4{0, 0, 0, 0}));
         t1 = MFMA(dzf[1][1], FR(fb + 8 + nt * 2 + 1), t1);
         if (RELU_GATE_ASM) {
-          h8 tv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            tv[r] = f2h_grad(t0[r]);
-            tv[4 + r] = f2h_grad(t1[r]);
-          }
-          nzT[nt] = relu_gate(tv, hT[nt]);
+          nzT[nt] = relu_gate(t0, t1, hT[nt]);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

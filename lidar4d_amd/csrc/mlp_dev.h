@@ -78,22 +78,26 @@ __device__ __forceinline__ h8 relu_pack(const f4& lo, const f4& hi) {
 #ifndef RELU_GATE_ASM
 #define RELU_GATE_ASM 1
 #endif
-__device__ __forceinline__ h8 relu_gate(const h8& v, const h8& h) {
+__device__ __forceinline__ h8 relu_gate(const f4& lo, const f4& hi, const h8& h) {  // halfs of (lo | hi), gated by h
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  // (plain dword arrays: with the dwords taken as elements of a 4-vector -- vb[q] -- the compiler multiplied dwords 1 .. 3 by the
-  // RESULT of dword 0, tools/ubench/relu_gate_check.hip)
-  uint32_t vw[4], hw[4];
-  __builtin_memcpy(vw, &v, 16);
+  typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+  typedef float ff2 __attribute__((ext_vector_type(2)));
+  // (plain dwords, each built from its own pair of floats -- one v_cvt_pk_f16_f32: with the eight halfs taken out of an h8 the compiler
+  // converted them one by one and packed them with v_perm_b32; with the dwords as elements of a 4-vector it multiplied dwords 1 .. 3 by
+  // the RESULT of dword 0, tools/ubench/relu_gate_check.hip)
+  uint32_t hw[4], vw[4];
   __builtin_memcpy(hw, &h, 16);
   const uint32_t one = 0x00010001u;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
+    const f4& src = q < 2 ? lo : hi;
+    const ff2 pair = {src[2 * (q & 1)], src[2 * (q & 1) + 1]};
+    const hh2 half2 = __builtin_convertvector(pair, hh2);  // (= f2h_grad of both: round to nearest even, inf kept)
     // The minimum is asm (opaque: as C the pair min + multiply is folded back into compare + select); the MULTIPLY is C, so that the
     // instruction that defines an MFMA operand is one the compiler's hazard recogniser sees.
     uint32_t m;
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(hw[q]), "s"(one));
-    const us2 r = __builtin_bit_cast(us2, vw[q]) * __builtin_bit_cast(us2, m);
-    vw[q] = __builtin_bit_cast(uint32_t, r);
+    vw[q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, half2) * __builtin_bit_cast(us2, m));
   }
   h8 out;
   __builtin_memcpy(&out, vw, 16);

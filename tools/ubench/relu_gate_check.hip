@@ -7,10 +7,12 @@ __global__ void k(const uint4* v, const uint4* h, uint4* out, uint4* ref, int n)
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   h8 vv = __builtin_bit_cast(h8, v[i]), hh = __builtin_bit_cast(h8, h[i]);
-  h8 r = relu_gate(vv, hh);
+  f4 lo, hi;
+  for (int e = 0; e < 4; ++e) { lo[e] = (float)vv[e]; hi[e] = (float)vv[4 + e]; }
+  h8 r = relu_gate(lo, hi, hh);
   out[i] = __builtin_bit_cast(uint4, r);
   h8 q;
-  for (int e = 0; e < 8; ++e) q[e] = hh[e] > (_Float16)0.0f ? vv[e] : (_Float16)0.0f;
+  for (int e = 0; e < 8; ++e) q[e] = hh[e] > (_Float16)0.0f ? (_Float16)(float)vv[e] : (_Float16)0.0f;
   ref[i] = __builtin_bit_cast(uint4, q);
 }
 int main() {
@@ -21,7 +23,12 @@ int main() {
   srand(1);
   for (int i = 0; i < n; ++i) {
     unsigned w[8];
-    for (int j = 0; j < 4; ++j) w[j] = ((unsigned)rand() << 16) ^ (unsigned)rand();
+    for (int j = 0; j < 4; ++j) {  // finite halfs of either sign (an infinity now and then)
+      unsigned a = rand() & 0xFFFF, b = rand() & 0xFFFF;
+      if ((a & 0x7C00) == 0x7C00) a &= 0xFC00;
+      if ((b & 0x7C00) == 0x7C00) b &= 0xFC00;
+      w[j] = a | (b << 16);
+    }
     for (int j = 0; j < 4; ++j) {  // activations: non-negative halfs, a third of them zero, some denormal
       unsigned a = rand() % 3 == 0 ? 0u : (rand() % 7 == 0 ? (unsigned)(rand() & 0x3FF) : (unsigned)(rand() & 0x7BFF));
       unsigned b = rand() % 3 == 0 ? 0u : (unsigned)(rand() & 0x7BFF);
