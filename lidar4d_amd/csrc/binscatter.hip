@@ -419,6 +419,10 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
       if (use_scan) {
         wave_scan<NV>(runs, vals[k]);
         emit[k] = runs.tail;
+        // a merged run's total (up to 64 contributions) is what the record carries: the level's maximum -- pass 2's fixed-point bound --
+        // has to cover it, and a total beyond the fp16 range must not become a finite record (checked once, below)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) amax = fmaxf(amax, fabsf(vals[k][j]));
       }
     } else {
       emit[k] = false;
@@ -454,6 +458,9 @@ __global__ void __launch_bounds__(BS_THREADS, BS_MIN_WAVES) bin_pass1_kernel(Gri
     continue;  // block-uniform: next level
   }
   if (!pairs) { BS_CLK(10) BS_CNT(15) } else { BS_CNT(14) }  // merged-run form of a binned level: values, scans
+  // (65520 = where round-to-nearest-even turns into the fp16 infinity; an upstream inf / nan is in amax already -- amax_nf.  A partial
+  // sum of a run may trip this with a total that fits: a skipped step and a halved loss scale, what an overflow costs anyway)
+  if (use_scan && amax >= 65520.0f) amax = __builtin_inff();
   amax = wave_max(amax);
   if (lane == 0 && amax > 0.0f) atomicMax(&lmax_s[lvl], __float_as_uint(amax));  // (ds_max_u32, nothing returned: no wait)
 
@@ -626,8 +633,10 @@ __global__ void __launch_bounds__(1024) bin_reduce_kernel(GridDesc desc, int shi
   // Fixed point: every contribution is |v| <= gmax, scaled to 30 bits and converted with ONE v_cvt_i32_f32 (a float -> int64
   // conversion is a dozen instructions on this ISA, eight of them per record), then sign-extended into the 64-bit accumulator --
   // 2^33 contributions per entry before it could overflow, quantisation 2^-26 of the level's largest gradient (the payload itself
-  // carries 11 bits).  (a merged run of a coarse level sums up to 16 lanes of one DPP row: 16 gmax bounds every record)
-  const float fxs = fx_scale(gmax * 16.5f, 30);
+  // carries 11 bits).  gmax = the level's largest |record value| as pass 1 saw it: the upstream gradients, and the totals of merged runs
+  // (up to 64 lanes of a wavefront; round 6's first wave-wide merge kept the 16-lane bound of the row scans here and saturated
+  // the conversion: tests/test_gpu_properties.py one_cell_const); + 1 % for the payload's fp16 rounding.
+  const float fxs = fx_scale(gmax * 1.01f, 30);
   // one record = NW words, kept as ONE register tuple from its load to its use (separate scalars made the register allocator copy
   // the words out of the load's destination right behind the load, i.e. wait for it there)
   typedef uint32_t RecVec __attribute__((ext_vector_type(NW)));

@@ -182,11 +182,20 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
   const half_t* wstage = stage + wave * 64 * ENC_PITCH;
   auto copy_out = [&](int c0, int ncols) {  // this wave's 64 staged rows -> X[:, c0 : c0 + ncols], 16 B per lane, coalesced
     const int chunks = ncols / 8;
+    // (row, chunk) of a lane's piece advanced by 64 pieces per iteration instead of divided out anew: the run-time division by
+    // `chunks` was 20 instructions in each of the 16 iterations of every 64-sample group -- 6 % of the kernel's VALU instructions
+    int r = lane / chunks, c = lane - r * chunks;
+    const int dr = 64 / chunks, dc = 64 - dr * chunks;  // (wave-uniform)
     for (int idx = lane; idx < 64 * chunks; idx += 64) {
-      const int r = idx / chunks, c = idx - r * chunks;
       const int64_t grow = wave_p0 + r;
       if (grow < P)
         __builtin_nontemporal_store(*reinterpret_cast<const u32x4_nt*>(wstage + r * ENC_PITCH + c * 8), reinterpret_cast<u32x4_nt*>(X + grow * in_pad + c0 + c * 8));
+      r += dr;
+      c += dc;
+      if (c >= chunks) {
+        c -= chunks;
+        ++r;
+      }
     }
   };
   if (PART != 2 && !SIGMA) {

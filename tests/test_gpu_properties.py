@@ -72,20 +72,21 @@ def test_binned_scatter_equals_atomic_scatter():
     assert torch.equal(g2[dense_lvl0:], g_binned[dense_lvl0:]), "sorted scatter must be bit-reproducible"
 
 
-@pytest.mark.parametrize("cloud", ["one_cell", "one_row", "mixed"])
+@pytest.mark.parametrize("cloud", ["one_cell", "one_cell_const", "one_row", "mixed"])
 def test_binned_scatter_overflowing_lists(cloud):
     """The sorted scatter's record lists hold 1.25 x their expected share (csrc/binscatter.hip, LISTS AND OVERFLOW); clustered
     points send far more than that into a few bins.  The surplus goes through the level's overflow list: same sums as the atomic
     path, and -- integer accumulation -- bit-identical from run to run although the layout depends on atomic arrival.
-    one_cell: every point identical (merged runs, <= 8 bins per level); one_row: points along one x-row (pair records, the bins of
-    4 (y, z) rows); mixed: half random, half on the row."""
+    one_cell: every point identical (merged runs, <= 8 bins per level); one_cell_const: and every gradient the same value -- a merged run
+    of 64 lanes then carries 64 x the level's largest gradient, the bound pass 2's fixed point has to be scaled for; one_row: points along
+    one x-row (pair records, the bins of 4 (y, z) rows); mixed: half random, half on the row."""
     from lidar4d_amd import ops
     from lidar4d_amd.gridmeta import GridMeta
     meta = GridMeta(3, 8, 8, 18, 32, np.exp2(np.log2(8192 / 32) / 7))
     P = 1 << 19
     g = torch.Generator(device=DEV).manual_seed(7)
     x = torch.rand(P, 4, device=DEV, generator=g)
-    if cloud == "one_cell":
+    if cloud.startswith("one_cell"):
         x[:, :3] = torch.tensor([0.3217, 0.6123, 0.4519], device=DEV)
     else:
         rows = slice(None) if cloud == "one_row" else slice(0, P // 2)
@@ -93,6 +94,8 @@ def test_binned_scatter_overflowing_lists(cloud):
         x[rows, 2] = 0.4519
     t = torch.tensor([0.37], device=DEV)
     dout = (torch.randn(P, 16, device=DEV, generator=g) * 0.1).half()
+    if cloud == "one_cell_const":
+        dout = torch.full((P, 16), 0.1, device=DEV).half()
     g_binned = torch.zeros(meta.n_params, device=DEV)
     ops.hashgrid_t_bwd(meta, x, (0, 1, 2), 1, t, dout, [g_binned], 1.0)
     prev = ops.BINNED_SCATTER_MIN_RECORDS
@@ -108,13 +111,57 @@ def test_binned_scatter_overflowing_lists(cloud):
     assert float((g_binned - g_atomic).abs().max()) < 4e-3 * scale
     # no run of records lost or misplaced: the same entries are touched (up to single contributions below the smallest fp16, which the
     # binned path's payload drops)
+    # The comparison path's sums are fp32 atomics in arrival order.  An element whose contributions cancel to within an ulp comes out as
+    # exactly 0 in one order and as a tiny residue in another -- seen twice in ~150 runs of this test as "4 elements (one scalar of the
+    # scatter, expanded by the time basis) non-zero only in the sorted scatter" while the sorted scatter's own count never moved
+    # (14,404,352 in every run, the atomic path's 14,404,348 in the odd one).  Such an element is a rounding residue: far below
+    # anything a misplaced record would carry.  A misplaced or stale record has the size of a gradient.
+    extra = torch.nonzero((g_binned != 0) & (g_atomic == 0)).reshape(-1)
+    if extra.numel():
+        lv = [max(l for l in range(meta.n_levels) if meta.offset[l] * 8 <= i) for i in extra[:8].tolist()]
+        msg = (f"{extra.numel()} elements non-zero only in the sorted scatter: indices {extra[:8].tolist()} levels {lv} "
+               f"values {g_binned[extra[:8]].tolist()} (largest gradient {scale:.3e})")
+        assert extra.numel() <= 16 and float(g_binned[extra].abs().max()) < 1e-6 * scale, msg
     n_a, n_b = int((g_atomic != 0).sum()), int((g_binned != 0).sum())
-    assert n_b <= n_a and n_a - n_b <= 1e-3 * n_a, (n_a, n_b)
-    assert int(((g_binned != 0) & (g_atomic == 0)).sum()) == 0
+    assert n_b <= n_a + 16 and n_a - n_b <= 1e-3 * n_a, (n_a, n_b)
     g2 = torch.zeros(meta.n_params, device=DEV)
     ops.hashgrid_t_bwd(meta, x, (0, 1, 2), 1, t, dout, [g2], 1.0)
     dense_lvl0 = meta.size[0] * 8
     assert torch.equal(g2[dense_lvl0:], g_binned[dense_lvl0:]), "sorted scatter must be bit-reproducible, overflow list included"
+
+
+def test_binned_scatter_merged_run_beyond_fp16_is_flagged():
+    """A merged run's total travels as an fp16 record.  64 gradients of 3,000 in one cell add up beyond the fp16 range on the corners
+    that carry most of the weight: such a level must come out NON-FINITE (the step is then skipped and the loss scale lowered --
+    common.h f2h_grad), never as a finite, wrong gradient (an infinite payload converted to the largest integer of pass 2's fixed
+    point); a level whose totals all fit must equal the atomic path."""
+    from lidar4d_amd import ops
+    from lidar4d_amd.gridmeta import GridMeta
+    meta = GridMeta(3, 8, 8, 18, 32, np.exp2(np.log2(8192 / 32) / 7))
+    P = 1 << 19
+    x = torch.rand(P, 4, device=DEV)
+    x[:, :3] = torch.tensor([0.3217, 0.6123, 0.4519], device=DEV)
+    t = torch.tensor([0.37], device=DEV)
+    dout = torch.full((P, 16), 3000.0, device=DEV).half()
+    g_binned = torch.zeros(meta.n_params, device=DEV)
+    ops.hashgrid_t_bwd(meta, x, (0, 1, 2), 1, t, dout, [g_binned], 1.0)
+    prev = ops.BINNED_SCATTER_MIN_RECORDS
+    ops.BINNED_SCATTER_MIN_RECORDS = 1 << 62
+    try:
+        g_atomic = torch.zeros(meta.n_params, device=DEV)
+        ops.hashgrid_t_bwd(meta, x, (0, 1, 2), 1, t, dout, [g_atomic], 1.0)
+    finally:
+        ops.BINNED_SCATTER_MIN_RECORDS = prev
+    flagged = 0
+    for lvl in range(meta.n_levels):
+        lo, hi = meta.offset[lvl] * 8, (meta.offset[lvl] + meta.size[lvl]) * 8
+        a, b = g_atomic[lo:hi], g_binned[lo:hi]
+        if not bool(torch.isfinite(b).all()):
+            flagged += 1
+            continue
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) < 4e-3 * scale, f"level {lvl}: finite and wrong ({float((a - b).abs().max()) / scale:.2e} of its largest gradient)"
+    assert flagged >= 1  # (a corner weight above 0.35 exists on some level: 64 x 3000 x 0.35 > 65504)
 
 
 def test_binned_scatter_ray_ordered_runs():
