@@ -93,7 +93,15 @@ __device__ __forceinline__ float pair_eval(const PairCorners& pc, const Cell<2>&
   float r = 0.0f;
   if (tc.sp.i1 != tc.sp.i2) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) r += tc.basis[f] * (tc.sp.w1 * h2f(f2h(a[f])) + tc.sp.w2 * h2f(f2h(b[f])));
+    for (int f = 0; f < 4; ++f) {
+      // both slices' features rounded to fp16 by ONE v_cvt_pk_f16_f32, their blend products taken straight from the packed halfs
+      // (fmix0: (float)half * w, rounded once -- the value of w * h2f(f2h(x))): 6 instructions per feature instead of 9
+      typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+      typedef float ff2 __attribute__((ext_vector_type(2)));
+      const ff2 ab = {a[f], b[f]};
+      const uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, hh2));
+      r += tc.basis[f] * (fmix0<false>(w, tc.sp.w1) + fmix0<true>(w, tc.sp.w2));
+    }
   } else {
 #pragma unroll
     for (int f = 0; f < 4; ++f) r += tc.basis[f] * h2f(f2h(hi ? b[f] : a[f]));
