@@ -323,19 +323,37 @@ __global__ void __launch_bounds__(256) hashgrid_t_fwd_kernel(GridDesc desc, cons
 // one table at a time chip-wide, the coordinate stream and the results non-temporal -- as hashgrid_fwd_levels_kernel, and for the
 // same reason: a gather that misses L2 costs the fabric a 128-byte line ON TOP of its slot in the address path, and written as 4
 // bytes per (sample, level) into 32-byte rows the output of the row kernel above is eight partial passes over every line.
+// The time coefficients of a launch -- slice pair, blend weights, the four Lagrange basis values -- computed ONCE, by one thread, into the
+// head of the workspace: evaluated per thread (one sample and level each, nothing to amortise them over) the basis' twelve IEEE
+// divisions were 130 of the level kernel's 355 instructions per wavefront.
+struct TimeHead {
+  float basis[4];
+  float w1, w2;
+  int i1, i2;
+};
+#define HG_T_HEAD_BYTES 256
+__global__ void hashgrid_t_head_kernel(const float* __restrict__ t_ptr, int n_slices, TimeHead* __restrict__ head) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float t = *t_ptr;
+  const SlicePair sp = slice_pair(t, n_slices);
+  TimeHead h;
+  lagrange4(t, h.basis);
+  h.w1 = sp.w1; h.w2 = sp.w2; h.i1 = sp.i1; h.i2 = sp.i2;
+  *head = h;
+}
 template <int D, int F>
 __global__ void __launch_bounds__(256) hashgrid_t_fwd_levels_kernel(GridDesc desc, const float* __restrict__ x, int64_t P, int x_stride, Cols cols,
-                                                                   SliceTables tabs, int n_slices, const float* __restrict__ t_ptr,
+                                                                   SliceTables tabs, const TimeHead* __restrict__ head,
                                                                    int64_t n_tiles, half_t* __restrict__ lvlT) {
   constexpr int FO = F / 4;
   const int lvl = (int)(blockIdx.x / n_tiles);
   const int64_t tile = blockIdx.x - (int64_t)lvl * n_tiles;
   const int64_t p = tile * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  const float t = *t_ptr;
-  const SlicePair sp = slice_pair(t, n_slices);
-  float basis[4];
-  lagrange4(t, basis);
+  const TimeHead th = *head;  // (uniform address: scalar loads)
+  SlicePair sp;
+  sp.i1 = th.i1; sp.i2 = th.i2; sp.w1 = th.w1; sp.w2 = th.w2;
+  const float basis[4] = {th.basis[0], th.basis[1], th.basis[2], th.basis[3]};
   float xin[D];
   load_coords_nt<D>(x, p, x_stride, cols, xin);
   const size_t off = (size_t)desc.offset[lvl] * F;
@@ -563,7 +581,7 @@ extern "C" int l4d_hashgrid_t_fwd(const l4d_grid_desc* desc, const float* x, int
 
 // level-major form (default from 2^18 points on; L4D_FLOW_LEVELS=0: the row kernel, A/B)
 extern "C" int64_t l4d_hashgrid_t_fwd_workspace(const l4d_grid_desc* desc, int64_t P) {
-  return (int64_t)desc->n_levels * P * (desc->n_features / 4) * 2;
+  return HG_T_HEAD_BYTES + (int64_t)desc->n_levels * P * (desc->n_features / 4) * 2;  // time coefficients, then the level-major columns
 }
 
 extern "C" int l4d_hashgrid_t_fwd_ws(const l4d_grid_desc* desc, const float* x, int64_t P, int32_t x_stride,
@@ -581,11 +599,14 @@ extern "C" int l4d_hashgrid_t_fwd_ws(const l4d_grid_desc* desc, const float* x, 
   Cols c = make_cols(cols, desc->n_dims);
   SliceTables tabs;
   for (int i = 0; i < L4D_MAX_SLICES; ++i) tabs.t[i] = i < n_slices ? (const half_t*)tables[i] : nullptr;
+  TimeHead* head = (TimeHead*)workspace;
+  half_t* lvlT = (half_t*)((char*)workspace + HG_T_HEAD_BYTES);
+  L4D_LAUNCH(hashgrid_t_head_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, n_slices, head);
   L4D_LAUNCH((hashgrid_t_fwd_levels_kernel<3, 8>), dim3((unsigned)(n_tiles * desc->n_levels)), dim3(256), 0, (hipStream_t)stream, g, x, P, x_stride,
-             c, tabs, n_slices, t, n_tiles, (half_t*)workspace);
+             c, tabs, (const TimeHead*)head, n_tiles, lvlT);
   const int lds = HG_ROWS_THREADS * (width + 8) * 2;
   L4D_LAUNCH((hashgrid_rows_from_levels_kernel<2>), dim3((unsigned)ceil_div64(P, HG_ROWS_THREADS)), dim3(HG_ROWS_THREADS), lds, (hipStream_t)stream,
-             desc->n_levels, P, (const half_t*)workspace, (half_t*)out, out_stride);
+             desc->n_levels, P, (const half_t*)lvlT, (half_t*)out, out_stride);
   L4D_LAUNCH_CHECK("l4d_hashgrid_t_fwd_ws");
   return 0;
 }
