@@ -79,13 +79,17 @@ __device__ __forceinline__ void pack_payload(const float v[NV], uint32_t out[(NV
 // level, summed over the launch -- [0: wavefront 0 (the scanning one), 1: the others][phase]; not compiled into the shipped library
 #ifdef BS_PHASE_CLOCK
 __device__ unsigned long long bs_phase_clk[2][18];
-extern "C" int l4d_debug_bs_phase_clk(unsigned long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(bs_phase_clk), sizeof(bs_phase_clk)) != hipSuccess) return 1;
-  if (reset) {
-    unsigned long long z[2][18] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(bs_phase_clk), z, sizeof(z)) != hipSuccess) return 1;
-  }
-  return 0;
+// (read out and reset by a kernel into DEVICE memory the caller owns -- the library issues no memcpy / memset calls: graph safety)
+__global__ void bs_phase_clk_read_kernel(unsigned long long* __restrict__ out, int reset) {
+  const int i = threadIdx.x;
+  if (i >= 36) return;
+  unsigned long long* src = &bs_phase_clk[0][0];
+  if (out) out[i] = src[i];
+  if (reset) src[i] = 0ull;
+}
+extern "C" int l4d_debug_bs_phase_clk(unsigned long long* out_dev, int reset, void* stream) {
+  bs_phase_clk_read_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out_dev, reset);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 // (sampled: wavefronts 1 -- one of the four that reserve -- 4 and 7 of every 16th workgroup -- s_memtime from every wavefront made the kernel ten times slower)
 #define BS_CLK_DECL const bool clk_on = (blockIdx.x & 15) == 0 && (threadIdx.x >> 6) % 3 == 1; uint32_t clk_acc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t clk_last = clk_on ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;

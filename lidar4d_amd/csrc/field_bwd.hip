@@ -214,13 +214,15 @@ __global__ void __launch_bounds__(PREP_THREADS) field_bwd_prep_kernel(FieldDesc 
 // sample iteration, sampled (wavefront 0 of every 8th workgroup; every wavefront reading the clock slows a kernel tenfold: binscatter.hip)
 #ifdef FB_PHASE_CLOCK
 __device__ unsigned long long fb_phase_clk[16];
-extern "C" int l4d_debug_fb_phase_clk(unsigned long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_phase_clk), sizeof(fb_phase_clk)) != hipSuccess) return 1;
-  if (reset) {
-    unsigned long long z[16] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(fb_phase_clk), z, sizeof(z)) != hipSuccess) return 1;
-  }
-  return 0;
+__global__ void fb_phase_clk_read_kernel(unsigned long long* __restrict__ out, int reset) {  // (into DEVICE memory of the caller: no memcpy calls in the library)
+  const int i = threadIdx.x;
+  if (i >= 16) return;
+  if (out) out[i] = fb_phase_clk[i];
+  if (reset) fb_phase_clk[i] = 0ull;
+}
+extern "C" int l4d_debug_fb_phase_clk(unsigned long long* out_dev, int reset, void* stream) {
+  fb_phase_clk_read_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out_dev, reset);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 #define FB_CLK_DECL const bool clk_on = (blockIdx.x & 7) == 0 && threadIdx.x < 64; uint32_t clk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t clk_last = clk_on ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
 #define FB_CLK(i) if (clk_on) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); clk_acc[i] += now_ - clk_last; clk_last = now_; }

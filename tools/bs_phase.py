@@ -39,7 +39,8 @@ for label, F, log2T, base, maxres in (("flow grid  <3,2>", 8, 18, 32, 8192),):
     fn()
     torch.cuda.synchronize()
     if have_clk:
-        lib.l4d_debug_bs_phase_clk(None, 1)
+        lib.l4d_debug_bs_phase_clk(None, 1, None)
+        torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(3):
@@ -48,9 +49,10 @@ for label, F, log2T, base, maxres in (("flow grid  <3,2>", 8, 18, 32, 8192),):
     torch.cuda.synchronize()
     print(f"{label}: P = {P}, {s.elapsed_time(e) / 3:.3f} ms per call (both passes and the expansion)")
     if have_clk:
-        out = (C.c_ulonglong * 36)()
-        lib.l4d_debug_bs_phase_clk(out, 1)
-        a = np.array(list(out), dtype=np.float64).reshape(2, 18) / 3
+        out = torch.zeros(36, dtype=torch.int64, device=dev)
+        lib.l4d_debug_bs_phase_clk(C.c_void_p(out.data_ptr()), 1, None)
+        torch.cuda.synchronize()
+        a = out.cpu().numpy().astype(np.float64).reshape(2, 18) / 3
         n_wg = ((P + 511) // 512 + 15) // 16  # sampled workgroups
         for w, nm in ((0, "wavefront 1"), (1, "wavefronts 4, 7 (mean)")):
             tot = a[w, :14].sum()

@@ -25,7 +25,8 @@ torch.cuda.synchronize()
 lib = _lib.lib()
 if not hasattr(lib, "l4d_debug_fb_phase_clk"):
     sys.exit("library without -DFB_PHASE_CLOCK")
-lib.l4d_debug_fb_phase_clk(None, 1)
+lib.l4d_debug_fb_phase_clk(None, 1, None)
+torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(steps):
@@ -33,9 +34,10 @@ for _ in range(steps):
 e.record()
 torch.cuda.synchronize()
 print(f"{s.elapsed_time(e) / steps:.3f} ms per step")
-out = (C.c_ulonglong * 16)()
-lib.l4d_debug_fb_phase_clk(out, 1)
-a = np.array(list(out), dtype=np.float64)
+out = torch.zeros(16, dtype=torch.int64, device=dev)
+lib.l4d_debug_fb_phase_clk(C.c_void_p(out.data_ptr()), 1, None)
+torch.cuda.synchronize()
+a = out.cpu().numpy().astype(np.float64)
 n_w = a[15]
 names = ["loop tail / head", "coordinates + flow arrive", "PREP: static planes' factors (taps, gvs stores)", "PREP: dynamic-hash columns", "time planes: gradient piece, frame set-up",
          "time planes: row texels loaded + interpolated", "time planes: product rule, adjoint, scans, LDS atomics", "d(flow) stored"]
