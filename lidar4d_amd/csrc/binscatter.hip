@@ -10,7 +10,8 @@
 //           reserves the run's place in list [level][bin][XCD of the workgroup] (round 6; rounds 1-5 kept every workgroup's
 //           records in its own slot, sorted by bin, plus a table of bin offsets -- pass 2 then read ~100-byte runs at 4-byte
 //           alignment out of 24,576 slots: 9.15 GB of 128-byte line fills for 4.8 GB of records at an L2 hit rate of 17 %).
-//           Coarse levels first merge runs of samples in one cell along the ray (DPP row scan, wave_dev.h).
+//           Coarse levels first merge runs of samples in one cell along the ray, over the whole wavefront (DPP: wave_dev.h wave_scan);
+//           the level maximum pass 1 reports covers those totals (pass 2 scales its fixed point by it).
 //   pass 2  (one workgroup per (level, bin)): STREAMS its bin's eight lists -- contiguous, every line read once, whole --
 //           accumulates in LDS as int64 fixed point (ds_add_u64: 2.9 T lane-ops/s, exact and order independent), and
 //           adds the segment to the fp32 gradient table with plain stores -- each segment has exactly one owner.
