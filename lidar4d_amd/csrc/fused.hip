@@ -85,6 +85,28 @@ struct SigmaOut {
   float* sigma;     // [P]
   int persistent;   // 1: gridDim.x workgroups (one per CU) whose wavefronts each walk many 64-sample groups (see the kernel)
 };
+// -DENC_PHASE_CLOCK (tools/build_abl.sh, tools/phase_probe.py enc): cycles (s_memtime) a wavefront of the fused encode spends in every part of
+// a 64-sample group, sampled (wavefront 0 of every 8th workgroup); not compiled into the shipped library
+#ifdef ENC_PHASE_CLOCK
+__device__ unsigned long long enc_phase_clk[16];
+__global__ void enc_phase_clk_read_kernel(unsigned long long* __restrict__ out, int reset) {
+  const int i = threadIdx.x;
+  if (i >= 16) return;
+  if (out) out[i] = enc_phase_clk[i];
+  if (reset) enc_phase_clk[i] = 0ull;
+}
+extern "C" int l4d_debug_enc_phase_clk(unsigned long long* out_dev, int reset, void* stream) {
+  enc_phase_clk_read_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out_dev, reset);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+#define ENC_CLK_DECL const bool clk_on = (blockIdx.x & 7) == 0 && threadIdx.x < 64; uint32_t clk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t clk_last = clk_on ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u;
+#define ENC_CLK(i) if (clk_on) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); clk_acc[i] += now_ - clk_last; clk_last = now_; }
+#define ENC_CLK_FLUSH if (clk_on && threadIdx.x == 0) { for (int i_ = 0; i_ < 15; ++i_) atomicAdd(&enc_phase_clk[i_], (unsigned long long)clk_acc[i_]); atomicAdd(&enc_phase_clk[15], 1ull); }
+#else
+#define ENC_CLK_DECL
+#define ENC_CLK(i)
+#define ENC_CLK_FLUSH
+#endif
 template <bool USE_HDT, bool ROWS, int PART = 0, int HSMODE = 0, bool SIGMA = false>
 __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __attribute__((amdgpu_waves_per_eu(PART == 2 ? ENC_WAVES_PER_EU_HASH : ENC_WAVES_PER_EU, 8))) density_encode_fwd_kernel(FieldDesc fd, const float* __restrict__ xt,
                                                                         const half_t* __restrict__ flow16,
@@ -130,7 +152,9 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
   const int64_t g_step = (int64_t)(gridDim.x >> 3) * (ENC_SIGMA_THREADS / 64);
   int64_t g_in_xcd = (int64_t)(blockIdx.x >> 3) * (ENC_SIGMA_THREADS / 64) + wave;
   const bool persistent = SIGMA && so.persistent;
+  ENC_CLK_DECL
   for (;; g_in_xcd += g_step) {
+  ENC_CLK(0)  // loop tail / head
   int64_t wave_p0_ = blk_p0 + wave * 64;
   if (persistent) {
     const int64_t grp = (int64_t)(blockIdx.x & 7) * gpx + g_in_xcd;
@@ -154,6 +178,11 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
 #pragma unroll
     for (int k = 0; k < 8; ++k) fl[k] = h2f(h[k]);
   }
+#ifdef ENC_PHASE_CLOCK
+  asm volatile("" : "+v"(fl[0]), "+v"(fl[5]));
+  { float cx = c4[0]; asm volatile("" : "+v"(cx)); }
+#endif
+  ENC_CLK(1)  // coordinates and flow arrived
   const float x0[4] = {c4[0], c4[1], c4[2], t0};
   const float x1[4] = {c4[0] + fl[0], c4[1] + fl[1], c4[2] + fl[2], t1};
   const float x2[4] = {c4[0] + fl[3], c4[1] + fl[4], c4[2] + fl[5], t2};
@@ -164,6 +193,10 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
   for (int s = 0; PART != 2 && s < nS; ++s) {
     float ps[C], d0[C], d1[C], d2[C];
     planes_group<C>(fd, s, x0, false, ps);
+#ifdef ENC_PHASE_CLOCK
+    asm volatile("" : "+v"(ps[0]), "+v"(ps[7]));
+#endif
+    ENC_CLK(8)  // (static planes of a scale: 12 taps)
     if (ROWS) {
       planes_time_group<C>(fd, prows, s, 0, x0, d0);
       if (has_fwd) planes_time_group<C>(fd, prows, s, 1, x1, d1);
@@ -179,6 +212,7 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     store8h(row + s * C, ps);
     store8h(row + (nS + s) * C, pd);
   }
+  ENC_CLK(2)  // hex-planes: static + time rows, all scales, staged
   const half_t* wstage = stage + wave * 64 * ENC_PITCH;
   auto copy_out = [&](int c0, int ncols) {  // this wave's 64 staged rows -> X[:, c0 : c0 + ncols], 16 B per lane, coalesced
     const int chunks = ncols / 8;
@@ -211,9 +245,19 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
   {
     const float xs[3] = {x0[0], x0[1], x0[2]};
     constexpr bool HSPRE = HSMODE == 1;
-    for (int lvl = 0; HSPRE && lvl < fd.hs.n_levels; ++lvl) {
+    // Eight levels' columns requested TOGETHER, then staged: written level by level the loop was compiled as two loads, a wait, two
+    // LDS stores, ... -- four HBM round trips in a row per sample group (5.6 k of a group's 89 k cycles: tools/phase_probe.py enc)
+    for (int l0 = 0; HSPRE && l0 < fd.hs.n_levels; l0 += 8) {
       typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<u32x2_t*>(row + col + lvl * 4) = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(hsT) + (int64_t)lvl * P + p);
+      u32x2_t v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)  // (a level behind the last re-reads the last one: unconditional loads, nothing waits in between)
+        v[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(hsT) + (int64_t)min(l0 + q, fd.hs.n_levels - 1) * P + p);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(v[q]));
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (l0 + q < fd.hs.n_levels) *reinterpret_cast<u32x2_t*>(row + col + (l0 + q) * 4) = v[q];
     }
     for (int lvl = 0; !HSPRE && lvl < fd.hs.n_levels; ++lvl) {
       float a[4];
@@ -227,6 +271,7 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     col += fd.hs.n_levels * 4;
   }
 
+  ENC_CLK(3)  // static grid's columns (pre-pass) loaded and staged
   // ---- dynamic HashGridT stacks at the current and the two warped neighbour frames (lidar4d.py:145,157-176) ----
   const int col_dyn0 = col;
   {
@@ -235,8 +280,20 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     for (int plane = 0; plane < 3; ++plane) {
       const int L = fd.hd[plane].n_levels;
       if (USE_HDT && plane > 0) {  // xz / yz: evaluated by dynhash_fwd_lds_kernel from LDS-resident slice tables
-        for (int lvl = 0; lvl < L; ++lvl)
-          row[col + lvl] = __builtin_bit_cast(half_t, __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(hdT) + (int64_t)(col - col_dyn0 + lvl) * P + p));
+        for (int l0 = 0; l0 < L; l0 += 8) {  // (eight columns requested together, as the static grid's above)
+          unsigned short v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            v[q] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(hdT) + (int64_t)(col - col_dyn0 + min(l0 + q, L - 1)) * P + p);
+          uint32_t w[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) w[q] = v[q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(w[q]));
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (l0 + q < L) row[col + l0 + q] = __builtin_bit_cast(half_t, (unsigned short)w[q]);
+        }
         col += L;
         continue;
       }
@@ -247,11 +304,20 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
         const PairSel ps0 = pair_sel(tc0.sp, fd.n_slices), ps1 = pair_sel(tc1.sp, fd.n_slices), ps2 = pair_sel(tc2.sp, fd.n_slices);
         const uint4* base = reinterpret_cast<const uint4*>(fd.hd_pairs[plane]);
         const size_t E = fd.hd_entries[plane];
+        // The level loop is software-pipelined: the NEXT level's frame-0 corner entries are requested before the current level is
+        // evaluated (16 registers), so that a level's gather round trip (L2: ~1.5 k cycles) runs under the previous level's three
+        // frame evaluations instead of in front of its own (tools/phase_probe.py enc: this block was 55 % of a group's cycles).
+        Cell<2> c0n = locate<2>(q0, g.scale[0]);
+        PairCorners pcn;
+        pair_fetch(base + (size_t)ps0.q * E + g.offset[0], g, 0, c0n, false, pcn);
         for (int lvl = 0; lvl < L; ++lvl) {
-          const uint4* t0p = base + (size_t)ps0.q * E + g.offset[lvl];
-          const Cell<2> c0 = locate<2>(q0, g.scale[lvl]);
-          PairCorners pc;
-          pair_fetch(t0p, g, lvl, c0, false, pc);
+          const Cell<2> c0 = c0n;
+          const PairCorners pc = pcn;
+          {
+            const int ln = min(lvl + 1, L - 1);  // (the last level requests itself once more: an unconditional request, never used)
+            c0n = locate<2>(q0, g.scale[ln]);
+            pair_fetch(base + (size_t)ps0.q * E + g.offset[ln], g, ln, c0n, false, pcn);
+          }
           const float r0 = pair_eval(pc, c0, tc0, ps0.hi);
           float r1 = r0, r2 = r0;
           if (has_fwd) {
@@ -271,6 +337,7 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
           row[col + lvl] = f2h(0.5f * r0 + 0.25f * (r1 + r2));
         }
         col += L;
+        ENC_CLK(7)  // (a stack gathered here through its pair tables: xy)
         continue;
       }
       for (int lvl = 0; lvl < L; ++lvl) {
@@ -283,6 +350,7 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     }
   }
   for (; col < in_pad; ++col) row[col] = (half_t)1.0f;  // tcnn pads the network input with ones
+  ENC_CLK(4)  // dynamic hash: xy stack gathered + evaluated, xz / yz columns loaded
 
   stage_sync();  // rows complete (and visible) before the cooperative copy-out
   if (!SIGMA) {
@@ -290,6 +358,7 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     return;
   }
   copy_out(0, in_pad);
+  ENC_CLK(5)  // row copy-out to X
   // ---- density network on the staged rows: mlp_fwd_kernel<8, 1>'s chain, four tiles of 16 rows per wavefront ----
   const int i = lane & 15, g = lane >> 4;
   auto FR = [&](int f) -> h8 { const uint4 u = reinterpret_cast<const uint4*>(stage_all)[f * 64 + lane]; return *reinterpret_cast<const h8*>(&u); };
@@ -324,9 +393,11 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
       if (g == 0) __builtin_nontemporal_store(expf(h2f(ov[0])), so.sigma + orow);
     }
   }
+  ENC_CLK(6)  // density network on the staged rows, its stores
   if (!persistent) break;
   stage_sync();  // this group's reads of the staged rows are done before the next group's rows overwrite them
   }  // groups of this wavefront
+  ENC_CLK_FLUSH
 }
 
 // ---- dynamic hash, forward, with LDS-resident slice tables ---------------------------------------------------

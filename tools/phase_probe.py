@@ -1,6 +1,7 @@
-"""Phase clocks of the time-plane adjoint (planes_dyn_lds_kernel) inside real training steps: a library built with -DFB_PHASE_CLOCK
-(tools/build_abl.sh fbclk "-DFB_PHASE_CLOCK" field_bwd.hip), a few C3 steps, the per-part share of a sampled wavefront's cycles.
-    L4D_LIB=tools/abl/lib_fbclk.so python tools/phase_probe.py [steps]"""
+"""Phase clocks of the time-plane adjoint (planes_dyn_lds_kernel, -DFB_PHASE_CLOCK in field_bwd.hip) or of the fused encode
+(density_encode_fwd_kernel, -DENC_PHASE_CLOCK in fused.hip) inside real training steps: a library built with the macro
+(tools/build_abl.sh clk "-DFB_PHASE_CLOCK -DENC_PHASE_CLOCK" field_bwd.hip fused.hip), a few C3 steps, the per-part share of a sampled
+wavefront's cycles.    L4D_LIB=tools/abl/lib_clk.so python tools/phase_probe.py [steps] [fb|enc]"""
 import ctypes as C
 import os
 import sys
@@ -14,6 +15,8 @@ from lidar4d_amd.data import KITTI360_SCALE, SyntheticKitti360  # noqa: E402
 from lidar4d_amd.trainer import Trainer  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+which = sys.argv[2] if len(sys.argv) > 2 else "fb"
+acc_name = {"fb": "l4d_debug_fb_phase_clk", "enc": "l4d_debug_enc_phase_clk"}[which]
 dev = "cuda"
 torch.manual_seed(0)
 model = LiDAR4D(near_lidar=KITTI360_SCALE, far_lidar=81 * KITTI360_SCALE, num_frames=51).to(dev)
@@ -23,9 +26,10 @@ for _ in range(3):
     tr.train_step()
 torch.cuda.synchronize()
 lib = _lib.lib()
-if not hasattr(lib, "l4d_debug_fb_phase_clk"):
-    sys.exit("library without -DFB_PHASE_CLOCK")
-lib.l4d_debug_fb_phase_clk(None, 1, None)
+if not hasattr(lib, acc_name):
+    sys.exit("library without the phase-clock macro")
+acc = getattr(lib, acc_name)
+acc(None, 1, None)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
@@ -35,13 +39,17 @@ e.record()
 torch.cuda.synchronize()
 print(f"{s.elapsed_time(e) / steps:.3f} ms per step")
 out = torch.zeros(16, dtype=torch.int64, device=dev)
-lib.l4d_debug_fb_phase_clk(C.c_void_p(out.data_ptr()), 1, None)
+acc(C.c_void_p(out.data_ptr()), 1, None)
 torch.cuda.synchronize()
 a = out.cpu().numpy().astype(np.float64)
 n_w = a[15]
+names_enc = ["loop tail / head", "coordinates + flow arrive", "hex-planes: time rows of the scales, blend, staging", "static grid's columns staged", "dynamic hash: xz / yz columns (+ the frame set-up)",
+             "row copy-out to X", "density network + its stores", "dynamic hash: xy stack (gathers + three frames' evaluation)", "hex-planes: static planes' taps of the scales"]
 names = ["loop tail / head", "coordinates + flow arrive", "PREP: static planes' factors (taps, gvs stores)", "PREP: dynamic-hash columns", "time planes: gradient piece, frame set-up",
          "time planes: row texels loaded + interpolated", "time planes: product rule, adjoint, scans, LDS atomics", "d(flow) stored"]
-tot = a[:8].sum()
+if which == "enc":
+    names = names_enc
+tot = a[:9].sum() if which == "enc" else a[:8].sum()
 print(f"sampled wavefronts: {int(n_w)} ({int(n_w / steps)} per launch), {tot / n_w:.0f} cycles each")
 for i, nm in enumerate(names):
     print(f"   {nm:58s} {100 * a[i] / tot:6.2f} %   {a[i] / n_w:10.0f}")
