@@ -76,6 +76,9 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 // The whole 128-column row is staged at once (272-byte pitch) next to the 18 weight fragments (18 KB, shared by the workgroup): eight
 // wavefronts per workgroup, one workgroup per CU (154 KB of LDS) = the two wavefronts per SIMD the registers allow anyway; the
 // wavefronts only ever touch their own rows, so staging and copy-out synchronise per wavefront, not per workgroup.
+#ifndef ENC_HS_EARLY
+#define ENC_HS_EARLY 1
+#endif
 #define ENC_SIGMA_THREADS 512
 #define ENC_SIGMA_FRAGS 18
 struct SigmaOut {
@@ -189,6 +192,16 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
   half_t* row = stage + (wave * 64 + lane) * ENC_PITCH;
   const int nS = fd.planes.n_scales;
 
+  // (HSMODE 1) the static grid's first eight columns are requested HERE, in front of the plane taps, and staged behind them: they
+  // depend on nothing but the sample index, and their HBM round trip then runs under the planes' gathers (16 registers)
+  typedef uint32_t hs_col_t __attribute__((ext_vector_type(2)));
+  hs_col_t hs_early[8];
+  if (HSMODE == 1 && ENC_HS_EARLY) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      hs_early[q] = __builtin_nontemporal_load(reinterpret_cast<const hs_col_t*>(hsT) + (int64_t)min(q, fd.hs.n_levels - 1) * P + p);
+    asm volatile("" ::: "memory");  // (the requests stay up here)
+  }
   // ---- hex-planes (planes_field.py:87-141; blend lidar4d.py:175) ----
   for (int s = 0; PART != 2 && s < nS; ++s) {
     float ps[C], d0[C], d1[C], d2[C];
@@ -250,9 +263,14 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
     for (int l0 = 0; HSPRE && l0 < fd.hs.n_levels; l0 += 8) {
       typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
       u32x2_t v[8];
+      if (ENC_HS_EARLY && l0 == 0) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q)  // (a level behind the last re-reads the last one: unconditional loads, nothing waits in between)
-        v[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(hsT) + (int64_t)min(l0 + q, fd.hs.n_levels - 1) * P + p);
+        for (int q = 0; q < 8; ++q) v[q] = hs_early[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)  // (a level behind the last re-reads the last one: unconditional loads, nothing waits in between)
+          v[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(hsT) + (int64_t)min(l0 + q, fd.hs.n_levels - 1) * P + p);
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(v[q]));
 #pragma unroll
