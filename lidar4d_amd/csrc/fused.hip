@@ -79,6 +79,9 @@ __device__ __forceinline__ void store8h(half_t* dst, const float v[8]) {
 #ifndef ENC_HS_EARLY
 #define ENC_HS_EARLY 1
 #endif
+#ifndef ENC_HD_EARLY
+#define ENC_HD_EARLY 1
+#endif
 #define ENC_SIGMA_THREADS 512
 #define ENC_SIGMA_FRAGS 18
 struct SigmaOut {
@@ -294,20 +297,42 @@ __global__ void __launch_bounds__(SIGMA ? ENC_SIGMA_THREADS : ENC_THREADS) __att
   const int col_dyn0 = col;
   {
     const TimeCoef tc0 = time_coef(t0, fd.n_slices), tc1 = time_coef(t1, fd.n_slices), tc2 = time_coef(t2, fd.n_slices);
+    // (ENC_HD_EARLY) the xz / yz stacks' first eight columns each -- produced by dynhash_fwd_lds_kernel, dependent on nothing but the
+    // sample index -- are requested in front of the xy stack's gathers and staged behind them (two columns per register)
+    uint32_t hd_early[2][4];
+    if (USE_HDT && ENC_HD_EARLY) {
+      const int L0 = fd.hd[0].n_levels;
+#pragma unroll
+      for (int pl = 1; pl < 3; ++pl) {
+        const int L = fd.hd[pl].n_levels, cb = L0 + (pl == 2 ? fd.hd[1].n_levels : 0);
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+          const unsigned short lo = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(hdT) + (int64_t)(cb + min(q, L - 1)) * P + p);
+          const unsigned short hi = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(hdT) + (int64_t)(cb + min(q + 1, L - 1)) * P + p);
+          hd_early[pl - 1][q >> 1] = (uint32_t)lo | ((uint32_t)hi << 16);
+        }
+      }
+      asm volatile("" ::: "memory");  // (the requests stay up here)
+    }
 #pragma unroll
     for (int plane = 0; plane < 3; ++plane) {
       const int L = fd.hd[plane].n_levels;
       if (USE_HDT && plane > 0) {  // xz / yz: evaluated by dynhash_fwd_lds_kernel from LDS-resident slice tables
         for (int l0 = 0; l0 < L; l0 += 8) {  // (eight columns requested together, as the static grid's above)
-          unsigned short v[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            v[q] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(hdT) + (int64_t)(col - col_dyn0 + min(l0 + q, L - 1)) * P + p);
           uint32_t w[8];
+          if (ENC_HD_EARLY && l0 == 0) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) w[q] = v[q];
+            for (int q = 0; q < 8; ++q) w[q] = (hd_early[plane - 1][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+          } else {
+            unsigned short v[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(w[q]));
+            for (int q = 0; q < 8; ++q)
+              v[q] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(hdT) + (int64_t)(col - col_dyn0 + min(l0 + q, L - 1)) * P + p);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = v[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(w[q]));
+          }
 #pragma unroll
           for (int q = 0; q < 8; ++q)
             if (l0 + q < L) row[col + l0 + q] = __builtin_bit_cast(half_t, (unsigned short)w[q]);
