@@ -42,6 +42,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 S = 0.010504329815187737  # KITTI-360 sequence scale (configs/kitti360_4950.txt:6)
 GRAD_TOL_L2, GRAD_TOL_MAX = 1.5e-2, 4e-2
+GRAD_TOL_GAIN = 3e-3  # |<g_hip, g_ref> / <g_ref, g_ref> - 1| per tensor: the systematic (scale-like) part of the error
 LAST = {}  # render_both leaves the total loss scale of its HIP backward here
 
 
@@ -50,7 +51,7 @@ def scale_err(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-def compare_grads(ref, hip, tol=GRAD_TOL_L2, tol_max=GRAD_TOL_MAX):
+def compare_grads(ref, hip, tol=GRAD_TOL_L2, tol_max=GRAD_TOL_MAX, tol_gain=GRAD_TOL_GAIN):
     """Elementwise comparison of every parameter gradient; returns the list of failures and prints a table."""
     fails, rows = [], []
     hip_named = dict(hip.named_parameters())
@@ -70,15 +71,20 @@ def compare_grads(ref, hip, tol=GRAD_TOL_L2, tol_max=GRAD_TOL_MAX):
         e_max = float((a - b).abs().max()) / scale
         e_l2 = float((a - b).norm() / b.norm())
         missed = int(((b.abs() > 1e-3 * scale) & (a == 0)).sum())
-        rows.append((name, a.numel(), e_max, e_l2, missed))
-        if not (e_max <= tol_max and e_l2 <= tol and missed == 0):
-            fails.append((name, e_max, e_l2, missed))
+        # systematic part of the error ("a 1 % bias in one table would pass the elementwise bound"): the HIP
+        # gradient projected on the oracle's, <a, b> / <b, b> - 1.  Rounding noise is (nearly) orthogonal to b and leaves this at
+        # e_l2 / sqrt(n); a wrong scale, a dropped neighbour frame's share or a mis-weighted corner shows up here in full.
+        gain = float((a * b).sum() / (b * b).sum()) - 1.0
+        rows.append((name, a.numel(), e_max, e_l2, missed, gain))
+        if not (e_max <= tol_max and e_l2 <= tol and missed == 0 and abs(gain) <= tol_gain):
+            fails.append((name, e_max, e_l2, missed, gain))
     worst = max(rows, key=lambda r: r[2])
+    wg = max(rows, key=lambda r: abs(r[5]))
     print(f"  {len(rows)} gradient tensors compared elementwise; worst max-error {worst[2]:.2e} ({worst[0]}), "
-          f"worst L2 error {max(r[3] for r in rows):.2e}")
+          f"worst L2 error {max(r[3] for r in rows):.2e}, worst projected gain error {wg[5]:+.2e} ({wg[0]})")
     for r in rows:
-        if r[2] > 0.2 * tol or r[3] > 0.2 * tol:
-            print(f"    {r[0]:48s} n={r[1]:9d} max {r[2]:.2e} l2 {r[3]:.2e} missed {r[4]}")
+        if r[2] > 0.2 * tol or r[3] > 0.2 * tol or abs(r[5]) > 0.2 * tol_gain:
+            print(f"    {r[0]:48s} n={r[1]:9d} max {r[2]:.2e} l2 {r[3]:.2e} missed {r[4]} gain {r[5]:+.2e}")
     return fails
 
 
