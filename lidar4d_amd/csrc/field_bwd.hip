@@ -674,14 +674,20 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
                                                          const float* __restrict__ stats, float* __restrict__ Hbuf) {
   extern __shared__ long long lds_l[];
   const int task = blockIdx.y;
-  const int plane = tasks.plane[task], lvl = tasks.lvl[task], lo = tasks.lo[task], cnt = tasks.cnt[task];
+  const int plane = tasks.plane[task], lvl = tasks.lvl[task], cnt = tasks.cnt[task];
+  // lo >= 0: the task owns entries [lo, lo + cnt).  lo < 0 (PARITY, hashed power-of-two levels of twice the window): the task owns
+  // the entries of parity par = -1 - lo, slot = entry >> 1; its part of Hbuf is parity-major: [par * cnt + slot] (dynhash_expand_kernel)
+  const bool parity = tasks.lo[task] < 0;
+  const uint32_t par = parity ? (uint32_t)(-1 - tasks.lo[task]) : 0u;
+  const int lo = parity ? 0 : tasks.lo[task];
+  const int hbase = tasks.hoff[task] + (parity ? (int)par * cnt : lo);
   const GridDesc& g = fd.hd[plane];
   int cidx = lvl;
   for (int q = 0; q < plane; ++q) cidx += fd.hd[q].n_levels;
   const float gmax = stats[ST_DYN_MAX + cidx];
   if (!(gmax > 0.0f)) return;  // no gradient reaches this level at all
   if (nonfinite(gmax)) {       // overflowed upstream gradient: hand it on (expanded into both slices' gradients)
-    if (blockIdx.x == 0 && threadIdx.x == 0) Hbuf[tasks.hoff[task] + lo] = __builtin_nanf("");
+    if (blockIdx.x == 0 && threadIdx.x == 0) Hbuf[hbase] = __builtin_nanf("");
     return;
   }
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) lds_l[i] = 0;
@@ -693,8 +699,14 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
   const bool hashed = (g.hashed_mask >> lvl) & 1u;
   const half_t* gcol = gdynT + (int64_t)cidx * P;
   const int64_t lo_p = (int64_t)blockIdx.x * chunk, hi_p = min(P, lo_p + chunk);
-  auto walk = [&](auto fast_tag) {  // FAST: hashed level with a power-of-two table (block-uniform; hashgrid_dev.h grid_index_fast)
+  // PAR: on a hashed power-of-two level the entry index is (x ^ y * PRIME1) & mask with PRIME1 odd, so its lowest bit is (x ^ y) & 1:
+  // of a cell's four corners exactly TWO have each parity -- (0, 0) and (1, 1), or (1, 0) and (0, 1).  A task that owns one parity
+  // of the table therefore evaluates two corners per sample, both of them its own, where a task that owns an index RANGE evaluates
+  // all four and drops half of them on average: the xy stack's levels (two windows each) cost 2 x 2 corner evaluations per sample
+  // instead of 2 x 4.  Same contributions, same fixed point, integer accumulation: bit-identical gradients.
+  auto walk = [&](auto fast_tag, auto par_tag) {  // FAST: hashed level with a power-of-two table (block-uniform; hashgrid_dev.h grid_index_fast)
     constexpr bool FAST = decltype(fast_tag)::value;
+    constexpr bool PAR = decltype(par_tag)::value;
     // DH_UNROLL samples per lane and iteration, ALL their loads issued before the first use: at the four wavefronts per SIMD that a
     // 1,024-thread workgroup with 128 KB of LDS leaves, a load -> use -> load chain paid one memory latency (~1 us under load) per
     // sample and wavefront -- the kernel ran at twice its issue floor (profiles/r04_floor_table.md).  Integer accumulation: the
@@ -720,6 +732,16 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
         if (go == 0.0f) continue;
         const float q[2] = {qa[u], qb[u]};
         Cell<2> c = locate<2>(q, scale);
+        if (PAR) {
+          const uint32_t sy = (c.cell[0] ^ c.cell[1] ^ par) & 1u;  // corners (0, sy) and (1, 1 - sy) have this task's parity
+          const float wx0 = 1.0f - c.frac[0], wx1 = c.frac[0], wy0 = 1.0f - c.frac[1], wy1 = c.frac[1];  // (corner(): 1.0f * wx * wy)
+          const float wa = wx0 * (sy ? wy1 : wy0), wb = wx1 * (sy ? wy0 : wy1);
+          const uint32_t ga[2] = {c.cell[0], c.cell[1] + sy}, gb[2] = {c.cell[0] + 1u, c.cell[1] + 1u - sy};
+          const uint32_t ia = grid_index_fast<2>(ga, size - 1u) >> 1, ib = grid_index_fast<2>(gb, size - 1u) >> 1;
+          atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[ia]), (unsigned long long)(long long)fx_round(go * wa * fxs));
+          atomicAdd(reinterpret_cast<unsigned long long*>(&lds_l[ib]), (unsigned long long)(long long)fx_round(go * wb * fxs));
+          continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           uint32_t gv[2];
@@ -730,11 +752,12 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
       }
     }
   };
-  if (hashed && is_pow2(size)) walk(std::true_type{});
-  else walk(std::false_type{});
+  if (parity) walk(std::true_type{}, std::true_type{});  // (the host side asks for it on hashed power-of-two levels only)
+  else if (hashed && is_pow2(size)) walk(std::true_type{}, std::false_type{});
+  else walk(std::false_type{}, std::false_type{});
   __syncthreads();
   const double inv = 1.0 / (double)fxs;
-  float* H = Hbuf + tasks.hoff[task] + lo;
+  float* H = Hbuf + hbase;
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
     const long long v = lds_l[i];
     if (v != 0) atomicAdd(H + i, (float)((double)v * inv));
@@ -743,12 +766,15 @@ __global__ void __launch_bounds__(1024) dynhash_lds_kernel(FieldDesc fd, HashTas
 
 // grad[slice i1][entry][f] += w1 * basis[f] * H[entry] * pscale (and i2 with w2): hash_field.py:65-88 adjoint
 __global__ void __launch_bounds__(256) dynhash_expand_kernel(FieldDesc fd, FieldGrads fg, const float* __restrict__ tinfo,
-                                                            const float* __restrict__ Hbuf, int plane, int hoff0, float pscale) {
+                                                            const float* __restrict__ Hbuf, int plane, int hoff0, float pscale,
+                                                            uint32_t parity_levels) {
   const GridDesc& g = fd.hd[plane];
   const int lvl = blockIdx.y;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.size[lvl]) return;
-  const float h = Hbuf[hoff0 + g.offset[lvl] + i] * pscale;
+  // (levels the LDS kernel walked by entry parity keep their part of Hbuf parity-major: [parity][entry >> 1])
+  const uint32_t hi = (parity_levels >> lvl) & 1u ? (i & 1u) * (g.size[lvl] >> 1) + (i >> 1) : i;
+  const float h = Hbuf[hoff0 + g.offset[lvl] + hi] * pscale;
   if (h == 0.0f) return;
   const TimeCoef tc = time_coef(tinfo[0], fd.n_slices);
   float4_t* a = reinterpret_cast<float4_t*>(fg.hd_tables[plane][tc.sp.i1] + ((size_t)g.offset[lvl] + i) * 4);
@@ -958,6 +984,9 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     // and every part streams all samples again.  Those levels get a launch of their own with 128 KB parts (one workgroup per CU,
     // half the passes: measured 1.51 -> 1.46 ms against 64 KB parts, gpurun_out/r4f); the levels that fit 64 KB keep two workgroups per CU.
     constexpr int big_kb = 128;
+    uint32_t parity_levels[3] = {0u, 0u, 0u};
+    static int dh_parity = -1;  // (read once, like the library's other A/B switches)
+    if (dh_parity < 0) { const char* e = getenv("L4D_DH_PARITY"); dh_parity = (e && e[0] == '0') ? 0 : 1; }
     for (int group = 0; group < 2; ++group) {  // 0: levels that fit DYNHASH_LDS_KB; 1: larger ones
       const int lds_kb = group == 0 ? DYNHASH_LDS_KB : big_kb;
       const int max_entries = (lds_kb * 1024) / 8, fit = (DYNHASH_LDS_KB * 1024) / 8;
@@ -967,6 +996,18 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
         for (int l = 0; l < d.hd[p].n_levels; ++l) {
           const int size = (int)d.hd[p].size[l];
           if ((size <= fit) != (group == 0)) continue;
+          // a hashed power-of-two level of exactly two windows: one task per entry PARITY (two corners per sample each) instead of
+          // one per index range (four each); L4D_DH_PARITY=0: the range form (A/B switch, tests/test_gpu_switches.py)
+          if (dh_parity && size == 2 * max_entries && is_pow2((uint32_t)size) && ((d.hd[p].hashed_mask >> l) & 1u)) {
+            for (int par = 0; par < 2; ++par) {
+              if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many hash tasks"); return fail(1); }
+              t.plane[t.n] = p; t.lvl[t.n] = l; t.lo[t.n] = -1 - par; t.cnt[t.n] = size / 2;
+              t.hoff[t.n] = hoff_plane[p] + (int)d.hd[p].offset[l];
+              ++t.n;
+            }
+            parity_levels[p] |= 1u << l;
+            continue;
+          }
           for (int lo = 0; lo < size; lo += max_entries) {
             if (t.n >= MAX_TASKS) { l4d_set_error(1, "l4d_density_encode_bwd: too many hash tasks"); return fail(1); }
             t.plane[t.n] = p; t.lvl[t.n] = l; t.lo[t.n] = lo; t.cnt[t.n] = std::min(max_entries, size - lo);
@@ -982,7 +1023,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
       unsigned max_size = 0;
       for (int l = 0; l < d.hd[p].n_levels; ++l) max_size = std::max(max_size, d.hd[p].size[l]);
       L4D_LAUNCH(dynhash_expand_kernel, dim3((max_size + 255) / 256, d.hd[p].n_levels), dim3(256), 0, s_lds, d, fg, tinfo,
-                         Hbuf, p, hoff_plane[p], param_scale);
+                         Hbuf, p, hoff_plane[p], param_scale, parity_levels[p]);
     }
   }
   L4D_LAUNCH_CHECK("l4d_density_encode_bwd");

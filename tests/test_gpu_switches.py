@@ -58,7 +58,7 @@ def default_digest():
 
 
 @pytest.mark.parametrize("switch", ["L4D_ENC_HS_SPLIT=0", "L4D_HS_PAIRLD=0", "L4D_HG_ORDER=0", "L4D_FLOW_LEVELS=0", "L4D_ENC_SIGMA=0",
-                                    "L4D_ENC_PERSISTENT=0", "L4D_MLP_RECOMP_SIGMA=0", "L4D_ENC_HS_SPLIT=0,L4D_HS_PAIRLD=0"])
+                                    "L4D_ENC_PERSISTENT=0", "L4D_MLP_RECOMP_SIGMA=0", "L4D_DH_PARITY=0", "L4D_ENC_HS_SPLIT=0,L4D_HS_PAIRLD=0"])
 def test_switch_reproduces_the_default_path(switch, default_digest):
     got = _run(dict(kv.split("=") for kv in switch.split(",")))
     assert got["finite"] and default_digest["finite"]
