@@ -182,6 +182,7 @@ def kernel_models(model, P, M):
     m["planes_dyn_lds_kernel<true, false>"] = m["planes_dyn_lds_kernel<false, false>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32) * P, note="xt + flow + dX rows (128-B lines) read, d(flow) written; LDS int32 accumulation")
     m["planes_dyn_lds_kernel<true, true>"] = dict(bound="hbm", bytes=(16 + 32 + X + 32 + 3 * nS * 16 + 2 * n_dyn + 12) * P,
                                                   note="the same + the preparation pass' outputs (static-plane factors, transposed dyn gradient, SoA coordinates) from the one read of the dX rows")
+    m["planes_dyn_lds_wide_kernel"] = m["planes_dyn_lds_kernel<true, true>"]  # (more than 24 dynamic-hash columns: the C2-shaped model)
     m["planes_static_lds_kernel"] = dict(bound="hbm", bytes=(3 * nS * 16 + 3 * nS * 8) * P, note="plane-major factors read once per (scale, plane)")
     m["dynhash_lds_kernel"] = dict(bound="hbm", bytes=(2 * n_dyn + n_dyn * 8) * P, per_step=True,
                                    note="transposed gradient + 2 coordinates per (plane, level) pass; two launches per step (levels that fit a 64 KB window / larger ones), modelled together")

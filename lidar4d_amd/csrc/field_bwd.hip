@@ -248,12 +248,14 @@ struct PrepOut {
   float* stats;
   float* segb;
 };
-template <bool ROWS, bool PREP>
-__global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
-                                                            const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
-                                                            int64_t P, int64_t chunk, const half_t* __restrict__ dX,
-                                                            int in_pad, float pscale, const float* __restrict__ stats,
-                                                            half_t* __restrict__ dflow16, PlaneRows prows, PrepOut po) {
+// DYN_BATCHES: (PREP) batches of three 16-byte pieces that hold the row's dynamic-hash columns: 1 = up to 24 columns (the default model:
+// 3 x 8 levels), 2 = up to 48 (16 levels per stack: the C2-shaped model) -- a compile-time count so that the default kernel stays what it is
+template <bool ROWS, bool PREP, int DYN_BATCHES>
+__device__ __forceinline__ void planes_dyn_lds_body(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
+                                                    const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
+                                                    int64_t P, int64_t chunk, const half_t* __restrict__ dX,
+                                                    int in_pad, float pscale, const float* __restrict__ stats,
+                                                    half_t* __restrict__ dflow16, PlaneRows prows, PrepOut po) {
   // value arithmetic of THIS function body may contract a * b + c into one fma (texel interpolation, the coordinate adjoint's dot
   // products): gradient values move in their last bit; cell / texel indices come from axis_tap (planes_dev.h), which is
   // compiled under the file-wide -ffp-contract=off and still rounds like the forward pass
@@ -376,19 +378,21 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
       const half2_t c0h = {(half_t)c0, (half_t)c0};
       // (the three 16-byte pieces are requested together -- a piece behind the last level re-reads piece 0 and is skipped below:
       // requested one by one, each in front of its own use, they were three memory round trips in a row per iteration)
+#pragma unroll
+      for (int qb = 0; qb < DYN_BATCHES; ++qb) {
       uint4 ud[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) ud[q] = *reinterpret_cast<const uint4*>(row + colD + (q * 8 < L3 ? q * 8 : 0));
+      for (int q = 0; q < 3; ++q) ud[q] = *reinterpret_cast<const uint4*>(row + colD + ((qb * 3 + q) * 8 < L3 ? (qb * 3 + q) * 8 : 0));
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        if (q * 8 < L3) {  // uniform
+        if ((qb * 3 + q) * 8 < L3) {  // uniform
           const uint4 u = ud[q];
           const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const half2_t hv = __builtin_bit_cast(half2_t, w4[k]) * c0h;
             const uint32_t wv = active ? __builtin_bit_cast(uint32_t, hv) : 0u;
-            const int c = q * 8 + 2 * k;
+            const int c = (qb * 3 + q) * 8 + 2 * k;
             if (active) {
               po.gdynT[(int64_t)c * P + p] = hv[0];
               po.gdynT[(int64_t)(c + 1) * P + p] = hv[1];
@@ -399,6 +403,7 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
           }
         }
       }
+      }  // batches of three pieces
     }
     FB_CLK(3)  // PREP: dynamic-hash columns transposed
     float gflow[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // d/d(x1), d/d(x2): x1 = x + flow[:3], x2 = x + flow[3:]
@@ -541,6 +546,22 @@ __global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc 
     }
   }
 #undef lds_off
+}
+template <bool ROWS, bool PREP>
+__global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
+                                                            const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
+                                                            int64_t P, int64_t chunk, const half_t* __restrict__ dX,
+                                                            int in_pad, float pscale, const float* __restrict__ stats,
+                                                            half_t* __restrict__ dflow16, PlaneRows prows, PrepOut po) {
+  planes_dyn_lds_body<ROWS, PREP, 1>(fd, garena, xt, flow16, tinfo, P, chunk, dX, in_pad, pscale, stats, dflow16, prows, po);
+}
+// the same with the preparation pass for up to 48 dynamic-hash columns (16 levels per stack)
+__global__ void __launch_bounds__(PDYN_THREADS) planes_dyn_lds_wide_kernel(FieldDesc fd, float* __restrict__ garena, const float* __restrict__ xt,
+                                                                 const half_t* __restrict__ flow16, const float* __restrict__ tinfo,
+                                                                 int64_t P, int64_t chunk, const half_t* __restrict__ dX,
+                                                                 int in_pad, float pscale, const float* __restrict__ stats,
+                                                                 half_t* __restrict__ dflow16, PlaneRows prows, PrepOut po) {
+  planes_dyn_lds_body<true, true, 2>(fd, garena, xt, flow16, tinfo, P, chunk, dX, in_pad, pscale, stats, dflow16, prows, po);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -878,7 +899,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   // With the largest |dX| of the time-plane columns known beforehand (gd_absmax, from the sigma network's backward) the prep
   // kernel's work is done by the time-plane kernel itself (planes_dyn_lds_kernel<.., PREP = true>).
   const int colsA_ = 2 * d.planes.n_scales * 8, colD_ = colsA_ + d.hs.n_levels * 4;
-  const bool fused_prep = gd_absmax && plane_rows && colD_ % 8 == 0 && L3 % 8 == 0 && L3 <= 24 && in_pad % 8 == 0;
+  const bool fused_prep = gd_absmax && plane_rows && colD_ % 8 == 0 && L3 % 8 == 0 && L3 <= 48 && in_pad % 8 == 0;
   const bool prep_side = false;  // (the preparation kernel on the side stream of its consumers: measured no gain in round 4, switch removed)
   if (fused_prep || prep_side) {
     l4d_copy_words_async(stats + ST_GD_MAX, gd_absmax, 1, stream);
@@ -930,7 +951,11 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
     const PrepOut po{gvs, gdynT, xsoa, stats, wave_skip ? segb : nullptr};  // (read only under wave_skip; chunks of another size do not start on segments)
     if (plane_rows) {
       L4D_LAUNCH(plane_time_rows_kernel, dim3(2, d.planes.n_scales * 3, TROWS_FRAMES), dim3(256), 0, stream, d, pr, tinfo, plane_rows);
-      if (fused_prep) {
+      if (fused_prep && L3 > 24) {
+        (void)hipFuncSetAttribute((const void*)planes_dyn_lds_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        L4D_LAUNCH(planes_dyn_lds_wide_kernel, dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
+                   P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr, po);
+      } else if (fused_prep) {
         (void)hipFuncSetAttribute((const void*)planes_dyn_lds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         L4D_LAUNCH((planes_dyn_lds_kernel<true, true>), dim3(n_chunks), dim3(PDYN_THREADS), lds, stream, d, fg.planes_cl, xt, (const half_t*)flow16, tinfo,
                    P, chunk, (const half_t*)dX, in_pad, param_scale, stats, (half_t*)dflow16, pr, po);

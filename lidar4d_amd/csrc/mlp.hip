@@ -881,8 +881,8 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
                            int32_t n_hidden, const void* weights, void* dx, float* grad_w, float inv_loss_scale,
                            float* dx_absmax, int32_t absmax_col_lo, int32_t absmax_col_hi, void* stream) {
   if (P == 0) return 0;
-  if (dx_absmax && (absmax_col_lo % 16 || absmax_col_hi % 16 || absmax_col_lo < 0 || absmax_col_hi > in_pad || !dx || in_pad > 128)) {
-    l4d_set_error(1, "l4d_mlp_bwd: dx_absmax needs dx, in_pad <= 128 and a column range in multiples of 16 inside [0, in_pad]");
+  if (dx_absmax && (absmax_col_lo % 16 || absmax_col_hi % 16 || absmax_col_lo < 0 || absmax_col_hi > in_pad || !dx)) {
+    l4d_set_error(1, "l4d_mlp_bwd: dx_absmax needs dx and a column range in multiples of 16 inside [0, in_pad]");
     return 1;
   }
   const DxStat dstat{dx_absmax, absmax_col_lo / 16, absmax_col_hi / 16};
@@ -918,10 +918,10 @@ extern "C" int l4d_mlp_bwd(const void* x, const void* act, const void* dy, int64
   if (!done && in_pad % 16 == 0 && in_tiles == IT && n_hidden == NHH) {                                              \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 0, 6, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,          \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                              \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1}, no_epi, dstat);   \
     L4D_LAUNCH((mlp_bwd_kernel<IT, NHH, 6, IT, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
                        (const half_t*)x, (const half_t*)act, (const half_t*)dy, P, n_rows, (const half_t*)weights,   \
-                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1});                                              \
+                       (half_t*)dx, grad_w, inv_loss_scale, AttrSrc{nullptr, nullptr, nullptr, 1, 0, -1}, no_epi, dstat);   \
     done = true;                                                                                                     \
   }
   FOR_EACH_WIDE_CFG(X)

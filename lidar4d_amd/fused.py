@@ -221,7 +221,7 @@ class RenderFn(torch.autograd.Function):
         # (the backward reports max |dX| of the time-plane columns as it stores them: the field adjoint's fixed-point scale)
         pe = model.planes_encoder
         n_pl = pe.layout.n_scales * pe.layout.C
-        gd_absmax = torch.zeros(1, dtype=torch.float32, device=dev) if (n_pl % 16 == 0 and X.shape[1] <= 128) else None  # (wider rows: two launches)
+        gd_absmax = torch.zeros(1, dtype=torch.float32, device=dev) if n_pl % 16 == 0 else None  # (rows wider than 128: two launches, each reports the tiles it stores)
         dX = ops.mlp_bwd(X, act_s, dh, store.half(model.sigma_net.params), model.sigma_net.n_hidden_layers,
                          store.grad_view(model.sigma_net.params), inv, dx_absmax=gd_absmax, absmax_cols=(n_pl, 2 * n_pl))
         # field
