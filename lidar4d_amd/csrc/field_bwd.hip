@@ -234,6 +234,9 @@ extern "C" int l4d_debug_fb_phase_clk(unsigned long long* out_dev, int reset, vo
 #endif
 // lanes a run of equal texels is merged over before the LDS atomics (16 = a whole DPP row: 4 scan steps per value; 8: 3 steps)
 #define PDYN_MERGE 16
+#ifndef LDS_PASS_CHUNK_MIN
+#define LDS_PASS_CHUNK_MIN 32768  // the multi-pass LDS kernels take at most P / this many chunks: every workgroup zeroes and flushes its whole window (8192 until round 6: at 1,024 rays static planes 0.20 -> 0.17 ms, dynamic hash 0.16 -> 0.11; C2 0.51 -> 0.49 / 0.62 -> 0.58; C3 has 128 chunks either way)
+#endif
 #define PSTAT_MERGE 16
 #define PDYN_THREADS 768  // 12 waves on the one workgroup a CU can hold (138 KB of LDS; 155 VGPRs allow 3 per SIMD): 3.00 -> 2.73 ms against 512
 // PREP: the kernel also does the prep kernel's work for its samples -- static planes' product-rule factors gvs, the transposed
@@ -931,7 +934,7 @@ extern "C" int l4d_density_encode_bwd(const l4d_field_desc* f, const l4d_field_g
   // the multi-pass LDS kernels may cut the samples into fewer, larger chunks than the time-plane kernel (whose grid IS the chunks):
   // every workgroup flushes its whole LDS window once, so fewer chunks = less flush traffic
   auto chunks_for = [&](int n, int* n_out) -> int64_t {
-    n = (int)std::min<int64_t>(n, std::max<int64_t>(1, ceil_div64(P, 8192)));
+    n = (int)std::min<int64_t>(n, std::max<int64_t>(1, ceil_div64(P, LDS_PASS_CHUNK_MIN)));
     int64_t c = ceil_div64(ceil_div64(P, n), 64) * 64;  // whole 64-sample segments
     *n_out = (int)ceil_div64(P, c);
     return c;
