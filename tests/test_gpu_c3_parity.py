@@ -74,7 +74,7 @@ def compare_grads(ref, hip, tol=GRAD_TOL_L2, tol_max=GRAD_TOL_MAX, tol_gain=GRAD
         # systematic part of the error ("a 1 % bias in one table would pass the elementwise bound"): the HIP
         # gradient projected on the oracle's, <a, b> / <b, b> - 1.  Rounding noise is (nearly) orthogonal to b and leaves this at
         # e_l2 / sqrt(n); a wrong scale, a dropped neighbour frame's share or a mis-weighted corner shows up here in full.
-        # (Measured: within 2.4e-4 on the hash tables, -2.0e-3 at worst on a coarsest-scale plane -- thousands of samples per texel, the
+        # (Measured: within 1.3e-3 on the hash tables, -2.0e-3 at worst on a coarsest-scale plane -- thousands of samples per texel, the
         # smallest of whose fp16 adjoints underflow: the one direction fp16 rounding is not symmetric in.)
         gain = float((a * b).sum() / (b * b).sum()) - 1.0
         rows.append((name, a.numel(), e_max, e_l2, missed, gain))
